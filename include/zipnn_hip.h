@@ -1,0 +1,108 @@
+/*
+ * zipnn_hip.h — C ABI of libzipnn_hip.so, the MI355X (gfx950) implementation of
+ * ZipNN's compress/decompress hot path.
+ *
+ * This is the drop-in boundary.  In the reference the boundary is the CPython
+ * extension `zipnn_core` (csrc/zipnn_core_module.c:9-23) with two functions:
+ *
+ *   zipnn_core.zipnn_core(header, data, numBuf, bits_mode, bytes_mode, is_redata,
+ *                         origChunkSize, compThreshold, checkThAfterPercent, threads)
+ *                                                  csrc/zipnn_core.c:401-702, called at zipnn/zipnn.py:714-725
+ *   zipnn_core.combine_dtype(data_after_header, numBuf, bits_mode, bytes_mode,
+ *                            origChunkSize, origSize, threads)
+ *                                                  csrc/zipnn_core.c:881-1164, called at zipnn/zipnn.py:1143-1151
+ *
+ * zn_compress() / zn_decompress() below take exactly those arguments (minus the dead
+ * ones: is_redata, checkThAfterPercent, threads — SURVEY.md Appendix D) as plain
+ * pointers and sizes, and produce / consume exactly the same bytes (wire format:
+ * SURVEY.md Appendix A).  The *_dev variants are the same operations on buffers that
+ * already live in HBM (what bench.py times, and what a device-aware safetensors
+ * loader calls).  No torch types, no exceptions, no longjmp: every function returns
+ * 0 or a negative zn_status and never touches the caller's input buffers (the
+ * reference rotates its input in place, csrc/data_manipulation_dtype16.c:68 — we
+ * deliberately do not).
+ *
+ * Parameters shared by all entry points
+ *   num_buf     1 (fp8), 2 (bf16/fp16), 4 (fp32)            zipnn/zipnn.py:786-815
+ *   bits_mode   1 = sign-bit rotate (bf16/fp32), 0 = none   csrc/data_manipulation_dtype16.c:10-29, dtype32.c:39-58
+ *   bytes_mode  10 for num_buf 1/2, 220 for num_buf 4        csrc/data_manipulation_dtype16.c:77, dtype32.c:219-268
+ *   chunk       origChunkSize in bytes (power of two; callers pass min(128 KiB, chunk)
+ *               for num_buf == 1, zipnn/zipnn.py:721,1148)
+ *   threshold   compThreshold: a plane is kept Huffman-coded iff
+ *               0 < csize < plane_len * (double)threshold    csrc/zipnn_core.c:371-373
+ */
+#ifndef ZIPNN_HIP_H
+#define ZIPNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum zn_status {
+  ZN_OK = 0,
+  ZN_E_ARG = -1,      /* bad argument (unsupported num_buf/bytes_mode, chunk == 0, ...) */
+  ZN_E_HIP = -2,      /* a HIP runtime call failed; zn_last_hip_error() has the text */
+  ZN_E_CAP = -3,      /* destination capacity too small */
+  ZN_E_CORRUPT = -4,  /* compressed body is malformed (sizes, huff0 header, streams) */
+  ZN_E_TYPE = -5,     /* a chunk-type byte is not 0/1 (reference: MemoryError "Compress Type is not correct", zipnn_core.c:993-996) */
+  ZN_E_NODEV = -6,    /* no usable GPU */
+  ZN_E_ALLOC = -7     /* device/host allocation failed */
+} zn_status;
+
+/* ABI version of this header (bumped on incompatible change). */
+int zn_abi_version(void);
+const char* zn_strerror(int status);
+/* Text of the last failing HIP call on this thread ("" if none). */
+const char* zn_last_hip_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int zn_device_count(void);
+
+/* numChunks = ceil(n / chunk)                                   csrc/zipnn_core.c:420,893 */
+size_t zn_num_chunks(size_t n, size_t chunk);
+/* Upper bound of a frame: hdr_len + 9*num_buf*numChunks + n     csrc/zipnn_core.c:105-118 */
+size_t zn_compress_bound(size_t n, int num_buf, size_t chunk, size_t hdr_len);
+
+/* ---- host-buffer entry points (replace the two zipnn_core functions) ---- */
+
+/* dst <- hdr ‖ types[P][K] ‖ cumSizes[P][K] (u64) ‖ payload (plane-major); when
+ * hdr_len >= 32 the total frame length is written to dst[24:32] (zipnn_core.c:121).
+ * `hdr`/`src`/`dst` are host pointers; the call stages through HBM on `device`. */
+int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf,
+                int bits_mode, int bytes_mode, size_t chunk, float threshold, int device,
+                void* dst, size_t dst_cap, size_t* dst_len);
+
+/* body = frame minus (32-byte header + shape ext-header); dst receives orig_size bytes. */
+int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode,
+                  size_t chunk, size_t orig_size, int device, void* dst);
+
+/* ---- device-resident entry points (inputs and outputs already in HBM) ---- */
+
+/* d_src: n bytes on the current device.  d_body (capacity body_cap >=
+ * zn_compress_bound(n, num_buf, chunk, 0)) receives types ‖ cumSizes ‖ payload; its
+ * length is returned in *body_len (one 8-byte device→host read).  `stream` is a
+ * hipStream_t (NULL = the null stream); work is enqueued on it and the call returns
+ * after the length has been read back. */
+int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                    size_t chunk, float threshold, void* d_body, size_t body_cap,
+                    size_t* body_len, void* stream);
+
+/* d_body: body_len bytes on the current device; d_dst receives orig_size bytes.
+ * Asynchronous on `stream` unless `check` is non-zero, in which case the call
+ * synchronises and returns ZN_E_CORRUPT / ZN_E_TYPE if a kernel flagged bad input. */
+int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode,
+                      int bytes_mode, size_t chunk, size_t orig_size, void* d_dst, void* stream,
+                      int check);
+
+/* Frees the per-device workspaces this library caches (scratch planes, size tables). */
+int zn_release_workspace(void);
+
+/* Names of the kernels the last *_dev call launched, ';'-separated (for profiles). */
+const char* zn_last_kernels(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZIPNN_HIP_H */

@@ -26,3 +26,29 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---------------------------------------------------------------------------------------
+# SIMT-emulated build of the kernels (tests/simt): lets the CPU suite execute the product's
+# kernel sources and host logic where no GPU exists.  Test infrastructure only — the
+# product never loads it (zipnn_amd._capi.lib() only opens libzipnn_hip.so).
+# ---------------------------------------------------------------------------------------
+@pytest.fixture(scope="session")
+def simt_lib():
+    import glob
+    import subprocess
+    from zipnn_amd._capi import ZnLib
+    here = os.path.join(ROOT, "tests", "simt")
+    so = os.path.join(here, "libzipnn_simt.so")
+    srcs = glob.glob(os.path.join(ROOT, "zipnn_amd", "csrc", "*")) + [os.path.join(here, "hip", "hip_runtime.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run(["sh", os.path.join(here, "build.sh")], check=True, capture_output=True)
+    return ZnLib(so)
+
+
+@pytest.fixture()
+def use_simt(simt_lib, monkeypatch):
+    """Route zipnn_amd through the emulated kernels for one test (CPU tensors as 'device' memory)."""
+    import zipnn_amd._capi as capi
+    monkeypatch.setattr(capi, "_LIB", simt_lib)
+    return simt_lib

@@ -1,0 +1,249 @@
+// tests/simt/hip/hip_runtime.h — TEST INFRASTRUCTURE ONLY.
+//
+// A tiny single-threaded SIMT emulator that stands in for <hip/hip_runtime.h> when the
+// product's kernel sources (zipnn_amd/csrc/*.hip) are compiled with g++ for the CPU
+// test-suite (tests/simt/build.sh → tests/simt/libzipnn_simt.so).  There is no GPU in the
+// build container, so this is how kernel *logic* (wave ballots/shuffles, LDS staging,
+// barriers, bit packing) is debugged before a run on a real MI355X.  It is never built
+// into, loaded by, or shipped with the product: zipnn_amd/ loads libzipnn_hip.so only.
+//
+// Model: blocks run one after another; the threads of a block are ucontext fibers that
+// are switched only at __syncthreads() and at wave-collective calls (__ballot, __shfl*,
+// __any, __all).  A wave = 64 consecutive threads.  Wave collectives must be reached by
+// every live lane of the wave (the kernels are written that way); a lane that never
+// arrives is reported as a deadlock instead of hanging.
+#pragma once
+
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <ucontext.h>
+
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 {
+  uint32_t x, y, z;
+  dim3(uint32_t x_ = 1, uint32_t y_ = 1, uint32_t z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint4 { uint32_t x, y, z, w; };
+struct uint2 { uint32_t x, y; };
+static inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+static inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipHostMallocDefault = 0 };
+
+namespace zn_simt {
+
+enum State { RUN = 0, WAIT_BLOCK, WAIT_WAVE, DONE };
+
+struct Fiber {
+  ucontext_t ctx;
+  State st;
+  dim3 tid;
+  uint32_t flat;
+};
+
+struct Engine {
+  std::vector<Fiber> fibers;
+  std::vector<char> stacks;
+  ucontext_t sched;
+  Fiber* cur = nullptr;
+  dim3 bid, bdim, gdim;
+  std::function<void()> body;
+  uint64_t wave_in[64][64];    // [wave][lane] contribution of the pending collective
+  uint64_t wave_out[64][64];   // snapshot handed to the lanes on release
+  uint64_t wave_live[64];      // live-lane mask at release time
+};
+
+inline Engine& E() { static Engine e; return e; }
+
+inline void trampoline() {
+  Engine& e = E();
+  e.body();
+  e.cur->st = DONE;
+  swapcontext(&e.cur->ctx, &e.sched);
+}
+
+inline void yield_to_sched(State s) {
+  Engine& e = E();
+  e.cur->st = s;
+  swapcontext(&e.cur->ctx, &e.sched);
+}
+
+inline void run_block(uint32_t nthreads) {
+  Engine& e = E();
+  const size_t STK = 256 * 1024;
+  if (e.fibers.size() < nthreads) { e.fibers.resize(nthreads); e.stacks.resize((size_t)nthreads * STK); }
+  for (uint32_t t = 0; t < nthreads; t++) {
+    Fiber& f = e.fibers[t];
+    getcontext(&f.ctx);
+    f.ctx.uc_stack.ss_sp = e.stacks.data() + (size_t)t * STK;
+    f.ctx.uc_stack.ss_size = STK;
+    f.ctx.uc_link = &e.sched;
+    f.st = RUN; f.flat = t;
+    f.tid = dim3(t % e.bdim.x, (t / e.bdim.x) % e.bdim.y, t / (e.bdim.x * e.bdim.y));
+    makecontext(&f.ctx, (void (*)())trampoline, 0);
+  }
+  const uint32_t nwaves = (nthreads + 63) / 64;
+  for (;;) {
+    bool progressed = false; uint32_t done = 0;
+    for (uint32_t t = 0; t < nthreads; t++) {
+      Fiber& f = e.fibers[t];
+      if (f.st == RUN) { e.cur = &f; swapcontext(&e.sched, &f.ctx); progressed = true; }
+      if (f.st == DONE) done++;
+    }
+    if (done == nthreads) break;
+    // release waves whose live lanes all wait on a collective
+    for (uint32_t w = 0; w < nwaves; w++) {
+      uint32_t waiting = 0, live = 0; uint64_t mask = 0;
+      for (uint32_t l = 0; l < 64 && w * 64 + l < nthreads; l++) {
+        State s = e.fibers[w * 64 + l].st;
+        if (s != DONE) { live++; mask |= 1ull << l; }
+        if (s == WAIT_WAVE) waiting++;
+      }
+      if (live && waiting == live) {
+        memcpy(e.wave_out[w], e.wave_in[w], sizeof(e.wave_in[w]));
+        e.wave_live[w] = mask;
+        for (uint32_t l = 0; l < 64 && w * 64 + l < nthreads; l++)
+          if (e.fibers[w * 64 + l].st == WAIT_WAVE) e.fibers[w * 64 + l].st = RUN;
+        progressed = true;
+      }
+    }
+    // release the block barrier when every live thread waits on it
+    {
+      uint32_t waiting = 0, live = 0;
+      for (uint32_t t = 0; t < nthreads; t++) { State s = e.fibers[t].st; if (s != DONE) live++; if (s == WAIT_BLOCK) waiting++; }
+      if (live && waiting == live) { for (uint32_t t = 0; t < nthreads; t++) if (e.fibers[t].st == WAIT_BLOCK) e.fibers[t].st = RUN; progressed = true; }
+    }
+    if (!progressed) {
+      fprintf(stderr, "zn_simt: deadlock in block (%u,%u,%u): lanes diverge around a barrier/collective\n", e.bid.x, e.bid.y, e.bid.z);
+      abort();
+    }
+  }
+}
+
+// one collective: publish v, wait for the wave, return the snapshot row
+inline const uint64_t* collective(uint64_t v, uint64_t* live_mask) {
+  Engine& e = E();
+  const uint32_t w = e.cur->flat / 64, l = e.cur->flat % 64;
+  e.wave_in[w][l] = v;
+  yield_to_sched(WAIT_WAVE);
+  if (live_mask) *live_mask = e.wave_live[w];
+  return e.wave_out[w];
+}
+
+template <typename F>
+inline void launch(dim3 grid, dim3 block, F&& f) {
+  Engine& e = E();
+  e.gdim = grid; e.bdim = block;
+  e.body = std::function<void()>(f);
+  for (uint32_t z = 0; z < grid.z; z++)
+    for (uint32_t y = 0; y < grid.y; y++)
+      for (uint32_t x = 0; x < grid.x; x++) { e.bid = dim3(x, y, z); run_block(block.x * block.y * block.z); }
+}
+
+}  // namespace zn_simt
+
+#define threadIdx (zn_simt::E().cur->tid)
+#define blockIdx (zn_simt::E().bid)
+#define blockDim (zn_simt::E().bdim)
+#define gridDim (zn_simt::E().gdim)
+#define warpSize 64
+
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+  zn_simt::launch((grid), (block), [=]() { kernel(__VA_ARGS__); })
+
+static inline void __syncthreads() { zn_simt::yield_to_sched(zn_simt::WAIT_BLOCK); }
+
+static inline unsigned long long __ballot(int pred) {
+  uint64_t live; const uint64_t* r = zn_simt::collective(pred ? 1 : 0, &live);
+  unsigned long long m = 0;
+  for (int l = 0; l < 64; l++) if (((live >> l) & 1) && r[l]) m |= 1ull << l;
+  return m;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+static inline int __all(int pred) {
+  uint64_t live; const uint64_t* r = zn_simt::collective(pred ? 1 : 0, &live);
+  for (int l = 0; l < 64; l++) if (((live >> l) & 1) && !r[l]) return 0;
+  return 1;
+}
+template <typename T> static inline T zn_simt_shfl_idx(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shuffle of wide types not emulated");
+  uint64_t raw = 0; memcpy(&raw, &v, sizeof(T));
+  const uint32_t self = zn_simt::E().cur->flat % 64;
+  const uint64_t* r = zn_simt::collective(raw, nullptr);
+  const uint32_t s = (src >= 0 && src < 64) ? (uint32_t)src : self;
+  T out; memcpy(&out, &r[s], sizeof(T)); return out;
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) { (void)width; return zn_simt_shfl_idx(v, src & 63); }
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) { (void)width; int self = (int)(zn_simt::E().cur->flat % 64); return zn_simt_shfl_idx(v, self - (int)d >= 0 ? self - (int)d : self); }
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; int self = (int)(zn_simt::E().cur->flat % 64); return zn_simt_shfl_idx(v, self + (int)d < 64 ? self + (int)d : self); }
+template <typename T> static inline T __shfl_xor(T v, int m, int width = 64) { (void)width; int self = (int)(zn_simt::E().cur->flat % 64); return zn_simt_shfl_idx(v, self ^ m); }
+
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+
+template <typename T, typename U> static inline T atomicAdd(T* p, U v) { T o = *p; *p = (T)(o + (T)v); return o; }
+template <typename T, typename U> static inline T atomicOr(T* p, U v) { T o = *p; *p = (T)(o | (T)v); return o; }
+template <typename T, typename U> static inline T atomicAnd(T* p, U v) { T o = *p; *p = (T)(o & (T)v); return o; }
+template <typename T, typename U> static inline T atomicMax(T* p, U v) { T o = *p; if ((T)v > o) *p = (T)v; return o; }
+template <typename T, typename U> static inline T atomicMin(T* p, U v) { T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <typename T, typename U> static inline T atomicExch(T* p, U v) { T o = *p; *p = (T)v; return o; }
+template <typename T, typename U> static inline T atomicCAS(T* p, U cmp, U v) { T o = *p; if (o == (T)cmp) *p = (T)v; return o; }
+
+// AMD builtins used by the kernels
+static inline uint32_t zn_simt_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+static inline uint32_t zn_simt_alignbyte(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (sh & 3))); }
+static inline uint32_t zn_simt_perm(uint32_t a, uint32_t b, uint32_t sel) {
+  const uint64_t src = ((uint64_t)a << 32) | b; uint32_t r = 0;
+  for (int i = 0; i < 4; i++) {
+    const uint32_t s = (sel >> (8 * i)) & 0xFF; uint32_t byte;
+    if (s <= 7) byte = (uint32_t)(src >> (8 * s)) & 0xFF;
+    else if (s == 12) byte = 0; else if (s >= 13) byte = 0xFF;
+    else byte = (((src >> (16 * (s - 8) + 15)) & 1) ? 0xFF : 0);
+    r |= byte << (8 * i);
+  }
+  return r;
+}
+#define __builtin_amdgcn_alignbit(a, b, c) zn_simt_alignbit((a), (b), (c))
+#define __builtin_amdgcn_alignbyte(a, b, c) zn_simt_alignbyte((a), (b), (c))
+#define __builtin_amdgcn_perm(a, b, c) zn_simt_perm((a), (b), (c))
+#define __builtin_amdgcn_readfirstlane(v) __shfl((v), (int)__builtin_ctzll(__ballot(1)))
+#define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+
+// ---- host API subset ----
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "zn_simt"; }
+static inline hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p, 256, n ? n : 256) ? hipErrorOutOfMemory : hipSuccess; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
+static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }

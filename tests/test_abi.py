@@ -1,0 +1,61 @@
+"""CPU tests (-m "not gpu"): the C-ABI library builds, loads and exports every symbol that
+include/zipnn_hip.h declares; without a GPU the product fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    from zipnn_amd.build import build_extension
+    build_extension()
+    from zipnn_amd import _capi
+    return _capi.lib()
+
+
+def test_every_declared_symbol_is_exported(hip_lib):
+    text = open(os.path.join(ROOT, "include", "zipnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(zn_[a-z_0-9]+)\s*\(", text)))
+    assert len(names) >= 12
+    raw = ctypes.CDLL(hip_lib.path)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/zipnn_hip.h but not exported"
+
+
+def test_no_torch_types_in_abi():
+    text = open(os.path.join(ROOT, "include", "zipnn_hip.h")).read()
+    assert "torch" not in re.sub(r"/\*.*?\*/", "", text, flags=re.S).lower()
+    assert 'extern "C"' in text
+
+
+def test_size_helpers_and_errors(hip_lib):
+    L = hip_lib._L
+    assert L.zn_num_chunks(0, 262144) == 0 and L.zn_num_chunks(262145, 262144) == 2
+    assert L.zn_compress_bound(1 << 20, 2, 1 << 18, 38) == 38 + 9 * 2 * 4 + (1 << 20)
+    assert L.zn_strerror(0) == b"ok" and b"Compress Type" in L.zn_strerror(-5)
+
+
+def test_product_fails_loudly_without_gpu(hip_lib):
+    """No device → an exception, never a silent CPU result."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    from zipnn_amd import ZipNN
+    with pytest.raises(RuntimeError):
+        ZipNN(bytearray_dtype="bfloat16").compress(bytes(4096))
+    with pytest.raises(RuntimeError):
+        hip_lib.decompress(bytes(100), 2, 1, 10, 262144, 10)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under zipnn_amd/ may reference it."""
+    for dp, _, fs in os.walk(os.path.join(ROOT, "zipnn_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                s = open(os.path.join(dp, f), errors="ignore").read()
+                assert "oracle_lib" not in s and "zn_oracle" not in s and "libzn_oracle" not in s, f

@@ -1,0 +1,139 @@
+"""GPU parity tests (-m gpu): the real libzipnn_hip.so on an MI355X against the CPU oracle,
+the golden frames the reference produced, and size-independent properties at full size.
+Bit-exact is the bar (integer/byte work): compressed bytes AND decompressed bytes."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+import oracle_lib as O
+from test_oracle import gen_bytes
+
+pytestmark = pytest.mark.gpu
+HDR = bytes(range(32))
+C = 256 * 1024
+KB = 1024
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from zipnn_amd import _capi
+    L = _capi.lib()
+    assert L.device_count() >= 1
+    return L
+
+
+def _cases():
+    cs = []
+    for nb in (1, 2, 3, 6, 7, 1001, 1002, C - 2, C - 1, C, C + 1, C + 2, C + 6, 2 * C + 31338, 5 * C):
+        cs += [("bf16", nb, 2, 1, 10, C), ("fp16", nb, 2, 0, 10, C), ("rand", nb, 2, 1, 10, C), ("const", nb, 2, 1, 10, C)]
+    for nb in (4, 8, 1000, C - 4, C, C + 4, 2 * C + 4096, 1002, 7):
+        cs += [("fp32", nb, 4, 1, 220, C), ("rand", nb, 4, 1, 220, C)]
+    for nb in (1, 5, 1000, 128 * KB - 1, 128 * KB, 128 * KB + 1, 300001):
+        cs += [("fp8", nb, 1, 1, 10, 128 * KB), ("rand", nb, 1, 1, 10, 128 * KB)]
+    cs += [("bf16", 5 * 65536 + 10, 2, 1, 10, 65536), ("bf16", 9 * 16384 + 2, 2, 1, 10, 16384), ("bf16", 0, 2, 1, 10, C)]
+    return cs
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
+def test_c_abi_bit_exact_vs_oracle(lib, case):
+    kind, nb, P, rot, bm, chunk = case
+    d = gen_bytes(kind, nb, 5)
+    want = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)
+    got = bytes(lib.compress(HDR, d, P, rot, bm, chunk, 0.95))
+    assert got == want
+    if nb:
+        assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
+
+
+@pytest.mark.parametrize("name", G.names())
+def test_golden_frames_through_zipnn_api(lib, name):
+    from zipnn_amd import ZipNN
+    meta, blob = G.get(name)
+    ctor = dict(meta["ctor"])
+    back = ZipNN(**ctor).decompress(blob)
+    if meta["kind"] == "torch":
+        assert str(back.dtype) == "torch." + meta["dtype"] and list(back.shape) == meta["shape"]
+        raw = back.contiguous().view(torch.uint8).numpy().tobytes()
+        src = back.clone()
+    else:
+        raw, src = bytes(back), bytes(back)
+    assert G.sha(raw) == meta["in_sha256"]
+    assert G.sha(bytes(ZipNN(**ctor).compress(src))) == meta["frame_sha256"]
+    if meta["kind"] == "torch":   # device-resident variant: same frame, same tensor
+        assert G.sha(bytes(ZipNN(**ctor).compress(back.cuda()))) == meta["frame_sha256"]
+        dev = ZipNN(**ctor).decompress(blob, decompress_cpu_gpu="cuda")
+        assert dev.is_cuda and dev.cpu().view(torch.uint8).numpy().tobytes() == raw
+
+
+def test_reference_stress_sizes_roundtrip(lib):
+    """Sizes of the reference's tests/simple_stress_tests.py:19-70 (chunk boundary ±1 KiB)."""
+    from zipnn_amd import ZipNN
+    sizes = [255 * KB, 256 * KB, 257 * KB, 511 * KB, 512 * KB, 513 * KB, 1024 * KB, int(0.99 * KB * KB), KB * KB,
+             int(1.01 * KB * KB), int(1.99 * KB * KB), 2 * KB * KB, int(2.1 * KB * KB)]
+    for s in sizes:
+        t = (torch.rand(s // 2) * 2 - 1).to(torch.bfloat16)
+        z = ZipNN(input_format="torch")
+        frame = z.compress(t.clone())
+        assert torch.equal(ZipNN(input_format="torch").decompress(frame), t)
+        raw = t.view(torch.uint8).numpy().tobytes()
+        p = G.parse_frame(bytes(frame))
+        assert bytes(frame) == O.compress_frame(p["header"], raw, 2, 1, 10, C, threads=4)
+        b = np.random.default_rng(s).integers(0, 256, s, dtype=np.uint8).tobytes()
+        assert bytes(ZipNN(bytearray_dtype="bfloat16").decompress(ZipNN(bytearray_dtype="bfloat16").compress(b))) == b
+
+
+def test_256MiB_bf16_bit_exact_vs_oracle(lib):
+    """BASELINE.json configs[0] size on the GPU: frame identical to the oracle's, and round trip."""
+    from zipnn_amd import codec
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.randn(128 * KB * KB, generator=g) * 0.02).to(torch.bfloat16)
+    raw = x.view(torch.uint8).numpy()
+    want = O.compress_frame(bytes(32), raw, 2, 1, 10, C, threads=8)
+    body = codec.compress_device(lib, codec.flat_bytes(x.cuda()), 2, 1, 10, C, 0.95)
+    got = body.cpu().numpy().tobytes()
+    assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want[32:]).hexdigest()
+    out = codec.decompress_device(lib, body, 2, 1, 10, C, raw.size)
+    assert torch.equal(out.cpu(), torch.from_numpy(raw))
+    assert 0.655 < len(want) / raw.size < 0.670          # README: 66.3 % on bf16
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32"])
+def test_full_size_roundtrip_properties(lib, dtype):
+    """1 GiB per dtype (4 GiB bf16 is exercised by bench.py): decode(encode(x)) == x, the body's
+    metadata is self-consistent, and the first and last chunks equal the oracle's bytes."""
+    from zipnn_amd import codec
+    n_bytes = 1 << 30
+    torch.manual_seed(7)
+    if dtype == "bf16":
+        x = (torch.randn(n_bytes // 2, device="cuda") * 0.02).to(torch.bfloat16); P, rot, bm = 2, 1, 10
+    elif dtype == "fp16":
+        x = (torch.randn(n_bytes // 2, device="cuda") * 0.02).half(); P, rot, bm = 2, 0, 10
+    else:
+        x = torch.randn(n_bytes // 4, device="cuda") * 0.02; P, rot, bm = 4, 1, 220
+    flat = codec.flat_bytes(x)
+    body = codec.compress_device(lib, flat, P, rot, bm, C, 0.95)
+    out = codec.decompress_device(lib, body, P, rot, bm, C, n_bytes)
+    assert torch.equal(out, flat)
+    K = n_bytes // C
+    hb = body[: 9 * P * K].cpu().numpy()
+    types = hb[: P * K].reshape(P, K)
+    cum = hb[P * K:].view(np.uint64).reshape(P, K)
+    assert set(np.unique(types)) <= {0, 1}
+    assert (np.diff(cum.astype(np.int64), axis=1) > 0).all()
+    assert 9 * P * K + int(cum[:, -1].sum()) == body.numel()
+    # first / last chunk: stored bytes equal the oracle's for the same 256 KiB
+    for c in (0, K - 1):
+        chunk_raw = flat[c * C:(c + 1) * C].cpu().numpy().tobytes()
+        ofr = O.compress_frame(b"", chunk_raw, P, rot, bm, C)
+        osz = np.frombuffer(ofr[P:P + 8 * P], dtype=np.uint64)
+        opay = ofr[9 * P:]
+        base = 9 * P * K
+        off_o = 0
+        for p in range(P):
+            lo = int(cum[p, c - 1]) if c else 0
+            mine = body[base + lo: base + int(cum[p, c])].cpu().numpy().tobytes()
+            assert mine == opay[off_o: off_o + int(osz[p])]
+            off_o += int(osz[p]); base += int(cum[p, -1])

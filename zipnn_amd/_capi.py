@@ -1,0 +1,160 @@
+"""ctypes binding of libzipnn_hip.so (include/zipnn_hip.h).
+
+This is the only route from Python to the codec: there is no CPU implementation behind
+it.  If the shared library has not been built (``python -c "import __graft_entry__ as g;
+g.build()"``) importing the codec fails loudly.
+
+The two host-buffer calls mirror the reference's C extension one for one:
+``zipnn_core.zipnn_core`` (reference csrc/zipnn_core.c:401, called at zipnn/zipnn.py:714)
+-> :meth:`ZnLib.compress`, and ``zipnn_core.combine_dtype`` (csrc/zipnn_core.c:881, called
+at zipnn/zipnn.py:1143) -> :meth:`ZnLib.decompress`.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_NAME = "libzipnn_hip.so"
+
+ZN_OK, ZN_E_ARG, ZN_E_HIP, ZN_E_CAP, ZN_E_CORRUPT, ZN_E_TYPE, ZN_E_NODEV, ZN_E_ALLOC = 0, -1, -2, -3, -4, -5, -6, -7
+
+
+class ZnError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(text)
+        self.status = status
+
+
+class ZnLib:
+    """A loaded libzipnn_hip.so."""
+
+    def __init__(self, path):
+        self.path = path
+        L = ctypes.CDLL(path)
+        sz, vp, ci, cf = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        L.zn_abi_version.restype = ci
+        L.zn_strerror.restype = ctypes.c_char_p
+        L.zn_strerror.argtypes = [ci]
+        L.zn_last_hip_error.restype = ctypes.c_char_p
+        L.zn_last_kernels.restype = ctypes.c_char_p
+        L.zn_device_count.restype = ci
+        L.zn_num_chunks.restype = sz
+        L.zn_num_chunks.argtypes = [sz, sz]
+        L.zn_compress_bound.restype = sz
+        L.zn_compress_bound.argtypes = [sz, ci, sz, sz]
+        L.zn_compress.restype = ci
+        L.zn_compress.argtypes = [vp, sz, vp, sz, ci, ci, ci, sz, cf, ci, vp, sz, ctypes.POINTER(sz)]
+        L.zn_decompress.restype = ci
+        L.zn_decompress.argtypes = [vp, sz, ci, ci, ci, sz, sz, ci, vp]
+        L.zn_compress_dev.restype = ci
+        L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
+        L.zn_decompress_dev.restype = ci
+        L.zn_decompress_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, vp, vp, ci]
+        L.zn_release_workspace.restype = ci
+        self._L = L
+        if L.zn_abi_version() != 1:
+            raise ImportError(f"{path}: unexpected ABI version {L.zn_abi_version()}")
+
+    # -- error mapping: the Python-visible exceptions of the reference ------------------
+    def _check(self, rc):
+        if rc == ZN_OK:
+            return
+        text = self._L.zn_strerror(rc).decode()
+        if rc == ZN_E_HIP:
+            text += ": " + self._L.zn_last_hip_error().decode()
+        if rc in (ZN_E_TYPE, ZN_E_ALLOC):
+            # reference raises MemoryError for bad type bytes and failed allocations
+            # (csrc/zipnn_core.c:993-996 and the malloc checks around it)
+            raise MemoryError(text)
+        if rc == ZN_E_ARG:
+            raise ValueError(text)
+        # worker failure in the reference surfaces as RuntimeError("Thread processing failed")
+        # (csrc/zipnn_core.c:520-523,1088-1091)
+        raise ZnError(rc, "Thread processing failed: " + text)
+
+    def device_count(self):
+        return self._L.zn_device_count()
+
+    def compress_bound(self, n, num_buf, chunk, hdr_len):
+        return self._L.zn_compress_bound(n, num_buf, chunk, hdr_len)
+
+    def last_kernels(self):
+        return self._L.zn_last_kernels().decode()
+
+    # -- host buffers --------------------------------------------------------------------
+    def compress(self, header, data, num_buf, bits_mode, bytes_mode, chunk, threshold, device=0):
+        """header/data: bytes-like (not modified). Returns a bytearray holding the frame."""
+        hv = memoryview(header).cast("B")
+        dv = memoryview(data).cast("B")
+        n = dv.nbytes
+        cap = self._L.zn_compress_bound(n, num_buf, chunk, hv.nbytes)
+        out = bytearray(max(cap, 1))
+        out_len = ctypes.c_size_t(0)
+        hb = (ctypes.c_char * max(hv.nbytes, 1)).from_buffer_copy(hv.tobytes() or b"\0")
+        src = _as_c_buffer(dv)
+        rc = self._L.zn_compress(ctypes.addressof(hb), hv.nbytes, src.addr, n, num_buf, bits_mode, bytes_mode, chunk,
+                                 threshold, device, _addr_of_bytearray(out), cap, ctypes.byref(out_len))
+        self._check(rc)
+        del out[out_len.value:]
+        return out
+
+    def decompress(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, device=0):
+        """body: bytes-like after the header. Returns a bytearray of orig_size bytes."""
+        bv = memoryview(body).cast("B")
+        out = bytearray(max(orig_size, 1))
+        src = _as_c_buffer(bv)
+        rc = self._L.zn_decompress(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, device,
+                                   _addr_of_bytearray(out))
+        self._check(rc)
+        del out[orig_size:]
+        return out
+
+    # -- device pointers (ints), used by zipnn_amd.codec with torch tensors -----------------
+    def compress_dev(self, src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap, stream=0):
+        out_len = ctypes.c_size_t(0)
+        rc = self._L.zn_compress_dev(src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap,
+                                     ctypes.byref(out_len), stream)
+        self._check(rc)
+        return out_len.value
+
+    def decompress_dev(self, body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr, stream=0,
+                       check=True):
+        rc = self._L.zn_decompress_dev(body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr,
+                                       stream, 1 if check else 0)
+        self._check(rc)
+
+    def release_workspace(self):
+        self._check(self._L.zn_release_workspace())
+
+
+class _CBuf:
+    """Address of a (possibly read-only) Python buffer, zero-copy, kept alive for a call."""
+
+    def __init__(self, mv):
+        self.arr = np.frombuffer(mv, dtype=np.uint8) if mv.nbytes else None
+        self.addr = self.arr.ctypes.data if mv.nbytes else None
+
+
+def _as_c_buffer(mv):
+    return _CBuf(mv)
+
+
+def _addr_of_bytearray(ba):
+    return ctypes.addressof((ctypes.c_char * len(ba)).from_buffer(ba))
+
+
+_LIB = None
+
+
+def lib():
+    """The process-wide library handle; raises ImportError when the extension is not built."""
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, LIB_NAME)
+        if not os.path.exists(path):
+            raise ImportError(
+                f"{path} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). zipnn_amd has no CPU fallback.")
+        _LIB = ZnLib(path)
+    return _LIB

@@ -1,0 +1,68 @@
+"""torch <-> C-ABI glue for buffers that live in HBM.
+
+torch is plumbing here (device memory, streams); the work is in libzipnn_hip.so.  The
+functions take a `lib` (zipnn_amd._capi.ZnLib) so that the CPU test-suite can drive the
+same code through the SIMT-emulated build of the kernels with CPU tensors.
+"""
+import torch
+
+
+def current_device():
+    return torch.cuda.current_device() if torch.cuda.is_available() else 0
+
+
+def flat_bytes(t):
+    """Contiguous 1-D uint8 view of a tensor's storage bytes (no copy when contiguous)."""
+    t = t.contiguous()
+    if t.dtype in (torch.float8_e4m3fn, torch.float8_e5m2):
+        return t.view(torch.uint8).reshape(-1)
+    return t.reshape(-1).view(torch.uint8)
+
+
+def _stream_handle(t):
+    return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
+
+
+def compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold):
+    """flat: uint8 tensor in HBM -> uint8 tensor (same device) holding the frame BODY
+    (types ‖ cumSizes ‖ payload).  One 8-byte read-back for the length."""
+    n = flat.numel()
+    cap = lib.compress_bound(n, num_buf, chunk, 0)
+    body = torch.empty(max(cap, 16), dtype=torch.uint8, device=flat.device)
+    with torch.cuda.device(flat.device) if flat.is_cuda else _nullctx():
+        used = lib.compress_dev(flat.data_ptr() if n else 0, n, num_buf, bits_mode, bytes_mode, chunk, threshold,
+                                body.data_ptr(), body.numel(), _stream_handle(flat))
+    return body[:used]
+
+
+def compress_device_to_frame(lib, header, flat, num_buf, bits_mode, bytes_mode, chunk, threshold):
+    """Device tensor -> host frame bytes (header ‖ body); only compressed bytes cross PCIe."""
+    body = compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold)
+    frame = bytearray(header)
+    total = len(frame) + body.numel()
+    if len(frame) >= 32:
+        frame[24:32] = total.to_bytes(8, "little")   # what the reference core writes at zipnn_core.c:121
+    frame += body.cpu().numpy().tobytes()
+    return frame
+
+
+def decompress_device(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, out=None, check=True):
+    """body: uint8 tensor in HBM (frame minus header) -> uint8 tensor of orig_size bytes on
+    the same device."""
+    if out is None:
+        out = torch.empty(orig_size, dtype=torch.uint8, device=body.device)
+    if orig_size == 0:
+        return out
+    body = body.contiguous()
+    with torch.cuda.device(body.device) if body.is_cuda else _nullctx():
+        lib.decompress_dev(body.data_ptr(), body.numel(), num_buf, bits_mode, bytes_mode, chunk, orig_size,
+                           out.data_ptr(), _stream_handle(body), check)
+    return out
+
+
+class _nullctx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False

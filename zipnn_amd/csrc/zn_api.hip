@@ -1,0 +1,229 @@
+// zn_api.hip — the C ABI of libzipnn_hip.so (include/zipnn_hip.h).
+//
+// Host-side control only: argument checks, per-device workspace cache, kernel launches,
+// the one 8-byte read-back of the compressed length.  All data work is in the kernels.
+#include "../../include/zipnn_hip.h"
+#include "zn_internal.hpp"
+
+#include <mutex>
+#include <string>
+#include <string.h>
+
+namespace {
+
+thread_local std::string t_hip_err;
+thread_local std::string t_kernels;
+
+#define ZN_HIP(call)                                                            \
+  do {                                                                          \
+    hipError_t e_ = (call);                                                     \
+    if (e_ != hipSuccess) {                                                     \
+      t_hip_err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+      return ZN_E_HIP;                                                          \
+    }                                                                           \
+  } while (0)
+
+// Grow-only device buffers cached per device; guarded by one mutex (calls on the same
+// device serialise on their workspace — independent GPUs run in independent processes).
+struct Workspace {
+  void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[6] = {0, 0, 0, 0, 0, 0};
+  uint64_t* h_total = nullptr;   // pinned host word for the length read-back
+  uint32_t* h_status = nullptr;
+};
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS };
+
+std::mutex g_mu;
+Workspace g_ws[64];
+
+int ws_reserve(Workspace& w, int slot, size_t bytes) {
+  if (bytes == 0) bytes = 16;
+  if (w.cap[slot] >= bytes) return ZN_OK;
+  if (w.buf[slot]) { ZN_HIP(hipFree(w.buf[slot])); w.buf[slot] = nullptr; w.cap[slot] = 0; }
+  hipError_t e = hipMalloc(&w.buf[slot], bytes);
+  if (e != hipSuccess) { t_hip_err = std::string("hipMalloc: ") + hipGetErrorString(e); (void)hipGetLastError(); return ZN_E_ALLOC; }
+  w.cap[slot] = bytes;
+  return ZN_OK;
+}
+
+int ws_host_words(Workspace& w) {
+  if (!w.h_total) ZN_HIP(hipHostMalloc((void**)&w.h_total, 64, hipHostMallocDefault));
+  w.h_status = (uint32_t*)(w.h_total + 4);
+  return ZN_OK;
+}
+
+int check_geom(size_t n, int num_buf, int bytes_mode, size_t chunk, ZnGeom* g, int bits_mode) {
+  if (!(num_buf == 1 || num_buf == 2 || num_buf == 4)) return ZN_E_ARG;
+  if ((num_buf == 4 && bytes_mode != 220) || (num_buf != 4 && bytes_mode != 10)) return ZN_E_ARG;
+  if (chunk == 0 || (chunk % (size_t)num_buf) != 0 || chunk > (1ull << 31)) return ZN_E_ARG;
+  g->n = n; g->chunk = chunk; g->K = (n + chunk - 1) / chunk; g->P = (uint32_t)num_buf;
+  g->rot = (bits_mode == 1 && num_buf > 1) ? 1u : 0u;
+  if (g->K * (uint64_t)num_buf > 0x7FFFFFFFull) return ZN_E_ARG;
+  return ZN_OK;
+}
+
+}  // namespace
+
+void zn_note_kernel(const char* name) { if (!t_kernels.empty()) t_kernels += ";"; t_kernels += name; }
+
+extern "C" {
+
+int zn_abi_version(void) { return 1; }
+
+const char* zn_strerror(int s) {
+  switch (s) {
+    case ZN_OK: return "ok";
+    case ZN_E_ARG: return "bad argument";
+    case ZN_E_HIP: return "HIP runtime call failed";
+    case ZN_E_CAP: return "destination capacity too small";
+    case ZN_E_CORRUPT: return "compressed data is corrupt";
+    case ZN_E_TYPE: return "Compress Type is not correct in Decompression function";
+    case ZN_E_NODEV: return "no HIP device";
+    case ZN_E_ALLOC: return "allocation failed";
+    default: return "unknown status";
+  }
+}
+
+const char* zn_last_hip_error(void) { return t_hip_err.c_str(); }
+const char* zn_last_kernels(void) { return t_kernels.c_str(); }
+
+int zn_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+size_t zn_num_chunks(size_t n, size_t chunk) { return chunk ? (n + chunk - 1) / chunk : 0; }
+
+size_t zn_compress_bound(size_t n, int num_buf, size_t chunk, size_t hdr_len) {
+  return hdr_len + 9u * (size_t)num_buf * zn_num_chunks(n, chunk) + n;
+}
+
+int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                    float threshold, void* d_body, size_t body_cap, size_t* body_len, void* stream_) {
+  ZnGeom g;
+  int rc = check_geom(n, num_buf, bytes_mode, chunk, &g, bits_mode);
+  if (rc) return rc;
+  if (!body_len || (n && (!d_src || !d_body))) return ZN_E_ARG;
+  if (body_cap < zn_compress_bound(n, num_buf, chunk, 0)) return ZN_E_CAP;
+  hipStream_t stream = (hipStream_t)stream_;
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  t_kernels.clear();
+  std::lock_guard<std::mutex> lk(g_mu);
+  Workspace& w = g_ws[dev];
+  const size_t slot = zn_plane_slot(chunk, num_buf);
+  const size_t PK = (size_t)g.P * g.K;
+  if ((rc = ws_reserve(w, WS_PLANES, PK * slot))) return rc;
+  if ((rc = ws_reserve(w, WS_ENC, PK * slot))) return rc;
+  if ((rc = ws_reserve(w, WS_META_A, PK * sizeof(uint32_t)))) return rc;   // stored sizes
+  if ((rc = ws_reserve(w, WS_META_B, PK))) return rc;                      // types
+  if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(uint64_t)))) return rc;   // payload offsets
+  if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
+  if ((rc = ws_host_words(w))) return rc;
+  uint64_t* d_total = (uint64_t*)w.buf[WS_WORDS];
+  zn_launch_encode_generic(g, (const uint8_t*)d_src, threshold, (uint8_t*)w.buf[WS_PLANES], (uint8_t*)w.buf[WS_ENC],
+                           (uint32_t*)w.buf[WS_META_A], (uint8_t*)w.buf[WS_META_B], (uint64_t*)w.buf[WS_META_C], d_total,
+                           (uint8_t*)d_body, stream);
+  ZN_HIP(hipGetLastError());
+  ZN_HIP(hipMemcpyAsync(w.h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  ZN_HIP(hipStreamSynchronize(stream));
+  *body_len = (size_t)*w.h_total;
+  return ZN_OK;
+}
+
+int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                      size_t orig_size, void* d_dst, void* stream_, int check) {
+  ZnGeom g;
+  int rc = check_geom(orig_size, num_buf, bytes_mode, chunk, &g, bits_mode);
+  if (rc) return rc;
+  if (body_len < 9u * (size_t)g.P * g.K) return ZN_E_CORRUPT;
+  if (orig_size == 0) return ZN_OK;
+  if (!d_body || !d_dst) return ZN_E_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  t_kernels.clear();
+  std::lock_guard<std::mutex> lk(g_mu);
+  Workspace& w = g_ws[dev];
+  const size_t slot = zn_plane_slot(chunk, num_buf);
+  const size_t PK = (size_t)g.P * g.K;
+  if ((rc = ws_reserve(w, WS_PLANES, PK * slot))) return rc;
+  if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(ZnPlaneDesc)))) return rc;
+  if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
+  if ((rc = ws_host_words(w))) return rc;
+  uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
+  ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+  zn_launch_decode_generic(g, (const uint8_t*)d_body, body_len, (uint8_t*)w.buf[WS_PLANES], (ZnPlaneDesc*)w.buf[WS_META_C],
+                           d_status, (uint8_t*)d_dst, stream);
+  ZN_HIP(hipGetLastError());
+  if (check) {
+    ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ZN_HIP(hipStreamSynchronize(stream));
+    const uint32_t st = *w.h_status;
+    if (st & ZN_DEV_BAD_TYPE) return ZN_E_TYPE;
+    if (st & ZN_DEV_CORRUPT) return ZN_E_CORRUPT;
+  }
+  return ZN_OK;
+}
+
+int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
+  if (!dst_len || (hdr_len && !hdr) || (n && !src) || !dst) return ZN_E_ARG;
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  ZN_HIP(hipSetDevice(device));
+  const size_t bound = zn_compress_bound(n, num_buf, chunk, 0);
+  void* d_src = nullptr; void* d_body = nullptr;
+  hipError_t e1 = hipMalloc(&d_src, n ? n : 16), e2 = hipMalloc(&d_body, bound ? bound : 16);
+  if (e1 != hipSuccess || e2 != hipSuccess) { if (d_src) (void)hipFree(d_src); if (d_body) (void)hipFree(d_body); (void)hipGetLastError(); return ZN_E_ALLOC; }
+  int rc = ZN_OK; size_t body_len = 0;
+  do {
+    if (n && hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
+    rc = zn_compress_dev(d_src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, bound ? bound : 16, &body_len, nullptr);
+    if (rc) break;
+    if (hdr_len + body_len > dst_cap) { rc = ZN_E_CAP; break; }
+    if (hdr_len) memcpy(dst, hdr, hdr_len);
+    if (body_len && hipMemcpy((uint8_t*)dst + hdr_len, d_body, body_len, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy D2H"; break; }
+    *dst_len = hdr_len + body_len;
+    if (hdr_len >= 32) { const uint64_t total = *dst_len; memcpy((uint8_t*)dst + 24, &total, 8); }   // zipnn_core.c:121
+  } while (0);
+  (void)hipFree(d_src); (void)hipFree(d_body);
+  return rc;
+}
+
+int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                  size_t orig_size, int device, void* dst) {
+  if ((body_len && !body) || (orig_size && !dst)) return ZN_E_ARG;
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  ZN_HIP(hipSetDevice(device));
+  void* d_body = nullptr; void* d_dst = nullptr;
+  hipError_t e1 = hipMalloc(&d_body, body_len ? body_len : 16), e2 = hipMalloc(&d_dst, orig_size ? orig_size : 16);
+  if (e1 != hipSuccess || e2 != hipSuccess) { if (d_body) (void)hipFree(d_body); if (d_dst) (void)hipFree(d_dst); (void)hipGetLastError(); return ZN_E_ALLOC; }
+  int rc = ZN_OK;
+  do {
+    if (body_len && hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
+    rc = zn_decompress_dev(d_body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, d_dst, nullptr, 1);
+    if (rc) break;
+    if (orig_size && hipMemcpy(dst, d_dst, orig_size, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy D2H"; break; }
+  } while (0);
+  (void)hipFree(d_body); (void)hipFree(d_dst);
+  return rc;
+}
+
+int zn_release_workspace(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (int d = 0; d < 64; d++) {
+    Workspace& w = g_ws[d];
+    bool any = w.h_total != nullptr;
+    for (int i = 0; i < 6; i++) any = any || w.buf[i];
+    if (!any) continue;
+    if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
+    for (int i = 0; i < 6; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
+    if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
+  }
+  return ZN_OK;
+}
+
+}  // extern "C"

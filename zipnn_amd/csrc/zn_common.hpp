@@ -1,0 +1,77 @@
+// zn_common.hpp — shared constants and small device helpers for the gfx950 kernels.
+//
+// Wire format and return conventions follow the reference byte for byte
+// (reference csrc/zipnn_core.c:105-244,881-1028).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define ZN_WAVE 64
+
+// huff0 constants (Cyan4973/FiniteStateEntropy lib/huf.h as shipped in zstd 1.4.8)
+#define ZN_HUF_BLOCK_MAX (128u * 1024u)
+#define ZN_HUF_LOG_MAX 12u
+#define ZN_HUF_LOG_DEFAULT 11u
+#define ZN_HUF_SYM_MAX 255u
+#define ZN_FSE_LOG_MIN 5u
+#define ZN_FSE_LOG_MAX 12u
+#define ZN_WEIGHT_FSE_LOG 6u
+
+// device-side status bits OR-ed into the per-call status word
+#define ZN_DEV_BAD_TYPE 1u
+#define ZN_DEV_CORRUPT 2u
+
+// plane-chunk kinds resolved by the decoder from (type, stored size, plane length)
+#define ZN_KIND_RAW 0u   // type 0, or type 1 with csize == plane_len (HUF_decompress memcpy rule)
+#define ZN_KIND_RLE 1u   // type 1, csize == 1
+#define ZN_KIND_HUF 2u   // type 1, real huff0 block
+
+__device__ __forceinline__ uint32_t zn_hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+
+// Byte-granular loads for metadata and bit-stream heads/tails, where the address has
+// no alignment guarantee (payload offsets are sums of arbitrary compressed sizes).
+__device__ __forceinline__ uint32_t zn_ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t zn_ld32(const uint8_t* p) {
+  return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+__device__ __forceinline__ uint64_t zn_ld64(const uint8_t* p) {
+  return (uint64_t)zn_ld32(p) | ((uint64_t)zn_ld32(p + 4) << 32);
+}
+__device__ __forceinline__ void zn_st64(uint8_t* p, uint64_t v) {
+  for (int i = 0; i < 8; i++) p[i] = (uint8_t)(v >> (8 * i));
+}
+
+// Sign-bit rotate of the reference (csrc/data_manipulation_dtype16.c:10-20,145-155 and
+// data_manipulation_dtype32.c:39-49,275-285), on one 32-bit word.
+__device__ __forceinline__ uint32_t zn_rot_fwd16(uint32_t u) {
+  return ((u << 1) & 0xFF00FF00u) | ((u >> 8) & 0x00800080u) | (u & 0x007F007Fu);
+}
+__device__ __forceinline__ uint32_t zn_rot_inv16(uint32_t u) {
+  return ((u << 8) & 0x80008000u) | ((u >> 1) & 0x7F807F80u) | (u & 0x007F007Fu);
+}
+__device__ __forceinline__ uint32_t zn_rot_fwd32(uint32_t u) {
+  return ((u << 1) & 0xFF000000u) | ((u >> 8) & 0x00800000u) | (u & 0x007FFFFFu);
+}
+__device__ __forceinline__ uint32_t zn_rot_inv32(uint32_t u) {
+  return ((u << 8) & 0x80000000u) | ((u >> 1) & 0x7F800000u) | (u & 0x007FFFFFu);
+}
+
+// Geometry of one frame body, passed by value to every kernel.
+struct ZnGeom {
+  uint64_t n;         // original length in bytes
+  uint64_t chunk;     // origChunkSize
+  uint64_t K;         // number of chunks
+  uint32_t P;         // planes (num_buf)
+  uint32_t rot;       // bits_mode == 1 && P > 1
+};
+
+// length of chunk c and of its plane p (reference csrc/zipnn_core.c:1006-1027,
+// data_manipulation_dtype16.c:70-75, data_manipulation_dtype32.c:81-90)
+__device__ __forceinline__ uint32_t zn_chunk_len(const ZnGeom& g, uint64_t c) {
+  return (uint32_t)((c == g.K - 1) ? (g.n - c * g.chunk) : g.chunk);
+}
+__device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P, uint32_t p) {
+  return chunk_len / P + (p < chunk_len % P ? 1u : 0u);
+}

@@ -1,0 +1,241 @@
+// zn_decode_generic.hip — generic decode path: handles every dtype (1/2/4 planes), partial
+// last chunks, RLE planes, and any mix of raw/Huffman planes.  Two kernels:
+//
+//   zn_k_decode_planes   one wave per (plane, chunk): parse its metadata, classify it
+//                        (raw / RLE / huff0) and, for huff0 blocks, build the decode LUT in
+//                        LDS and decode the four backward streams into a scratch plane.
+//   zn_k_merge_planes    one workgroup per chunk: interleave the planes (from the body for
+//                        raw planes, from scratch for decoded ones), undo the sign-bit
+//                        rotate, write the chunk with 16-byte coalesced stores.
+//
+// Replaces: decompression_chunk_worker (reference csrc/zipnn_core.c:768-861), the metadata
+// parse of py_combine_dtype (:929-1028), HUF_decompress (call site :807) and
+// combine_buffers_dtype16/32 + revert_all_floats_* (data_manipulation_dtype16.c:145-216,
+// data_manipulation_dtype32.c:275-294,391-456).
+//
+// This is the correctness-first path; the bandwidth path for full chunks with one
+// Huffman-coded plane is zn_decode_fused.hip.
+#include "zn_internal.hpp"
+#include "zn_huf_tables.hpp"
+
+// ---------------------------------------------------------------------------
+// metadata of one (plane, chunk), computed identically by every lane
+// ---------------------------------------------------------------------------
+struct ZnPcMeta { uint64_t off; uint32_t csize; uint32_t plen; uint32_t type; uint32_t ok; };
+
+__device__ inline ZnPcMeta zn_pc_meta(const ZnGeom& g, const uint8_t* body, uint64_t body_len, uint32_t p, uint64_t c) {
+  ZnPcMeta m;
+  const uint64_t PK = (uint64_t)g.P * g.K;
+  const uint8_t* cum = body + PK;                       // u64 [P][K], inclusive, unaligned
+  uint64_t base = 9u * PK;                              // payload start
+  for (uint32_t q = 0; q < p; q++) base += zn_ld64(cum + 8u * ((uint64_t)q * g.K + g.K - 1));
+  const uint64_t hi = zn_ld64(cum + 8u * ((uint64_t)p * g.K + c));
+  const uint64_t lo = c ? zn_ld64(cum + 8u * ((uint64_t)p * g.K + c - 1)) : 0;
+  m.type = body[(uint64_t)p * g.K + c];
+  m.plen = zn_plane_len(zn_chunk_len(g, c), g.P, p);
+  m.ok = (hi >= lo) && (hi - lo <= 0xFFFFFFFFull) && (base + hi <= body_len);
+  m.csize = (uint32_t)(hi - lo);
+  m.off = base + lo;
+  return m;
+}
+
+// ---------------------------------------------------------------------------
+// single-symbol decode LUT, filled by all lanes of the calling wave(s)
+// ---------------------------------------------------------------------------
+// weights -> symbols ordered by (weight, symbol) + per-weight start cells.  Wave 0 only.
+// sh_symlist[256], sh_rank_start[14] (cells), sh_sym_start[14] (index into symlist).
+__device__ inline void zn_order_symbols(const uint8_t* weights, uint32_t nsym, uint32_t tl, uint8_t* sh_symlist,
+                                        uint32_t* sh_rank_start, uint32_t* sh_sym_start, uint32_t lane) {
+  uint32_t cnt[13];
+  for (int v = 0; v < 13; v++) cnt[v] = 0;
+  // pass 1: per-weight totals
+  for (uint32_t q = 0; q < 256; q += ZN_WAVE) {
+    const uint32_t s = q + lane; const uint32_t w = (s < nsym) ? weights[s] : 0u;
+    for (uint32_t v = 1; v <= 12; v++) cnt[v] += (uint32_t)__popcll(__ballot(w == v));
+  }
+  uint32_t rs[14], ss[14]; uint32_t cells = 0, syms = 0;
+  rs[0] = 0; ss[0] = 0;
+  for (uint32_t v = 1; v <= 12; v++) { rs[v] = cells; ss[v] = syms; cells += cnt[v] << (v - 1); syms += cnt[v]; }
+  rs[13] = cells; ss[13] = syms;
+  if (lane < 14) { sh_rank_start[lane] = rs[lane]; sh_sym_start[lane] = ss[lane]; }
+  // pass 2: rank of every symbol inside its weight class
+  uint32_t run[13];
+  for (int v = 0; v < 13; v++) run[v] = 0;
+  for (uint32_t q = 0; q < 256; q += ZN_WAVE) {
+    const uint32_t s = q + lane; const uint32_t w = (s < nsym) ? weights[s] : 0u;
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (uint32_t v = 1; v <= 12; v++) {
+      const uint64_t m = __ballot(w == v);
+      if (w == v) sh_symlist[ss[v] + run[v] + (uint32_t)__popcll(m & lt)] = (uint8_t)s;
+      run[v] += (uint32_t)__popcll(m);
+    }
+  }
+  (void)tl;
+}
+
+// cell u -> (symbol | nbBits << 8); cells of weight w (code length tl+1-w) are contiguous
+__device__ inline uint32_t zn_lut_entry(uint32_t u, uint32_t tl, const uint8_t* sh_symlist, const uint32_t* sh_rank_start,
+                                        const uint32_t* sh_sym_start) {
+  uint32_t w = 1;
+  for (uint32_t v = 2; v <= 12; v++) w += (u >= sh_rank_start[v]) ? 1u : 0u;   // rank_start is non-decreasing
+  const uint32_t j = (u - sh_rank_start[w]) >> (w - 1);
+  return (uint32_t)sh_symlist[sh_sym_start[w] + j] | ((tl + 1u - w) << 8);
+}
+
+// ---------------------------------------------------------------------------
+// one backward stream decoded by one lane (byte-granular; the generic path only)
+// ---------------------------------------------------------------------------
+__device__ inline uint64_t zn_window(const uint8_t* base, int32_t bitpos) {
+  // 64-bit container whose top bit is the next unread bit; zero-filled below bit 0
+  const int32_t k = bitpos >> 3, r = bitpos & 7;
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) {
+    const int32_t idx = k - 7 + i;
+    const uint32_t b = (idx >= 0 && (idx < k || r > 0)) ? base[idx] : 0u;
+    v |= (uint64_t)b << (8 * i);
+  }
+  return v << (8 - r);
+}
+
+// returns 0 when the stream decodes to exactly `nout` symbols and is fully consumed
+__device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, uint8_t* out, uint32_t nout,
+                                              const uint16_t* lut, uint32_t tl) {
+  if (len == 0 || src[len - 1] == 0) return 1;
+  int32_t bitpos = (int32_t)(len - 1u) * 8 + (int32_t)zn_hb32(src[len - 1]);
+  uint32_t produced = 0;
+  while (produced < nout) {
+    if (bitpos < -64) return 1;
+    uint64_t cont = zn_window(src, bitpos);
+    int32_t avail = ((bitpos >> 3) >= 7) ? 56 + (bitpos & 7) : (1 << 30);
+    while (produced < nout && avail >= (int32_t)tl) {
+      const uint32_t e = lut[(uint32_t)(cont >> (64 - tl))];
+      const uint32_t nb = e >> 8;
+      out[produced++] = (uint8_t)e;
+      cont <<= nb; bitpos -= (int32_t)nb; avail -= (int32_t)nb;
+    }
+  }
+  return bitpos != 0;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 1: classify + decode huff0 planes into scratch
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
+                                                              uint8_t* __restrict__ scratch, uint64_t slot,
+                                                              ZnPlaneDesc* __restrict__ descs, uint32_t* __restrict__ status) {
+  __shared__ ZnTabScratch S;
+  __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
+  __shared__ uint8_t sh_symlist[256];
+  __shared__ uint32_t sh_rank_start[14], sh_sym_start[14];
+  __shared__ int sh_hs; __shared__ uint32_t sh_nsym, sh_tl;
+
+  const uint32_t lane = threadIdx.x;
+  const uint64_t pc = blockIdx.x;
+  const uint32_t p = (uint32_t)(pc / g.K);
+  const uint64_t c = pc % g.K;
+  const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
+  ZnPlaneDesc d; d.off = 0; d.kind = ZN_KIND_RAW; d.len = m.plen;
+
+  uint32_t bad = 0;
+  if (!m.ok) bad = ZN_DEV_CORRUPT;
+  else if (m.type > 1u) bad = ZN_DEV_BAD_TYPE;
+  else if (m.type == 0u) { if (m.csize < m.plen) bad = ZN_DEV_CORRUPT; d.off = m.off; }
+  else {  // HUF_decompress conventions
+    if (m.plen == 0 || m.csize > m.plen || m.csize == 0) bad = ZN_DEV_CORRUPT;
+    else if (m.csize == m.plen) { d.off = m.off; }
+    else if (m.csize == 1u) { d.kind = ZN_KIND_RLE; d.off = body[m.off]; }
+    else { d.kind = ZN_KIND_HUF; d.off = pc * slot; }
+  }
+  if (bad) { d.kind = ZN_KIND_RLE; d.off = 0; }   // keep the merge kernel in bounds; output is discarded by the caller
+
+  if (!bad && d.kind == ZN_KIND_HUF) {
+    const uint8_t* src = body + m.off;
+    // stage the tree description (≤ 129 bytes) and parse it on lane 0
+    for (uint32_t i = lane; i < 160u; i += ZN_WAVE) S.hdr[i] = (i < m.csize) ? src[i] : 0;
+    __syncthreads();
+    if (lane == 0) {
+      uint32_t nsym = 0, tl = 0;
+      sh_hs = zn_read_stats(&S, S.hdr, m.csize < 160u ? m.csize : 160u, &nsym, &tl);
+      sh_nsym = nsym; sh_tl = tl;
+    }
+    __syncthreads();
+    const int hs = sh_hs; const uint32_t tl = sh_tl;
+    if (hs < 0 || (uint32_t)hs >= m.csize || m.csize - (uint32_t)hs < 10u) bad = ZN_DEV_CORRUPT;
+    else {
+      zn_order_symbols(S.weights, sh_nsym, tl, sh_symlist, sh_rank_start, sh_sym_start, lane);
+      __syncthreads();
+      if (sh_rank_start[13] != (1u << tl)) bad = ZN_DEV_CORRUPT;
+      else {
+        for (uint32_t u = lane; u < (1u << tl); u += ZN_WAVE)
+          lut[u] = (uint16_t)zn_lut_entry(u, tl, sh_symlist, sh_rank_start, sh_sym_start);
+      }
+      __syncthreads();
+      if (!bad) {
+        const uint8_t* js = src + hs; const uint32_t rem = m.csize - (uint32_t)hs;
+        const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+        const uint32_t seg = (m.plen + 3u) / 4u;
+        if (l1 + l2 + l3 + 6u > rem || 3u * seg > m.plen) bad = ZN_DEV_CORRUPT;
+        else if (lane < 4) {
+          const uint32_t lens[4] = {l1, l2, l3, rem - 6u - l1 - l2 - l3};
+          uint32_t so = 6; for (uint32_t k = 0; k < lane; k++) so += lens[k];
+          const uint32_t nout = (lane < 3) ? seg : m.plen - 3u * seg;
+          if (zn_decode_stream_serial(js + so, lens[lane], scratch + d.off + (uint64_t)lane * seg, nout, lut, tl))
+            bad = ZN_DEV_CORRUPT;
+        }
+      }
+    }
+  }
+  if (bad) atomicOr(status, bad);
+  if (lane == 0) descs[pc] = d;
+}
+
+// ---------------------------------------------------------------------------
+// kernel 2: merge planes of one chunk into the output
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const uint8_t* body, const uint8_t* scratch, uint32_t i) {
+  if (d.kind == ZN_KIND_RLE) return (uint32_t)d.off & 0xFFu;
+  const uint8_t* b = (d.kind == ZN_KIND_HUF) ? scratch : body;
+  return b[d.off + i];
+}
+
+template <int P>
+__global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t* __restrict__ body,
+                                                         const uint8_t* __restrict__ scratch,
+                                                         const ZnPlaneDesc* __restrict__ descs, uint8_t* __restrict__ dst) {
+  const uint64_t c = blockIdx.x;
+  const uint32_t clen = zn_chunk_len(g, c);
+  uint8_t* out = dst + c * g.chunk;
+  ZnPlaneDesc d[P];
+  for (int p = 0; p < P; p++) d[p] = descs[(uint64_t)p * g.K + c];
+  const uint32_t nwords = clen / 4u;
+  // whole 32-bit words: gather P-way, undo the rotate (applies to clen/4 words — all of them)
+  for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
+    uint32_t w = 0;
+    for (uint32_t t = 0; t < 4; t++) {
+      const uint32_t j = 4u * wi + t;
+      w |= zn_plane_byte(d[j % P], body, scratch, j / P) << (8 * t);
+    }
+    if (g.rot) w = (P == 2) ? zn_rot_inv16(w) : zn_rot_inv32(w);
+    const uint64_t a = (uint64_t)(out + 4ull * wi);
+    if ((a & 3u) == 0) *(uint32_t*)(out + 4ull * wi) = w;
+    else for (uint32_t t = 0; t < 4; t++) out[4ull * wi + t] = (uint8_t)(w >> (8 * t));
+  }
+  // trailing clen % 4 bytes are never rotated (reference rotates len/4 words only)
+  if (threadIdx.x < (clen & 3u)) {
+    const uint32_t j = 4u * nwords + threadIdx.x;
+    out[j] = (uint8_t)zn_plane_byte(d[j % P], body, scratch, j / P);
+  }
+}
+
+void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_scratch,
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, hipStream_t stream) {
+  if (g.K == 0) return;
+  const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
+  hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)(g.P * g.K)), dim3(ZN_WAVE), 0, stream, g, d_body, body_len,
+                     d_scratch, slot, d_descs, d_status);
+  zn_note_kernel("zn_k_decode_planes");
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst);
+  zn_note_kernel("zn_k_merge_planes");
+}

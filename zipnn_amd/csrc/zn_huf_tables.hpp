@@ -1,0 +1,454 @@
+// zn_huf_tables.hpp — huff0 table construction on the device (one lane, LDS scratch).
+//
+// These routines are the serial part of the codec: ≤256 symbols per plane-chunk.
+// They run on lane 0 of a workgroup while the other lanes wait at a barrier; the
+// data-parallel parts (histogram, LUT fill, bit packing, stream decode) live in the
+// kernels.  Everything follows the huff0 format of zstd 1.4.8 exactly, including
+// tie-breaks, because compressed bytes must equal the CPU reference's
+// (reference call sites: csrc/zipnn_core.c:366 HUF_compress, :807 HUF_decompress).
+// Spec: SURVEY.md Appendix B.
+#pragma once
+
+#include "zn_common.hpp"
+
+// ---------------------------------------------------------------------------
+// LDS scratch shared by the table builders of one workgroup
+// ---------------------------------------------------------------------------
+struct ZnHNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nb; };
+
+struct ZnTabScratch {
+  uint32_t count[256];       // byte histogram (encoder)
+  uint8_t  weights[256];     // huff0 weights (decoder input / encoder header)
+  uint8_t  nbits[256];       // code length per symbol (encoder)
+  uint16_t vals[256];        // code value per symbol (encoder)
+  uint8_t  hdr[160];         // tree description bytes (≤ 1 + 128)
+  // FSE over the weight alphabet (≤13 symbols, table log ≤ 6)
+  int16_t  norm[16];
+  uint16_t next[16];
+  uint32_t tt_nb[16];
+  int32_t  tt_fs[16];
+  uint8_t  cell[64];
+  uint16_t state[64];
+  uint8_t  dnb[64];
+};
+
+// ---------------------------------------------------------------------------
+// bit helpers over small byte arrays
+// ---------------------------------------------------------------------------
+// nb (≤25) bits starting at bit `bitpos`, LSB-first, zero-filled past the end
+__device__ inline uint32_t zn_bits_at(const uint8_t* p, uint32_t nbytes, uint32_t bitpos, uint32_t nb) {
+  uint32_t byte = bitpos >> 3, v = 0;
+  for (uint32_t i = 0; i < 4; i++) { uint32_t b = byte + i; v |= (b < nbytes ? (uint32_t)p[b] : 0u) << (8 * i); }
+  return (v >> (bitpos & 7)) & ((1u << nb) - 1u);
+}
+// the nb bits just below `pos` of a backward stream (MSB = bit pos-1), zero-filled below bit 0
+__device__ inline uint32_t zn_peek_back(const uint8_t* p, uint32_t nbytes, int32_t pos, uint32_t nb) {
+  if (nb == 0 || pos <= 0) return 0;
+  if ((uint32_t)pos >= nb) return zn_bits_at(p, nbytes, (uint32_t)pos - nb, nb);
+  return zn_bits_at(p, nbytes, 0, (uint32_t)pos) << (nb - (uint32_t)pos);
+}
+
+// FSE_optimalTableLog_internal: 32-bit unsigned arithmetic, wrap-around included
+__device__ inline uint32_t zn_optimal_table_log(uint32_t max_log, uint32_t src_size, uint32_t max_sv, uint32_t minus) {
+  uint32_t max_bits_src = zn_hb32(src_size - 1u) - minus;
+  uint32_t t = max_log;
+  uint32_t a = zn_hb32(src_size) + 1u, b = zn_hb32(max_sv) + 2u;
+  uint32_t min_bits = a < b ? a : b;
+  if (max_bits_src < t) t = max_bits_src;
+  if (min_bits > t) t = min_bits;
+  if (t < ZN_FSE_LOG_MIN) t = ZN_FSE_LOG_MIN;
+  if (t > ZN_FSE_LOG_MAX) t = ZN_FSE_LOG_MAX;
+  return t;
+}
+
+// ---------------------------------------------------------------------------
+// decoder side: tree description -> weights
+// ---------------------------------------------------------------------------
+// FSE-coded weights (HUF_readStats → FSE_decompress_wksp).  src: n bytes.
+// Returns number of weights written to w (≤255) or -1.
+__device__ inline int zn_fse_decode_weights(ZnTabScratch* S, uint8_t* w, const uint8_t* src, uint32_t n) {
+  uint32_t bitpos = 0, nsym = 0, tl;
+  const uint32_t nbits_total = n * 8u;
+  if (n < 1) return -1;
+  tl = zn_bits_at(src, n, 0, 4) + ZN_FSE_LOG_MIN; bitpos = 4;
+  if (tl > ZN_WEIGHT_FSE_LOG) return -1;
+  {
+    int remaining = (1 << tl) + 1, threshold = 1 << tl, nb_bits = (int)tl + 1, prev0 = 0;
+    while (remaining > 1 && nsym <= 12u) {   // weight alphabet is 0..12 (HUF_TABLELOG_MAX)
+      if (prev0) {
+        uint32_t n0 = nsym;
+        while (zn_bits_at(src, n, bitpos, 16) == 0xFFFFu) { n0 += 24; bitpos += 16; if (bitpos > nbits_total + 64u) return -1; }
+        while (zn_bits_at(src, n, bitpos, 2) == 3u) { n0 += 3; bitpos += 2; if (bitpos > nbits_total + 64u) return -1; }
+        n0 += zn_bits_at(src, n, bitpos, 2); bitpos += 2;
+        if (n0 > 12u) return -1;
+        while (nsym < n0) S->norm[nsym++] = 0;
+      }
+      {
+        const int mx = (2 * threshold - 1) - remaining; int c;
+        const int lo = (int)zn_bits_at(src, n, bitpos, (uint32_t)nb_bits - 1u);
+        if (lo < mx) { c = lo; bitpos += (uint32_t)nb_bits - 1u; }
+        else { c = (int)zn_bits_at(src, n, bitpos, (uint32_t)nb_bits); if (c >= threshold) c -= mx; bitpos += (uint32_t)nb_bits; }
+        c--;
+        remaining -= c < 0 ? -c : c;
+        S->norm[nsym++] = (int16_t)c; prev0 = !c;
+        if (remaining < 1) return -1;
+        while (remaining < threshold) { nb_bits--; threshold >>= 1; }
+      }
+    }
+    if (remaining != 1 || bitpos > nbits_total) return -1;
+  }
+  const uint32_t hdr_bytes = (bitpos + 7u) >> 3;
+  // decode table: cell -> (symbol, nbBits, base)
+  {
+    const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t high = size - 1u, pos = 0;
+    for (uint32_t s = 0; s < nsym; s++) {
+      if (S->norm[s] == -1) { S->cell[high--] = (uint8_t)s; S->next[s] = 1; } else S->next[s] = (uint16_t)S->norm[s];
+    }
+    for (uint32_t s = 0; s < nsym; s++)
+      for (int i = 0; i < S->norm[s]; i++) {
+        S->cell[pos] = (uint8_t)s; pos = (pos + step) & mask;
+        while (pos > high) pos = (pos + step) & mask;
+      }
+    if (pos != 0) return -1;
+    for (uint32_t u = 0; u < size; u++) {
+      uint32_t ns = S->next[S->cell[u]]++; uint32_t nb = tl - zn_hb32(ns);
+      S->dnb[u] = (uint8_t)nb; S->state[u] = (uint16_t)((ns << nb) - size);
+    }
+  }
+  // two interleaved states over a backward bit stream
+  {
+    const uint8_t* bs = src + hdr_bytes; const uint32_t bn = n - hdr_bytes;
+    if (n <= hdr_bytes || bs[bn - 1] == 0) return -1;
+    int32_t pos = (int32_t)(bn - 1u) * 8 + (int32_t)zn_hb32(bs[bn - 1]);
+    uint32_t s1 = zn_peek_back(bs, bn, pos, tl); pos -= (int32_t)tl;
+    uint32_t s2 = zn_peek_back(bs, bn, pos, tl); pos -= (int32_t)tl;
+    if (pos < 0) return -1;
+    int o = 0;
+    for (;;) {
+      if (o >= 255) return -1;
+      w[o++] = S->cell[s1];
+      { uint32_t nb = S->dnb[s1]; uint32_t v = zn_peek_back(bs, bn, pos, nb); pos -= (int32_t)nb; s1 = S->state[s1] + v; }
+      if (pos < 0) { if (o >= 255) return -1; w[o++] = S->cell[s2]; break; }
+      if (o >= 255) return -1;
+      w[o++] = S->cell[s2];
+      { uint32_t nb = S->dnb[s2]; uint32_t v = zn_peek_back(bs, bn, pos, nb); pos -= (int32_t)nb; s2 = S->state[s2] + v; }
+      if (pos < 0) { if (o >= 255) return -1; w[o++] = S->cell[s1]; break; }
+    }
+    return o;
+  }
+}
+
+// HUF_readStats: src (csize bytes, staged in LDS/global) -> S->weights[0..nsym), tableLog.
+// Returns header size consumed, or -1 on malformed input.
+__device__ inline int zn_read_stats(ZnTabScratch* S, const uint8_t* src, uint32_t csize, uint32_t* nsym_out, uint32_t* tl_out) {
+  uint8_t* w = S->weights;
+  uint32_t isz, osz, total = 0, rank1 = 0;
+  if (csize == 0) return -1;
+  isz = src[0];
+  if (isz >= 128u) {
+    osz = isz - 127u; isz = (osz + 1u) / 2u;
+    if (isz + 1u > csize) return -1;
+    for (uint32_t n = 0; n < osz; n += 2) { w[n] = src[1 + n / 2] >> 4; w[n + 1] = src[1 + n / 2] & 15; }
+  } else {
+    if (isz + 1u > csize) return -1;
+    int r = zn_fse_decode_weights(S, w, src + 1, isz);
+    if (r < 0) return -1;
+    osz = (uint32_t)r;
+  }
+  for (uint32_t n = 0; n < osz; n++) {
+    if (w[n] >= ZN_HUF_LOG_MAX) return -1;
+    total += (1u << w[n]) >> 1; rank1 += (w[n] == 1);
+  }
+  if (total == 0) return -1;
+  {
+    const uint32_t tl = zn_hb32(total) + 1u;
+    if (tl > ZN_HUF_LOG_MAX) return -1;
+    const uint32_t rest = (1u << tl) - total;
+    if ((1u << zn_hb32(rest)) != rest) return -1;
+    const uint32_t last = zn_hb32(rest) + 1u;
+    w[osz] = (uint8_t)last; rank1 += (last == 1);
+    *tl_out = tl;
+  }
+  if (rank1 < 2 || (rank1 & 1)) return -1;
+  *nsym_out = osz + 1u;
+  return (int)(isz + 1u);
+}
+
+// ---------------------------------------------------------------------------
+// encoder side: histogram -> code lengths/values -> tree description
+// ---------------------------------------------------------------------------
+// order: count descending, equal counts keep ascending symbol order (HUF_sort)
+__device__ inline void zn_huf_sort(ZnHNode* node, const uint32_t* count, uint32_t max_sv) {
+  uint32_t base[33], cur[33];
+  for (int i = 0; i < 33; i++) base[i] = 0;
+  for (uint32_t n = 0; n <= max_sv; n++) base[zn_hb32(count[n] + 1u)]++;
+  for (int n = 30; n > 0; n--) base[n - 1] += base[n];
+  for (int i = 0; i < 33; i++) cur[i] = base[i];
+  for (uint32_t n = 0; n <= max_sv; n++) {
+    const uint32_t c = count[n], r = zn_hb32(c + 1u) + 1u;
+    uint32_t pos = cur[r]++;
+    while (pos > base[r] && c > node[pos - 1].count) { node[pos] = node[pos - 1]; pos--; }
+    node[pos].count = c; node[pos].byte = (uint8_t)n;
+  }
+}
+
+// HUF_setMaxHeight
+__device__ inline uint32_t zn_huf_limit_height(ZnHNode* node, uint32_t last, uint32_t max_nb) {
+  const uint32_t largest = node[last].nb;
+  if (largest <= max_nb) return largest;
+  int cost = 0; const uint32_t base_cost = 1u << (largest - max_nb);
+  int n = (int)last;
+  while (node[n].nb > max_nb) { cost += (int)(base_cost - (1u << (largest - node[n].nb))); node[n].nb = (uint8_t)max_nb; n--; }
+  while (node[n].nb == max_nb) n--;
+  cost >>= (largest - max_nb);
+  const uint32_t NONE = 0xF0F0F0F0u;
+  uint32_t rank_last[ZN_HUF_LOG_MAX + 2];
+  for (uint32_t i = 0; i < ZN_HUF_LOG_MAX + 2; i++) rank_last[i] = NONE;
+  { uint32_t cur = max_nb;
+    for (int pos = n; pos >= 0; pos--) { if (node[pos].nb >= cur) continue; cur = node[pos].nb; rank_last[max_nb - cur] = (uint32_t)pos; } }
+  while (cost > 0) {
+    uint32_t d = zn_hb32((uint32_t)cost) + 1u;
+    for (; d > 1; d--) {
+      const uint32_t hp = rank_last[d], lp = rank_last[d - 1];
+      if (hp == NONE) continue;
+      if (lp == NONE) break;
+      if (node[hp].count <= 2u * node[lp].count) break;
+    }
+    while (d <= ZN_HUF_LOG_MAX && rank_last[d] == NONE) d++;
+    cost -= 1 << (d - 1);
+    if (rank_last[d - 1] == NONE) rank_last[d - 1] = rank_last[d];
+    node[rank_last[d]].nb++;
+    if (rank_last[d] == 0) rank_last[d] = NONE;
+    else { rank_last[d]--; if (node[rank_last[d]].nb != max_nb - d) rank_last[d] = NONE; }
+  }
+  while (cost < 0) {
+    if (rank_last[1] == NONE) {
+      while (node[n].nb == max_nb) n--;
+      node[n + 1].nb--; rank_last[1] = (uint32_t)(n + 1); cost++; continue;
+    }
+    node[rank_last[1] + 1].nb--; rank_last[1]++; cost++;
+  }
+  return max_nb;
+}
+
+// HUF_buildCTable: S->count[0..max_sv] -> S->nbits/S->vals; tab0 = 513 nodes of LDS.
+// Returns the maximum code length.
+__device__ inline uint32_t zn_huf_build_ctable(ZnTabScratch* S, ZnHNode* tab0, uint32_t max_sv, uint32_t max_nb_bits) {
+  const int START = 256;
+  ZnHNode* node = tab0 + 1;
+  for (int i = 0; i < 513; i++) { tab0[i].count = 0; tab0[i].parent = 0; tab0[i].byte = 0; tab0[i].nb = 0; }
+  zn_huf_sort(node, S->count, max_sv);
+  int non_null = (int)max_sv;
+  while (node[non_null].count == 0) non_null--;
+  int low_s = non_null, node_nb = START, low_n = START;
+  const int root = node_nb + low_s - 1;
+  node[node_nb].count = node[low_s].count + node[low_s - 1].count;
+  node[low_s].parent = node[low_s - 1].parent = (uint16_t)node_nb;
+  node_nb++; low_s -= 2;
+  for (int n = node_nb; n <= root; n++) node[n].count = 1u << 30;
+  tab0[0].count = 1u << 31;   // node[-1]: barrier below the smallest leaf
+  while (node_nb <= root) {
+    const int n1 = (node[low_s].count < node[low_n].count) ? low_s-- : low_n++;
+    const int n2 = (node[low_s].count < node[low_n].count) ? low_s-- : low_n++;
+    node[node_nb].count = node[n1].count + node[n2].count;
+    node[n1].parent = node[n2].parent = (uint16_t)node_nb;
+    node_nb++;
+  }
+  node[root].nb = 0;
+  for (int n = root - 1; n >= START; n--) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
+  for (int n = 0; n <= non_null; n++) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
+  max_nb_bits = zn_huf_limit_height(node, (uint32_t)non_null, max_nb_bits);
+  uint16_t per_rank[ZN_HUF_LOG_MAX + 1], val_rank[ZN_HUF_LOG_MAX + 1];
+  for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) { per_rank[i] = 0; val_rank[i] = 0; }
+  for (int n = 0; n <= non_null; n++) per_rank[node[n].nb]++;
+  { uint16_t mn = 0; for (int n = (int)max_nb_bits; n > 0; n--) { val_rank[n] = mn; mn = (uint16_t)(mn + per_rank[n]); mn >>= 1; } }
+  for (int n = 0; n <= (int)max_sv; n++) S->nbits[node[n].byte] = node[n].nb;
+  for (int n = 0; n <= (int)max_sv; n++) S->vals[n] = val_rank[S->nbits[n]]++;
+  return max_nb_bits;
+}
+
+// tiny LSB-first bit writer into S->hdr (tree descriptions are ≤ 129 bytes)
+struct ZnSmallBitW { uint8_t* out; uint32_t cap; uint64_t acc; uint32_t nacc; uint32_t nbytes; };
+__device__ inline void zn_sbw_add(ZnSmallBitW* w, uint32_t v, uint32_t nb) {
+  if (nb == 0) return;
+  w->acc |= ((uint64_t)(v & ((1u << nb) - 1u))) << w->nacc; w->nacc += nb;
+  while (w->nacc >= 8) { if (w->nbytes < w->cap) w->out[w->nbytes] = (uint8_t)w->acc; w->nbytes++; w->acc >>= 8; w->nacc -= 8; }
+}
+
+// FSE_normalizeCount (+ FSE_normalizeM2) for the weight histogram; low-probability
+// symbols get +1 (huff0 of zstd ≥ 1.4.7).  Returns 0 ok, 1 = rle, -1 = error.
+__device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_t* count, uint32_t total_in, uint32_t max_sv) {
+  const uint32_t rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+  uint64_t total = total_in;
+  const uint64_t scale = 62 - tl, step = (1ULL << 62) / (uint32_t)total, vstep = 1ULL << (scale - 20);
+  int still = 1 << tl; uint32_t largest = 0; int16_t largest_p = 0;
+  const uint32_t low_thr = (uint32_t)(total >> tl);
+  for (uint32_t s = 0; s <= max_sv; s++) {
+    if (count[s] == total) return 1;
+    if (count[s] == 0) { norm[s] = 0; continue; }
+    if (count[s] <= low_thr) { norm[s] = 1; still--; continue; }
+    int16_t p = (int16_t)(((uint64_t)count[s] * step) >> scale);
+    if (p < 8) { const uint64_t beat = vstep * rtb[p]; p += ((uint64_t)count[s] * step) - ((uint64_t)p << scale) > beat; }
+    if (p > largest_p) { largest_p = p; largest = s; }
+    norm[s] = p; still -= p;
+  }
+  if (-still < (norm[largest] >> 1)) { norm[largest] += (int16_t)still; return 0; }
+  // secondary normalisation
+  const int16_t UNSET = -2;
+  uint32_t distributed = 0, to_dist, low_one = (uint32_t)((total * 3) >> (tl + 1));
+  for (uint32_t s = 0; s <= max_sv; s++) {
+    if (count[s] == 0) { norm[s] = 0; continue; }
+    if (count[s] <= low_thr) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+    if (count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+    norm[s] = UNSET;
+  }
+  to_dist = (1u << tl) - distributed;
+  if (to_dist == 0) return 0;
+  if ((total / to_dist) > low_one) {
+    low_one = (uint32_t)((total * 3) / (to_dist * 2));
+    for (uint32_t s = 0; s <= max_sv; s++)
+      if (norm[s] == UNSET && count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; }
+    to_dist = (1u << tl) - distributed;
+  }
+  if (distributed == max_sv + 1) {
+    uint32_t best = 0, best_c = 0;
+    for (uint32_t s = 0; s <= max_sv; s++) if (count[s] > best_c) { best = s; best_c = count[s]; }
+    norm[best] += (int16_t)to_dist;
+    return 0;
+  }
+  if (total == 0) {
+    for (uint32_t s = 0; to_dist > 0; s = (s + 1) % (max_sv + 1))
+      if (norm[s] > 0) { to_dist--; norm[s]++; }
+    return 0;
+  }
+  {
+    const uint64_t vlog = 62 - tl, mid = (1ULL << (vlog - 1)) - 1;
+    const uint64_t rstep = (((1ULL << vlog) * to_dist) + mid) / (uint32_t)total;
+    uint64_t run = mid;
+    for (uint32_t s = 0; s <= max_sv; s++) {
+      if (norm[s] != UNSET) continue;
+      const uint64_t end = run + (uint64_t)count[s] * rstep;
+      const uint32_t wgt = (uint32_t)(end >> vlog) - (uint32_t)(run >> vlog);
+      if (wgt < 1) return -1;
+      norm[s] = (int16_t)wgt; run = end;
+    }
+  }
+  return 0;
+}
+
+// HUF_compressWeights: weights w[0..nw) -> dst.  0 = not compressible, 1 = single value,
+// >1 = size (1000 = "too long to be kept"), -1 = error.
+__device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint8_t* w, uint32_t nw) {
+  uint32_t count[ZN_HUF_LOG_MAX + 1];
+  uint32_t max_sv = ZN_HUF_LOG_MAX, max_c = 0;
+  if (nw <= 1) return 0;
+  for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) count[i] = 0;
+  for (uint32_t i = 0; i < nw; i++) count[w[i]]++;
+  while (count[max_sv] == 0) max_sv--;
+  for (uint32_t i = 0; i <= max_sv; i++) if (count[i] > max_c) max_c = count[i];
+  if (max_c == nw) return 1;
+  if (max_c == 1) return 0;
+  const uint32_t tl = zn_optimal_table_log(ZN_WEIGHT_FSE_LOG, nw, max_sv, 2);
+  { int r = zn_fse_normalize(S->norm, tl, count, nw, max_sv); if (r != 0) return r == 1 ? 0 : -1; }
+  uint32_t off = 0;
+  // FSE_writeNCount
+  {
+    const int table_size = 1 << tl;
+    int nb_bits = (int)tl + 1, remaining = table_size + 1, threshold = table_size;
+    uint32_t bits = 0; int nbit = 0; uint32_t sym = 0; const uint32_t alpha = max_sv + 1; int prev0 = 0;
+    bits += (tl - ZN_FSE_LOG_MIN) << nbit; nbit += 4;
+    while (sym < alpha && remaining > 1) {
+      if (prev0) {
+        uint32_t start = sym;
+        while (sym < alpha && !S->norm[sym]) sym++;
+        if (sym == alpha) break;
+        while (sym >= start + 24) { start += 24; bits += 0xFFFFu << nbit; dst[off] = (uint8_t)bits; dst[off + 1] = (uint8_t)(bits >> 8); off += 2; bits >>= 16; }
+        while (sym >= start + 3) { start += 3; bits += 3u << nbit; nbit += 2; }
+        bits += (sym - start) << nbit; nbit += 2;
+        if (nbit > 16) { dst[off] = (uint8_t)bits; dst[off + 1] = (uint8_t)(bits >> 8); off += 2; bits >>= 16; nbit -= 16; }
+      }
+      {
+        int c = S->norm[sym++];
+        const int mx = (2 * threshold - 1) - remaining;
+        remaining -= c < 0 ? -c : c;
+        c++;
+        if (c >= threshold) c += mx;
+        bits += (uint32_t)c << nbit; nbit += nb_bits; nbit -= (c < mx);
+        prev0 = (c == 1);
+        if (remaining < 1) return -1;
+        while (remaining < threshold) { nb_bits--; threshold >>= 1; }
+      }
+      if (nbit > 16) { dst[off] = (uint8_t)bits; dst[off + 1] = (uint8_t)(bits >> 8); off += 2; bits >>= 16; nbit -= 16; }
+    }
+    if (remaining != 1) return -1;
+    dst[off] = (uint8_t)bits; dst[off + 1] = (uint8_t)(bits >> 8);
+    off += (uint32_t)(nbit + 7) / 8u;
+  }
+  // FSE_buildCTable
+  {
+    const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t cumul[ZN_HUF_LOG_MAX + 3];
+    uint32_t high = size - 1u;
+    cumul[0] = 0;
+    for (uint32_t u = 1; u <= max_sv + 1; u++) {
+      if (S->norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; S->cell[high--] = (uint8_t)(u - 1); }
+      else cumul[u] = cumul[u - 1] + (uint32_t)S->norm[u - 1];
+    }
+    cumul[max_sv + 1] = size + 1;
+    { uint32_t pos = 0;
+      for (uint32_t s = 0; s <= max_sv; s++)
+        for (int i = 0; i < S->norm[s]; i++) { S->cell[pos] = (uint8_t)s; pos = (pos + step) & mask; while (pos > high) pos = (pos + step) & mask; } }
+    for (uint32_t u = 0; u < size; u++) { const uint32_t s = S->cell[u]; S->state[cumul[s]++] = (uint16_t)(size + u); }
+    int total = 0;
+    for (uint32_t s = 0; s <= max_sv; s++) {
+      const int f = S->norm[s];
+      if (f == 0) { S->tt_nb[s] = ((tl + 1) << 16) - (1u << tl); S->tt_fs[s] = 0; }
+      else if (f == -1 || f == 1) { S->tt_nb[s] = (tl << 16) - (1u << tl); S->tt_fs[s] = total - 1; total++; }
+      else {
+        const uint32_t max_bits_out = tl - zn_hb32((uint32_t)f - 1u);
+        S->tt_nb[s] = (max_bits_out << 16) - ((uint32_t)f << max_bits_out);
+        S->tt_fs[s] = total - f; total += f;
+      }
+    }
+  }
+  // FSE_compress_usingCTable: two states, symbols walked backwards
+  {
+    if (nw <= 2) return 0;
+    ZnSmallBitW bw; bw.out = dst + off; bw.cap = cap - off; bw.acc = 0; bw.nacc = 0; bw.nbytes = 0;
+    uint32_t i = nw, s1, s2;
+#define ZN_FSE_INIT(sym_) ({ const uint32_t y_ = (sym_); const uint32_t nb_ = (S->tt_nb[y_] + (1u << 15)) >> 16; \
+                            const uint32_t v_ = (nb_ << 16) - S->tt_nb[y_]; (uint32_t)S->state[(int)(v_ >> nb_) + S->tt_fs[y_]]; })
+#define ZN_FSE_ENC(st_, sym_) ({ const uint32_t y_ = (sym_); const uint32_t nb_ = ((st_) + S->tt_nb[y_]) >> 16; \
+                                 zn_sbw_add(&bw, (st_), nb_); (uint32_t)S->state[(int)((st_) >> nb_) + S->tt_fs[y_]]; })
+    if (nw & 1) { s1 = ZN_FSE_INIT(w[--i]); s2 = ZN_FSE_INIT(w[--i]); s1 = ZN_FSE_ENC(s1, w[--i]); }
+    else        { s2 = ZN_FSE_INIT(w[--i]); s1 = ZN_FSE_INIT(w[--i]); }
+    while (i > 0) { s2 = ZN_FSE_ENC(s2, w[--i]); s1 = ZN_FSE_ENC(s1, w[--i]); }
+#undef ZN_FSE_INIT
+#undef ZN_FSE_ENC
+    zn_sbw_add(&bw, s2, tl); zn_sbw_add(&bw, s1, tl);
+    zn_sbw_add(&bw, 1, 1);
+    uint32_t c = bw.nbytes;
+    if (bw.nacc) { if (bw.nbytes < bw.cap) bw.out[bw.nbytes] = (uint8_t)bw.acc; c++; }
+    if (c > bw.cap) return 1000;   // longer than any description huff0 would keep (needs < maxSV/2 ≤ 127)
+    off += c;
+  }
+  return (int)off;
+}
+
+// HUF_writeCTable: S->nbits -> S->hdr.  Returns header size, or -1 (caller stores the plane raw).
+__device__ inline int zn_huf_write_ctable(ZnTabScratch* S, uint32_t max_sv, uint32_t huff_log) {
+  uint8_t* w = S->weights; uint8_t* op = S->hdr;
+  for (uint32_t n = 0; n < max_sv; n++) w[n] = S->nbits[n] ? (uint8_t)(huff_log + 1u - S->nbits[n]) : 0;
+  {
+    // an FSE description is only kept when shorter than maxSV/2 ≤ 127 bytes
+    const int h = zn_huf_compress_weights(S, op + 1, 140, w, max_sv);
+    if (h < 0) return -1;
+    if (h > 1 && (uint32_t)h < max_sv / 2u) { op[0] = (uint8_t)h; return h + 1; }
+  }
+  if (max_sv > 128u) return -1;
+  op[0] = (uint8_t)(128u + (max_sv - 1u));
+  w[max_sv] = 0;
+  for (uint32_t n = 0; n < max_sv; n += 2) op[n / 2 + 1] = (uint8_t)((w[n] << 4) + w[n + 1]);
+  return (int)(((max_sv + 1u) / 2u) + 1u);
+}

@@ -1,0 +1,29 @@
+// zn_internal.hpp — host-side declarations shared by the kernel translation units
+// and the C-ABI (zn_api.hip).  Not part of the public interface (include/zipnn_hip.h).
+#pragma once
+
+#include "zn_common.hpp"
+
+// What the decoder resolved for one (plane, chunk): where its bytes come from.
+struct ZnPlaneDesc {
+  uint64_t off;    // RAW: byte offset into the body; HUF: byte offset into the scratch planes; RLE: the byte value
+  uint32_t kind;   // ZN_KIND_*
+  uint32_t len;    // uncompressed plane length
+};
+
+// Slot stride (bytes) of one plane of one chunk in the scratch-plane buffers.
+static inline size_t zn_plane_slot(size_t chunk, int P) { return ((chunk + (size_t)P - 1) / (size_t)P + 15) & ~(size_t)15; }
+
+// ---- generic decode path (any dtype, any tail) : zn_decode_generic.hip ----
+// descs: [P*K]; scratch: P*K slots of zn_plane_slot bytes; status: one device word.
+void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_scratch,
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, hipStream_t stream);
+
+// ---- generic encode path : zn_encode_generic.hip ----
+// planes/enc: P*K slots each; csize/type: [P*K]; offs: [P*K] u64; d_total: one u64 (body length).
+void zn_launch_encode_generic(const ZnGeom& g, const uint8_t* d_src, float threshold, uint8_t* d_planes,
+                              uint8_t* d_enc, uint32_t* d_csize, uint8_t* d_type, uint64_t* d_offs,
+                              uint64_t* d_total, uint8_t* d_body, hipStream_t stream);
+
+// kernel-name log for zn_last_kernels()
+void zn_note_kernel(const char* name);

@@ -1,0 +1,508 @@
+"""ZipNN().compress()/decompress() and the zipnn_safetensors() plugin, on MI355X.
+
+Drop-in for the reference's L3/L4 surface on the compress/decompress hot path
+(reference zipnn/zipnn.py: class ZipNN :27-1218, SafeOpen/zipnn_safetensors :1584-1643):
+same constructor keywords, same frame bytes, same return types, same exceptions — but
+the two calls into the C extension (zipnn.py:714 `zipnn_core.zipnn_core`, :1143
+`zipnn_core.combine_dtype`) go to the HIP library through `zipnn_amd._capi` instead.
+There is no CPU code path here: without a GPU / the built extension the calls raise.
+
+Additions the reference does not have (all optional):
+  * tensors that already live on a GPU are compressed in place in HBM (no host round trip
+    of the uncompressed bytes);
+  * `decompress(..., decompress_cpu_gpu="cuda:0")` (the reference accepts and ignores this
+    argument, zipnn.py:928) returns the tensor on that device, so a loader ships only the
+    compressed bytes over PCIe.
+"""
+import json
+import math
+import multiprocessing
+
+import numpy as np
+import torch
+
+from . import _capi, codec
+from .header import (HEADER_LEN, VERSION, EnumFormat, EnumLossy, EnumMethod, dtype_from_code, dtype_from_user,
+                     is_pow2, pack_shape, unpack_shape)
+
+FP8_CHUNK_CAP = 128 * 1024   # huff0 block limit; fp8 has one plane per chunk (reference zipnn.py:721,1148)
+
+
+def _delta_code(kind):
+    return 1 if kind == "byte" else 2 if kind == "file" else 0
+
+
+class ZipNN:
+    def __init__(self, method: str = "AUTO", input_format: str = "byte", bytearray_dtype: str = "bfloat16",
+                 is_monotonic: int = 0, threads: int = 0, compression_threshold=0.95, check_th_after_percent=10,
+                 byte_reorder: int = 0, reorder_signbit: int = 0, delta_compressed_type: str = 0,
+                 lossy_compressed_type: str = 0, lossy_compressed_factor=27, compression_chunk=256 * 1024,
+                 is_streaming: bool = False, streaming_chunk: int = 1024 * 1024, input_file: str = None,
+                 compressed_file: str = None, decompressed_file: str = None, zstd_level: int = 3,
+                 lz4_compression_level: int = 0):
+        """Same keywords as the reference constructor (zipnn/zipnn.py:29-51).
+
+        `method` only selects header byte 7: on this path the core always codes with huff0,
+        exactly as the reference does (zipnn.py:658-668 never changes the codec when byte
+        grouping is on).  `threads`, `check_th_after_percent`, `is_monotonic`, `byte_reorder`
+        and `reorder_signbit` are accepted and recorded; the GPU path has no use for them
+        (they are dead in the reference core too — SURVEY.md Appendix D).
+        """
+        self.method = EnumMethod(method).value
+        self.input_format = EnumFormat(input_format).value
+        self.bytearray_dtype = bytearray_dtype
+        self.is_monotonic = is_monotonic
+        self.threads = threads or min(multiprocessing.cpu_count(), 16)
+        self.compression_threshold = compression_threshold
+        self.check_th_after_percent = check_th_after_percent
+        self.byte_reorder = byte_reorder
+        self.reorder_signbit = reorder_signbit
+        self.delta_compressed_type = delta_compressed_type
+        self.lossy_compressed_type = EnumLossy.NONE if lossy_compressed_type is None else EnumLossy(lossy_compressed_type)
+        self.lossy_compressed_factor = lossy_compressed_factor
+        if not is_pow2(compression_chunk):
+            raise ValueError("compression_chunk must be a number that is a power of 2.")
+        self.compression_chunk = compression_chunk
+        if self.input_format != EnumFormat.BYTE.value and is_streaming:
+            raise ValueError("Streaming is currently implemented only for bytes data type.")
+        self.is_streaming = is_streaming
+        if not is_pow2(streaming_chunk):
+            raise ValueError("streaming_chunk must be a number that is a power of 2.")
+        self.streaming_chunk = streaming_chunk
+        self.input_file = input_file
+        self.compressed_file = compressed_file
+        self.decompressed_file = decompressed_file
+        self.zstd_level = zstd_level
+        self.lz4_compression_level = lz4_compression_level
+        if self.lossy_compressed_type != EnumLossy.NONE and self.input_format != EnumFormat.TORCH.value:
+            raise ValueError("When use lossy compression the input have to be torch.tensor")
+        self._version_major, self._version_minor, self._version_tiny = VERSION
+        self.header_length = HEADER_LEN
+        self._header = bytearray(HEADER_LEN)
+        self._ext_header = b""
+        self._shape_size = 0
+        self._update_header()
+
+    # ------------------------------------------------------------------ header
+    def _update_header(self):
+        """Static header fields (reference zipnn.py:355-394)."""
+        h = self._header
+        h[0:2] = b"ZN"
+        h[2], h[3], h[4] = VERSION
+        h[7] = self.method
+        h[8] = self.input_format
+        h[9] = 0 if self.delta_compressed_type is None else _delta_code(self.delta_compressed_type)
+        h[13] = 128 + int(math.log(self.streaming_chunk, 2)) if self.is_streaming else 0
+        h[14] = int(math.log(self.compression_chunk, 2))
+
+    def _retrieve_header(self, frame):
+        """Parse a frame header into instance state (the reference overwrites its own
+        configuration the same way, zipnn.py:396-438) and return the offset of the body."""
+        mv = memoryview(frame)
+        h = mv[:HEADER_LEN]
+        if h[0:2].tobytes() != b"ZN":
+            raise ValueError("Header should start with ZN")
+        self.version_major, self.version_minor, self.version_tiny = int(h[2]), int(h[3]), int(h[4])
+        self._byte_reorder = int(h[5])
+        self._bit_reorder = int(h[6])
+        self.method = int(h[7])
+        self.input_format = int(h[8])
+        d = self._header[9]   # sic: the reference reads its OWN header byte here (zipnn.py:420-422)
+        self.delta_compressed_type = "byte" if d == 1 else "file" if d == 2 else 0
+        self.lossy_compressed_type = int(h[10])
+        self.lossy_compressed_factor = int(h[11])
+        self._lossy_is_int = int(h[12])
+        self.is_streaming = 1 if int(h[13]) > 127 else 0
+        self.compression_chunk = 2 ** h[14]
+        self.dtype = int(h[15])
+        self.original_len = int.from_bytes(h[16:24], "little")
+        if self.input_format in (EnumFormat.TORCH.value, EnumFormat.NUMPY.value):
+            self.shape_bytes, self._shape_size = unpack_shape(mv[HEADER_LEN:])
+        else:
+            self._shape_size = 0
+        return HEADER_LEN + self._shape_size
+
+    def __metadata__(self):
+        info = {
+            "ZipNN version": ".".join(str(v) for v in VERSION),
+            "Byte reorder": self.byte_reorder, "Bit reorder": self.reorder_signbit, "Method": self.method,
+            "Input format": self.input_format, "Data type": self.bytearray_dtype, "Is monotonic": self.is_monotonic,
+            "Threads": self.threads, "Compression threshold": self.compression_threshold,
+            "Check threshold after percent": self.check_th_after_percent,
+            "Delta compressed type": self.delta_compressed_type, "Lossy compressed type": self.lossy_compressed_type,
+            "Lossy compressed factor": self.lossy_compressed_factor, "Compression chunk": self.compression_chunk,
+            "Is streaming": self.is_streaming, "Streaming chunk": self.streaming_chunk,
+            "Input file path": self.input_file, "Compressedfile path": self.compressed_file,
+            "Decompressed file path": self.decompressed_file,
+        }
+        print(info)
+        return info
+
+    def __version__(self):
+        print("ZipNN version: " + ".".join(str(v) for v in VERSION))
+
+    def metadata(self, file, version=False):
+        """Header fields of a compressed file / buffer as a dict (reference zipnn.py:497-553)."""
+        if isinstance(file, str):
+            with open(file, "rb") as f:
+                mv = memoryview(f.read(HEADER_LEN + 80))
+        else:
+            mv = memoryview(file)
+        h = mv[:HEADER_LEN]
+        if h[0:2].tobytes() != b"ZN":
+            raise ValueError("Header should start with ZN")
+        if version:
+            print(f"ZipNN version: {h[2]}.{h[3]}.{h[4]}")
+            return None
+        info = {
+            "zipnn version": f"{h[2]}.{h[3]}.{h[4]}", "byte_reorder": int(h[5]), "bit_reorder": int(h[6]),
+            "method": EnumMethod(int(h[7])).name if int(h[7]) in EnumMethod._value2member_map_ else "UNKNOWN",
+            "input_format": EnumFormat(int(h[8])).name if int(h[8]) in EnumFormat._value2member_map_ else "UNKNOWN",
+            "delta_compressed_type": "byte" if h[9] == 1 else "file" if h[9] == 2 else 0,
+            "lossy_compressed_type": EnumLossy(int(h[10])).name if int(h[10]) in EnumLossy._value2member_map_ else "NONE",
+            "lossy_compressed_factor": int(h[11]), "lossy_is_int": int(h[12]), "is_streaming": int(h[13]) > 127,
+            "compression_chunk": f"{2 ** h[14]} Bytes", "dtype": int(h[15]),
+            "original_len": f"{int.from_bytes(h[16:24], 'little')} Bytes",
+        }
+        if int(h[8]) in (EnumFormat.TORCH.value, EnumFormat.NUMPY.value):
+            info["shape_bytes"], info["shape_size"] = unpack_shape(mv[HEADER_LEN:])
+        print(info)
+        return info
+
+    # ------------------------------------------------------------------ compress
+    def compress(self, data, compress_cpu_gpu="cpu", delta_second_data=None, lossy_compressed_type: str = None,
+                 lossy_compressed_factor: int = None):
+        """Compress bytes / a torch tensor / a numpy array into one ZN frame (or, when
+        streaming, a bytearray of back-to-back frames).  Reference: zipnn.py:560-643."""
+        if self.delta_compressed_type == "byte":
+            if len(data) != len(delta_second_data):
+                raise ValueError("Length of delta file has to match the length of the original file.")
+        elif self.delta_compressed_type == "file":
+            try:
+                with open(delta_second_data, "rb") as f:
+                    delta_second_data = f.read()
+            except Exception:
+                raise FileNotFoundError("Encountered an error when reading the delta file")
+            if len(data) != len(delta_second_data):
+                raise ValueError("Length of delta file has to match the length of the original file.")
+        elif delta_second_data is not None:
+            raise ValueError("ZipNN isn't set for delta compression, but delta_second_data is not null.")
+
+        if self.is_streaming and self.input_format == EnumFormat.BYTE.value:
+            mv = memoryview(data).cast("B")
+            mvd = memoryview(delta_second_data).cast("B") if delta_second_data else None
+            out = bytearray()
+            for off in range(0, mv.nbytes, self.streaming_chunk):
+                piece = mv[off:off + self.streaming_chunk]
+                if mvd is not None:
+                    piece = _xor(piece, mvd[off:off + self.streaming_chunk])
+                out += self.compress_torch_numpy_byte(piece, lossy_compressed_type, lossy_compressed_factor)
+            return out
+        if delta_second_data:
+            data = _xor(data, delta_second_data)
+        return self.compress_torch_numpy_byte(data, lossy_compressed_type, lossy_compressed_factor)
+
+    def compress_torch_numpy_byte(self, data, lossy_compressed_type=None, lossy_compressed_factor=None):
+        """dtype -> (planes, rotate, byte mode), header, flat byte view, core call.
+        Reference: zipnn.py:748-867 and compress_bin :670-746."""
+        fmt = self.input_format
+        if fmt == EnumFormat.BYTE.value:
+            dt = dtype_from_user(self.bytearray_dtype)
+            is_float = self.bytearray_dtype in ("float64", "float32", "float16", "bfloat16", "float8_e4m3fn", "float8_e5m2")
+            shape = None
+        elif fmt == EnumFormat.TORCH.value:
+            dt = dtype_from_user(data.dtype)
+            is_float = torch.is_floating_point(data)
+            shape = tuple(data.shape)
+        elif fmt == EnumFormat.NUMPY.value:
+            dt = dtype_from_user(data.dtype)
+            is_float = np.issubdtype(data.dtype, np.floating)
+            shape = tuple(data.shape)
+        else:
+            raise ValueError("Unsupported input_format")
+        if not is_float:
+            if fmt == EnumFormat.NUMPY.value and np.dtype(data.dtype) == np.uint32:
+                raise ValueError("Not support uint32 with NumPy format")
+            raise ValueError("Support only uint32 with NumPy format")
+        if dt is None:
+            raise ValueError("Support only torch.dtype float32/bfloat16/float16")
+
+        h = self._header
+        h[5], h[6], h[15] = dt.byte_mode, dt.rotate, dt.code
+        chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
+        lib = _capi.lib()
+
+        if fmt == EnumFormat.TORCH.value and data.is_cuda:
+            flat = codec.flat_bytes(data)
+            h[16:24] = flat.numel().to_bytes(8, "little")
+            hdr = bytes(h) + pack_shape(shape)
+            return memoryview(codec.compress_device_to_frame(lib, hdr, flat, dt.planes, dt.rotate, dt.byte_mode, chunk,
+                                                             self.compression_threshold))
+        if fmt == EnumFormat.TORCH.value:
+            ba = memoryview(codec.flat_bytes(data).numpy())
+        elif fmt == EnumFormat.NUMPY.value:
+            ba = memoryview(np.ascontiguousarray(data).reshape(-1).view(np.uint8))
+        else:
+            ba = memoryview(data).cast("B")
+        h[16:24] = ba.nbytes.to_bytes(8, "little")
+        self._ext_header = pack_shape(shape) if shape is not None else self._ext_header
+        hdr = bytes(h) + (pack_shape(shape) if shape is not None else b"")
+        frame = lib.compress(hdr, ba, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold,
+                             device=codec.current_device())
+        h[24:32] = frame[24:32]   # the core patches the total length into the caller's header (zipnn_core.c:121)
+        return memoryview(frame)
+
+    # ------------------------------------------------------------------ decompress
+    def decompress(self, data, decompress_cpu_gpu="cpu", delta_second_data=None):
+        """Inverse of compress (reference zipnn.py:928-1005).  `decompress_cpu_gpu` other than
+        "cpu" (e.g. "gpu", "cuda", "cuda:1") keeps a TORCH-format result on that device."""
+        if self.delta_compressed_type == "byte":
+            if delta_second_data is None:
+                raise ValueError("delta_second_data is None or not set for delta copression")
+        elif self.delta_compressed_type == "file":
+            try:
+                with open(delta_second_data, "rb") as f:
+                    delta_second_data = f.read()
+            except Exception:
+                raise FileNotFoundError("Encountered an error when reading the delta file")
+        elif delta_second_data is not None:
+            raise ValueError("ZipNN isn't set for delta compression, but delta_second_data is not null.")
+
+        if isinstance(data, torch.Tensor):
+            mv = None
+            was_delta, stream_byte = int(data[9]), int(data[13])
+        else:
+            mv = memoryview(data).cast("B") if not isinstance(data, memoryview) else data
+            was_delta, stream_byte = mv[9], mv[13]
+        if was_delta == 0 and self.delta_compressed_type != 0:
+            raise ValueError("The data wasn't compressed using delta compression and you're trying to delta-decompress it.")
+        if was_delta != 0 and self.delta_compressed_type == 0:
+            raise ValueError("The data was compressed using delta compression and you're trying to decompress it normally.")
+        target = _resolve_device(decompress_cpu_gpu)
+
+        if self.input_format == EnumFormat.BYTE.value and stream_byte > 127 and mv is not None:
+            out = bytearray()
+            off = od = 0
+            mvd = memoryview(delta_second_data).cast("B") if delta_second_data else None
+            while off < mv.nbytes:
+                total = int.from_bytes(mv[off + 24:off + 32], "little")
+                piece = self.decompress_bin(mv[off:off + total])
+                if piece:
+                    if mvd is not None:
+                        if od + len(piece) > mvd.nbytes:
+                            raise ValueError("Length of delta file has to match the length of the decompressed file.")
+                        piece = _xor(piece, mvd[od:od + len(piece)])
+                        od += len(piece)
+                    out += piece
+                off += total
+            if mvd is not None and od != mvd.nbytes:
+                raise ValueError("Length of delta file has to match the length of the decompressed file.")
+            return out
+        if delta_second_data:
+            plain = self.decompress_bin(mv)
+            if len(plain) != len(delta_second_data):
+                raise ValueError("Length of delta file has to match the length of the decompressed file.")
+            return _xor(plain, delta_second_data)
+        return self.decompress_bin(data if mv is None else mv, target)
+
+    def decompress_bin(self, frame, target=None):
+        """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198)."""
+        on_device = isinstance(frame, torch.Tensor) and frame.is_cuda
+        head = bytes(frame[:HEADER_LEN + 80].cpu().numpy()) if isinstance(frame, torch.Tensor) else frame
+        body_off = self._retrieve_header(head)
+        dt = dtype_from_code(self.dtype)
+        if self.input_format == EnumFormat.NUMPY.value and dt.numpy is None:
+            raise ValueError(f"Unsupported Dtype {self.dtype}")
+        chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
+        lib = _capi.lib()
+        fmt = self.input_format
+
+        if fmt == EnumFormat.TORCH.value and (on_device or target is not None):
+            # device-resident result: only compressed bytes cross PCIe
+            dev = target if target is not None else frame.device
+            if isinstance(frame, torch.Tensor):
+                body = frame.reshape(-1).view(torch.uint8)[body_off:].to(dev, non_blocking=True)
+            else:
+                body = torch.frombuffer(bytearray(memoryview(frame)[body_off:]), dtype=torch.uint8).to(dev) \
+                    if len(frame) > body_off else torch.empty(0, dtype=torch.uint8, device=dev)
+            flat = codec.decompress_device(lib, body, dt.planes, self._bit_reorder, self._byte_reorder, chunk,
+                                           self.original_len)
+            return flat.view(dt.torch).reshape(self.shape_bytes)
+
+        if isinstance(frame, torch.Tensor):
+            frame = memoryview(frame.cpu().contiguous().view(torch.uint8).reshape(-1).numpy())
+        raw = lib.decompress(memoryview(frame)[body_off:], dt.planes, self._bit_reorder, self._byte_reorder, chunk,
+                             self.original_len, device=codec.current_device())
+        if fmt == EnumFormat.BYTE.value:
+            return memoryview(raw)
+        if fmt == EnumFormat.TORCH.value:
+            if self.original_len == 0:
+                return torch.empty(self.shape_bytes, dtype=dt.torch)
+            return torch.frombuffer(raw, dtype=torch.uint8).view(dt.torch).reshape(self.shape_bytes)
+        if fmt == EnumFormat.NUMPY.value:
+            return np.frombuffer(raw, dtype=dt.numpy).reshape(self.shape_bytes)
+        raise ValueError(f"Unsupported input_format {self.input_format}")
+
+    def decompress_read_file(self, data=None):
+        import os
+        filename = data if data is not None else self.compressed_file
+        if not os.path.exists(filename):
+            raise FileNotFoundError(f"The file at {filename} was not found.")
+        with open(filename, "rb") as f:
+            return self.decompress_bin(f.read())
+
+    def write_bin(self, ba_decom):
+        with open(self.decompressed_file, "wb") as f:
+            f.write(ba_decom)
+        return 0
+
+
+def _xor(a, b):
+    return np.bitwise_xor(np.frombuffer(a, dtype=np.uint8), np.frombuffer(b, dtype=np.uint8)).tobytes()
+
+
+def _resolve_device(spec):
+    """"cpu" -> None; "gpu"/"cuda" -> current device; "cuda:N" / torch.device -> that device."""
+    if spec is None or spec == "cpu":
+        return None
+    if isinstance(spec, torch.device):
+        return None if spec.type == "cpu" else spec
+    if spec in ("gpu", "cuda"):
+        return torch.device("cuda", codec.current_device())
+    return torch.device(spec)
+
+
+# ---------------------------------------------------------------------------------------
+# safetensors plugin (reference zipnn.py:1584-1643, util_safetensors.py, util_patch.py)
+# ---------------------------------------------------------------------------------------
+METADATA_KEY = "znn_compressed_vectors"     # reference util_safetensors.py:9
+COMPRESSION_METHOD = "HUFFMAN"
+COMPRESSED_DTYPE = torch.uint8
+
+
+def build_compressed_tensor_info(uncompressed_tensor):
+    """Per-tensor metadata stored under METADATA_KEY (reference util_safetensors.py:28-38)."""
+    return {"dtype": str(uncompressed_tensor.dtype).replace("torch.", "", 1),
+            "shape": str(list(uncompressed_tensor.shape))}
+
+
+def set_compressed_tensors_metadata(compressed_tensor_infos, metadata):
+    if metadata:
+        metadata[METADATA_KEY] = json.dumps(compressed_tensor_infos)
+
+
+def get_compressed_tensors_metadata(metadata):
+    if metadata:
+        return json.loads(metadata.get(METADATA_KEY) or "{}")
+    return {}
+
+
+def decompress_safetensors_tensor(tensor, device="cpu"):
+    """One stored uint8 frame tensor -> the original tensor (reference zipnn.py:1584-1589).
+    With a non-CPU `device` the frame is shipped compressed and decoded in HBM."""
+    znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
+    return znn.decompress(tensor.contiguous(), decompress_cpu_gpu=device if device is not None else "cpu")
+
+
+class SafeOpen:
+    """`safetensors.safe_open` wrapper that decompresses tensors named in the file's
+    `znn_compressed_vectors` metadata on access (reference zipnn.py:1592-1626).  Unlike the
+    reference it honours `device=` for compressed tensors and tolerates the extra keyword
+    arguments newer safetensors releases pass (`backend=`)."""
+
+    def __init__(self, filename, framework="pt", device="cpu", **kwargs):
+        self._device = device
+        # compressed tensors are read on the host and decoded on `device`
+        self._f = _ORIGINAL_SAFE_OPEN(filename, framework=framework, device=device, **kwargs)
+        self._host = None
+        self._filename, self._framework, self._kwargs = filename, framework, kwargs
+        self.compressed_tensors_metadata = get_compressed_tensors_metadata(self._f.metadata())
+
+    def _host_reader(self):
+        if str(self._device) == "cpu":
+            return self._f
+        if self._host is None:
+            self._host = _ORIGINAL_SAFE_OPEN(self._filename, framework=self._framework, device="cpu", **self._kwargs)
+            self._host.__enter__()
+        return self._host
+
+    def get_tensor(self, name):
+        if name not in self.compressed_tensors_metadata:
+            return self._f.get_tensor(name)
+        dev = "cpu" if str(self._device) == "cpu" else (self._device if not isinstance(self._device, int) else f"cuda:{self._device}")
+        return decompress_safetensors_tensor(self._host_reader().get_tensor(name), device=dev)
+
+    def get_slice(self, name):
+        if name not in self.compressed_tensors_metadata:
+            return self._f.get_slice(name)
+        return NotImplementedError   # sic: the reference returns (does not raise) it, zipnn.py:1617
+
+    def __enter__(self):
+        self._f.__enter__()
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        if self._host is not None:
+            self._host.__exit__(exc_type, exc_value, traceback)
+            self._host = None
+        return self._f.__exit__(exc_type, exc_value, traceback)
+
+    def __getattr__(self, name):
+        return getattr(self._f, name)
+
+
+def _capture_original_safe_open():
+    import safetensors
+    import safetensors.torch
+    fn = getattr(safetensors.torch, "safe_open", None)
+    if fn is None or isinstance(fn, type) and issubclass(fn, SafeOpen):
+        fn = safetensors.safe_open
+    return fn
+
+
+_ORIGINAL_SAFE_OPEN = _capture_original_safe_open()
+_patches_applied = {}
+
+
+def multi_process_patcher(patch_func):
+    """Apply patch_func here and in every process spawned from now on
+    (reference util_patch.py:11-47)."""
+    if patch_func in _patches_applied:
+        return
+    _patches_applied[patch_func] = None
+    patch_func()
+    from multiprocessing.process import BaseProcess
+    start = BaseProcess.start
+
+    def patched_start(self):
+        self._target = _TargetWrapper(self._target, patch_func)
+        return start(self)
+
+    BaseProcess.start = patched_start
+
+
+class _TargetWrapper:
+    def __init__(self, target, patch_func):
+        self.target, self.patch_func = target, patch_func
+
+    def __call__(self, *args, **kwargs):
+        multi_process_patcher(self.patch_func)
+        return self.target(*args, **kwargs) if self.target is not None else None
+
+
+def _zipnn_safetensors():
+    import safetensors
+    import safetensors.torch
+    safetensors.torch.safe_open = SafeOpen      # what the reference patches (zipnn.py:1635)
+    safetensors.safe_open = SafeOpen            # what transformers ≥ 5 imports
+
+
+def zipnn_safetensors():
+    """Plugin for the safetensors library to use ZipNN compression (reference zipnn.py:1638-1643)."""
+    multi_process_patcher(_zipnn_safetensors)
+
+
+def zipnn_hf(replace_local_file: bool = False):
+    """Out of scope here (whole-file .znn path tied to private symbols of
+    old transformers releases).  Use zipnn_safetensors()."""
+    raise NotImplementedError("zipnn_hf is not part of the MI355X hot-path build; use zipnn_safetensors()")
