@@ -102,6 +102,11 @@ int zn_release_workspace(void);
 /* Names of the kernels the last *_dev call launched, ';'-separated (for profiles). */
 const char* zn_last_kernels(void);
 
+/* Diagnostic: how many chunks of the last zn_decompress_dev call on the current device were
+ * decoded by the fused single-pass kernel (the rest went through the generic two-kernel path).
+ * Synchronises the device.  Returns a count >= 0 or a negative zn_status. */
+long long zn_last_fused_chunks(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -228,6 +228,11 @@ static inline uint32_t zn_simt_perm(uint32_t a, uint32_t b, uint32_t sel) {
 #define __builtin_amdgcn_perm(a, b, c) zn_simt_perm((a), (b), (c))
 #define __builtin_amdgcn_readfirstlane(v) __shfl((v), (int)__builtin_ctzll(__ballot(1)))
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+// On hardware the lanes of a wave run in lockstep, so LDS written by one lane is visible to the
+// others after the (code-less) wave barrier; here the lanes are fibers, so it must be a real
+// rendezvous of the wave.
+static inline void zn_simt_wave_barrier() { zn_simt::collective(0, nullptr); }
+#define __builtin_amdgcn_wave_barrier() zn_simt_wave_barrier()
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 

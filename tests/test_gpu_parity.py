@@ -97,6 +97,7 @@ def test_256MiB_bf16_bit_exact_vs_oracle(lib):
     assert hashlib.sha256(got).hexdigest() == hashlib.sha256(want[32:]).hexdigest()
     out = codec.decompress_device(lib, body, 2, 1, 10, C, raw.size)
     assert torch.equal(out.cpu(), torch.from_numpy(raw))
+    assert lib.last_fused_chunks() == raw.size // C      # every chunk through the single-pass kernel
     assert 0.655 < len(want) / raw.size < 0.670          # README: 66.3 % on bf16
 
 

@@ -69,3 +69,52 @@ def test_zipnn_api_reproduces_golden(use_simt, name):
     assert len(raw) == meta["in_len"] and G.sha(raw) == meta["in_sha256"]
     again = bytes(ZipNN(**ctor).compress(src))
     assert G.sha(again) == meta["frame_sha256"]
+
+
+FUSED = [("bf16", 3 * C, 2, 1, 10, C, 3), ("bf16", 2 * C + 100, 2, 1, 10, C, 2), ("fp16", 2 * C, 2, 0, 10, C, 2),
+         ("fp32", 2 * C, 4, 1, 220, C, 2), ("fp8", 2 * C, 1, 1, 10, C, 2), ("const", 2 * C, 2, 1, 10, C, 2),
+         ("rand", 2 * C, 2, 1, 10, C, 2), ("u11", 2 * C, 2, 1, 10, C, 2), ("skew", 2 * C, 1, 1, 10, C, 2),
+         ("bf16", 2 * 4096 * 3, 2, 1, 10, 4096, 6), ("bf16", 256 * 1024, 2, 1, 10, 256 * 1024, 1)]
+
+
+def _gen2(kind, nb, seed):
+    if kind == "u11":
+        g = torch.Generator().manual_seed(seed)
+        return (torch.rand(nb // 2, generator=g) * 2 - 1).to(torch.bfloat16).view(torch.uint8).numpy().tobytes()
+    if kind == "skew":   # one symbol > 50 %: 1-bit codes, smallest sub-blocks
+        r = np.random.default_rng(seed)
+        return r.choice(np.array([7, 9, 200, 31, 32, 33], dtype=np.uint8), nb, p=[0.6, 0.2, 0.1, 0.05, 0.03, 0.02]).tobytes()
+    return gen_bytes(kind, nb, seed)
+
+
+@pytest.mark.parametrize("case", FUSED, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
+def test_fused_decode_path(simt_lib, case):
+    """Full chunks with ≤ 1 Huffman plane must go through zn_k_decode_fused and give the input back."""
+    kind, nb, P, rot, bm, chunk, want_fused = case
+    d = _gen2(kind, nb, 11)
+    frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8)
+    out = torch.empty(nb, dtype=torch.uint8)
+    simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
+    assert out.numpy().tobytes() == d
+    assert simt_lib.last_fused_chunks() == want_fused
+    assert "zn_k_decode_fused" in simt_lib.last_kernels()
+
+
+def test_fused_detects_corrupt_stream(simt_lib):
+    d = gen_bytes("bf16", 2 * C, 4)
+    frame = bytearray(O.compress_frame(HDR, d, 2, 1, 10, C))
+    p = G.parse_frame(bytes(frame) if frame[8] in (2, 3) else bytes(frame[:32]) + bytes(frame[32:])) if False else None
+    K = 2
+    meta = 32 + 9 * 2 * K
+    plane0 = int.from_bytes(frame[32 + 2 * K + 8 * (K - 1): 32 + 2 * K + 8 * K], "little")
+    # flip bits in the middle of the first Huffman block of plane 1
+    frame[meta + plane0 + 5000] ^= 0xFF
+    body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8)
+    out = torch.empty(2 * C, dtype=torch.uint8)
+    try:
+        simt_lib.decompress_dev(body.data_ptr(), body.numel(), 2, 1, 10, C, 2 * C, out.data_ptr())
+        same = out.numpy().tobytes() == d
+    except RuntimeError:
+        same = False
+    assert not same    # either flagged corrupt or (self-synchronising code) different bytes; never a crash or hang

@@ -52,6 +52,7 @@ class ZnLib:
         L.zn_decompress_dev.restype = ci
         L.zn_decompress_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, vp, vp, ci]
         L.zn_release_workspace.restype = ci
+        L.zn_last_fused_chunks.restype = ctypes.c_longlong
         self._L = L
         if L.zn_abi_version() != 1:
             raise ImportError(f"{path}: unexpected ABI version {L.zn_abi_version()}")
@@ -123,6 +124,13 @@ class ZnLib:
         rc = self._L.zn_decompress_dev(body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr,
                                        stream, 1 if check else 0)
         self._check(rc)
+
+    def last_fused_chunks(self):
+        """Chunks of the last decompress_dev call that took the fused single-pass kernel."""
+        n = self._L.zn_last_fused_chunks()
+        if n < 0:
+            self._check(int(n))
+        return int(n)
 
     def release_workspace(self):
         self._check(self._L.zn_release_workspace())

@@ -26,6 +26,7 @@ thread_local std::string t_kernels;
 // Grow-only device buffers cached per device; guarded by one mutex (calls on the same
 // device serialise on their workspace — independent GPUs run in independent processes).
 struct Workspace {
+  size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
   void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[6] = {0, 0, 0, 0, 0, 0};
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
@@ -152,12 +153,16 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
   const size_t PK = (size_t)g.P * g.K;
   if ((rc = ws_reserve(w, WS_PLANES, PK * slot))) return rc;
   if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(ZnPlaneDesc)))) return rc;
+  if ((rc = ws_reserve(w, WS_META_B, g.K))) return rc;                      // per-chunk "done by the fused kernel" flags
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
+  uint8_t* d_done = (uint8_t*)w.buf[WS_META_B];
+  w.last_K = g.K;
   ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+  zn_launch_decode_fused(g, (const uint8_t*)d_body, body_len, (uint8_t*)d_dst, d_done, d_status, stream);
   zn_launch_decode_generic(g, (const uint8_t*)d_body, body_len, (uint8_t*)w.buf[WS_PLANES], (ZnPlaneDesc*)w.buf[WS_META_C],
-                           d_status, (uint8_t*)d_dst, stream);
+                           d_status, (uint8_t*)d_dst, d_done, stream);
   ZN_HIP(hipGetLastError());
   if (check) {
     ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -210,6 +215,21 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
   } while (0);
   (void)hipFree(d_body); (void)hipFree(d_dst);
   return rc;
+}
+
+long long zn_last_fused_chunks(void) {
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Workspace& w = g_ws[dev];
+  if (!w.last_K || !w.buf[WS_META_B]) return 0;
+  std::string flags(w.last_K, '\0');
+  ZN_HIP(hipDeviceSynchronize());
+  ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_B], w.last_K, hipMemcpyDeviceToHost));
+  long long n = 0;
+  for (char f : flags) n += (f != 0);
+  return n;
 }
 
 int zn_release_workspace(void) {

@@ -17,70 +17,7 @@
 // Huffman-coded plane is zn_decode_fused.hip.
 #include "zn_internal.hpp"
 #include "zn_huf_tables.hpp"
-
-// ---------------------------------------------------------------------------
-// metadata of one (plane, chunk), computed identically by every lane
-// ---------------------------------------------------------------------------
-struct ZnPcMeta { uint64_t off; uint32_t csize; uint32_t plen; uint32_t type; uint32_t ok; };
-
-__device__ inline ZnPcMeta zn_pc_meta(const ZnGeom& g, const uint8_t* body, uint64_t body_len, uint32_t p, uint64_t c) {
-  ZnPcMeta m;
-  const uint64_t PK = (uint64_t)g.P * g.K;
-  const uint8_t* cum = body + PK;                       // u64 [P][K], inclusive, unaligned
-  uint64_t base = 9u * PK;                              // payload start
-  for (uint32_t q = 0; q < p; q++) base += zn_ld64(cum + 8u * ((uint64_t)q * g.K + g.K - 1));
-  const uint64_t hi = zn_ld64(cum + 8u * ((uint64_t)p * g.K + c));
-  const uint64_t lo = c ? zn_ld64(cum + 8u * ((uint64_t)p * g.K + c - 1)) : 0;
-  m.type = body[(uint64_t)p * g.K + c];
-  m.plen = zn_plane_len(zn_chunk_len(g, c), g.P, p);
-  m.ok = (hi >= lo) && (hi - lo <= 0xFFFFFFFFull) && (base + hi <= body_len);
-  m.csize = (uint32_t)(hi - lo);
-  m.off = base + lo;
-  return m;
-}
-
-// ---------------------------------------------------------------------------
-// single-symbol decode LUT, filled by all lanes of the calling wave(s)
-// ---------------------------------------------------------------------------
-// weights -> symbols ordered by (weight, symbol) + per-weight start cells.  Wave 0 only.
-// sh_symlist[256], sh_rank_start[14] (cells), sh_sym_start[14] (index into symlist).
-__device__ inline void zn_order_symbols(const uint8_t* weights, uint32_t nsym, uint32_t tl, uint8_t* sh_symlist,
-                                        uint32_t* sh_rank_start, uint32_t* sh_sym_start, uint32_t lane) {
-  uint32_t cnt[13];
-  for (int v = 0; v < 13; v++) cnt[v] = 0;
-  // pass 1: per-weight totals
-  for (uint32_t q = 0; q < 256; q += ZN_WAVE) {
-    const uint32_t s = q + lane; const uint32_t w = (s < nsym) ? weights[s] : 0u;
-    for (uint32_t v = 1; v <= 12; v++) cnt[v] += (uint32_t)__popcll(__ballot(w == v));
-  }
-  uint32_t rs[14], ss[14]; uint32_t cells = 0, syms = 0;
-  rs[0] = 0; ss[0] = 0;
-  for (uint32_t v = 1; v <= 12; v++) { rs[v] = cells; ss[v] = syms; cells += cnt[v] << (v - 1); syms += cnt[v]; }
-  rs[13] = cells; ss[13] = syms;
-  if (lane < 14) { sh_rank_start[lane] = rs[lane]; sh_sym_start[lane] = ss[lane]; }
-  // pass 2: rank of every symbol inside its weight class
-  uint32_t run[13];
-  for (int v = 0; v < 13; v++) run[v] = 0;
-  for (uint32_t q = 0; q < 256; q += ZN_WAVE) {
-    const uint32_t s = q + lane; const uint32_t w = (s < nsym) ? weights[s] : 0u;
-    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    for (uint32_t v = 1; v <= 12; v++) {
-      const uint64_t m = __ballot(w == v);
-      if (w == v) sh_symlist[ss[v] + run[v] + (uint32_t)__popcll(m & lt)] = (uint8_t)s;
-      run[v] += (uint32_t)__popcll(m);
-    }
-  }
-  (void)tl;
-}
-
-// cell u -> (symbol | nbBits << 8); cells of weight w (code length tl+1-w) are contiguous
-__device__ inline uint32_t zn_lut_entry(uint32_t u, uint32_t tl, const uint8_t* sh_symlist, const uint32_t* sh_rank_start,
-                                        const uint32_t* sh_sym_start) {
-  uint32_t w = 1;
-  for (uint32_t v = 2; v <= 12; v++) w += (u >= sh_rank_start[v]) ? 1u : 0u;   // rank_start is non-decreasing
-  const uint32_t j = (u - sh_rank_start[w]) >> (w - 1);
-  return (uint32_t)sh_symlist[sh_sym_start[w] + j] | ((tl + 1u - w) << 8);
-}
+#include "zn_decode_common.hpp"
 
 // ---------------------------------------------------------------------------
 // one backward stream decoded by one lane (byte-granular; the generic path only)
@@ -122,7 +59,8 @@ __device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
                                                               uint8_t* __restrict__ scratch, uint64_t slot,
-                                                              ZnPlaneDesc* __restrict__ descs, uint32_t* __restrict__ status) {
+                                                              ZnPlaneDesc* __restrict__ descs, uint32_t* __restrict__ status,
+                                                              const uint8_t* __restrict__ done) {
   __shared__ ZnTabScratch S;
   __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
   __shared__ uint8_t sh_symlist[256];
@@ -133,6 +71,7 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const ui
   const uint64_t pc = blockIdx.x;
   const uint32_t p = (uint32_t)(pc / g.K);
   const uint64_t c = pc % g.K;
+  if (done && done[c]) return;                 // chunk already written by the fused kernel
   const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
   ZnPlaneDesc d; d.off = 0; d.kind = ZN_KIND_RAW; d.len = m.plen;
 
@@ -201,8 +140,10 @@ __device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const ui
 template <int P>
 __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t* __restrict__ body,
                                                          const uint8_t* __restrict__ scratch,
-                                                         const ZnPlaneDesc* __restrict__ descs, uint8_t* __restrict__ dst) {
+                                                         const ZnPlaneDesc* __restrict__ descs, uint8_t* __restrict__ dst,
+                                                         const uint8_t* __restrict__ done) {
   const uint64_t c = blockIdx.x;
+  if (done && done[c]) return;
   const uint32_t clen = zn_chunk_len(g, c);
   uint8_t* out = dst + c * g.chunk;
   ZnPlaneDesc d[P];
@@ -228,14 +169,15 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t
 }
 
 void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_scratch,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, hipStream_t stream) {
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, const uint8_t* d_done,
+                              hipStream_t stream) {
   if (g.K == 0) return;
   const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
   hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)(g.P * g.K)), dim3(ZN_WAVE), 0, stream, g, d_body, body_len,
-                     d_scratch, slot, d_descs, d_status);
+                     d_scratch, slot, d_descs, d_status, d_done);
   zn_note_kernel("zn_k_decode_planes");
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst);
-  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst);
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst, d_done);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst, d_done);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst, d_done);
   zn_note_kernel("zn_k_merge_planes");
 }

@@ -16,8 +16,14 @@ static inline size_t zn_plane_slot(size_t chunk, int P) { return ((chunk + (size
 
 // ---- generic decode path (any dtype, any tail) : zn_decode_generic.hip ----
 // descs: [P*K]; scratch: P*K slots of zn_plane_slot bytes; status: one device word.
+// d_done: [K] flags written by the fused kernel (1 = chunk already decoded), or nullptr.
 void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_scratch,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, hipStream_t stream);
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, const uint8_t* d_done,
+                              hipStream_t stream);
+
+// ---- fused decode path (full chunks, ≤1 Huffman plane) : zn_decode_fused.hip ----
+void zn_launch_decode_fused(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_dst, uint8_t* d_done,
+                            uint32_t* d_status, hipStream_t stream);
 
 // ---- generic encode path : zn_encode_generic.hip ----
 // planes/enc: P*K slots each; csize/type: [P*K]; offs: [P*K] u64; d_total: one u64 (body length).
