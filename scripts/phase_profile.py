@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""Developer tool: build libzipnn_hip_prof.so (-DZN_PHASE_TIMERS) and print where wave 0 of the
+fused decode kernel spends its shader-clock cycles, per chunk.  Runs on the GPU box:
+    python scripts/phase_profile.py [GiB]
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from zipnn_amd import _capi, codec   # noqa: E402
+from zipnn_amd.build import hipcc_path, sources   # noqa: E402
+
+NAMES = {0: "metadata", 1: "tree description (serial)", 2: "LUT fill", 3: "flush rows", 4: "stage tile", 5: "sync run-in",
+         6: "count pass", 7: "fix-up passes", 8: "scan/shuffles", 9: "write pass"}
+
+
+def main():
+    gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    so = os.path.join(ROOT, "zipnn_amd", "libzipnn_hip_prof.so")
+    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZN_PHASE_TIMERS",
+                    "-o", so] + sources(), check=True)
+    lib = _capi.ZnLib(so)
+    raw = ctypes.CDLL(so)
+    n = int(gib * (1 << 30)) // (256 * 1024) * (256 * 1024)
+    torch.manual_seed(1)
+    x = (torch.randn(n // 2, device="cuda") * 0.02).to(torch.bfloat16)
+    flat = codec.flat_bytes(x)
+    body = codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95).clone()
+    out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    acc = (ctypes.c_ulonglong * 64)()
+    codec.decompress_device(lib, body, 2, 1, 10, 256 * 1024, n, out=out)
+    raw.zn_debug_phase_read(acc, 1)
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record()
+    codec.decompress_device(lib, body, 2, 1, 10, 256 * 1024, n, out=out, check=False)
+    t1.record(); torch.cuda.synchronize()
+    raw.zn_debug_phase_read(acc, 1)
+    assert torch.equal(out, flat)
+    chunks = acc[19] or 1
+    tot = sum(acc[i] for i in range(10))
+    print(f"{gib} GiB, {chunks} chunks, decode {t0.elapsed_time(t1):.3f} ms (with timers)")
+    for i in range(10):
+        print(f"  {NAMES[i]:28s} {acc[i] / chunks:10.0f} cyc/chunk  {100.0 * acc[i] / tot:5.1f} %")
+    print(f"  total                        {tot / chunks:10.0f} cyc/chunk")
+    print(f"  tiles/chunk(wave0) {acc[18] / chunks:.2f}  fix-up iterations/tile {acc[16] / max(acc[18], 1):.3f}  "
+          f"mismatching lanes/tile {acc[17] / max(acc[18], 1):.3f}")
+
+
+if __name__ == "__main__":
+    main()

@@ -226,7 +226,10 @@ static inline uint32_t zn_simt_perm(uint32_t a, uint32_t b, uint32_t sel) {
 #define __builtin_amdgcn_alignbit(a, b, c) zn_simt_alignbit((a), (b), (c))
 #define __builtin_amdgcn_alignbyte(a, b, c) zn_simt_alignbyte((a), (b), (c))
 #define __builtin_amdgcn_perm(a, b, c) zn_simt_perm((a), (b), (c))
-#define __builtin_amdgcn_readfirstlane(v) __shfl((v), (int)__builtin_ctzll(__ballot(1)))
+// v_readlane with a wave-uniform index: every lane gets lane idx's value
+#define __builtin_amdgcn_readlane(v, idx) __shfl((v), (int)(idx))
+// used by the kernels only on values that are already wave-uniform
+#define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
 // On hardware the lanes of a wave run in lockstep, so LDS written by one lane is visible to the
 // others after the (code-less) wave barrier; here the lanes are fibers, so it must be a real

@@ -75,3 +75,20 @@ __device__ __forceinline__ uint32_t zn_chunk_len(const ZnGeom& g, uint64_t c) {
 __device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P, uint32_t p) {
   return chunk_len / P + (p < chunk_len % P ? 1u : 0u);
 }
+
+// ---------------------------------------------------------------------------
+// Optional in-kernel phase timers (developer tool: scripts/phase_profile.py builds a second
+// library with -DZN_PHASE_TIMERS; the shipped libzipnn_hip.so has none of this).  Thread 0 of
+// each workgroup adds the shader-clock cycles spent since the previous mark to slot i.
+// ---------------------------------------------------------------------------
+#ifdef ZN_PHASE_TIMERS
+static __device__ unsigned long long zn_phase_acc[64];   // one copy per translation unit; only the fused decode TU reads it back
+#define ZN_PT_DECL unsigned long long zn_pt_t0_ = __builtin_readcyclecounter()
+#define ZN_PT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); \
+                      if (threadIdx.x == 0) atomicAdd(&zn_phase_acc[i], t_ - zn_pt_t0_); zn_pt_t0_ = t_; } while (0)
+#define ZN_PT_COUNT(i, n) do { if (threadIdx.x == 0) atomicAdd(&zn_phase_acc[i], (unsigned long long)(n)); } while (0)
+#else
+#define ZN_PT_DECL do { } while (0)
+#define ZN_PT(i) do { } while (0)
+#define ZN_PT_COUNT(i, n) do { } while (0)
+#endif

@@ -4,22 +4,26 @@
 // block (what real weights look like: bf16/fp32 exponent plane Huffman-coded, mantissa
 // planes stored raw).  Wave w owns quarter w of the chunk = stream w of the huff0 block.
 //
-//   1. threads < P parse the chunk's metadata; the workgroup builds the decode table in LDS:
-//      tree description (FSE-coded weights) → canonical single-symbol LUT → MULTI-symbol LUT
-//      (one 64-bit entry per 11-bit window: up to 4 symbols, total length, first length).
+//   1. threads < P parse the chunk's metadata; wave 0 turns the tree description into the
+//      canonical symbol order (zn_huf_wave.hpp: FSE chain on the scalar ALU, everything else
+//      with ballots); all 256 threads fill the single-symbol LUT and from it the MULTI-symbol
+//      LUT: one 64-bit entry per 11-bit window = up to 4 symbols, their start offsets, total.
 //   2. each wave decodes its backward bit-stream IN PARALLEL ACROSS ITS 64 LANES.  huff0 has no
 //      gap array, so this uses Huffman self-synchronisation, format-transparently: the stream
 //      is cut into tiles of 64 sub-blocks of D dwords; lane k guesses a start a few dozen bits
 //      above its sub-block, decodes until it crosses into it ("sync"), then decodes its
 //      sub-block counting symbols; a wave shuffle checks that every lane's exit position is the
 //      next lane's start (mismatching lanes restart from the exact position until the chain is
-//      consistent — the top lane always starts from the true position carried from the previous
-//      tile); a prefix sum of the counts gives each lane its output offset and a second decode
-//      writes the symbols with LDS atomic-OR into a small ring.
-//   3. as soon as the ring holds a row of 64 × (16/P) symbols the wave flushes it: ring bytes +
-//      the raw planes' bytes (unaligned vector loads straight from the body) are byte-interleaved
-//      with v_perm_b32, the sign-bit rotate is undone and 16 bytes per lane go out in one
-//      coalesced store.  Decoded symbols never touch HBM; the float stream is written once.
+//      consistent, and the run-in is doubled for the rest of the stream — the top lane always
+//      starts from the true position carried from the previous tile); a prefix sum of the
+//      counts gives each lane its output offset and a second decode ORs the symbols into a
+//      small LDS ring (ds_or_b32: neighbouring lanes share boundary dwords).
+//   3. the number of complete output rows is known after the prefix sum, so the raw planes'
+//      bytes for exactly those rows are requested from HBM before the write pass and consumed
+//      after it: ring bytes + raw bytes are byte-interleaved with v_perm_b32, the sign-bit rotate
+//      is undone and 16-byte stores go out coalesced.  The next tile of the stream is prefetched
+//      into registers the same way.  Decoded symbols never touch HBM; the float stream is
+//      written once.
 //
 // Algorithmic HBM traffic per chunk: stored bytes in + chunk bytes out.
 // Chunks this kernel does not take (partial tail, ≥2 Huffman planes, tableLog 12, odd chunk
@@ -29,16 +33,16 @@
 // HUF_decompress (:807), combine_buffers_dtype16/32 + revert_all_floats_* (data_manipulation_
 // dtype16.c:145-216, data_manipulation_dtype32.c:275-294,391-456).
 #include "zn_internal.hpp"
-#include "zn_huf_tables.hpp"
+#include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
 
 #define ZN_F_THREADS 256
-#define ZN_F_RING_BYTES 8192u
+#define ZN_F_RING_BYTES 7168u            // per wave; multiple of every row size (512 / 1024 symbols)
 #define ZN_F_RING_DW (ZN_F_RING_BYTES / 4u)
 #define ZN_F_DMAX 8
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
-#define ZN_F_DELTA 96
+#define ZN_F_DELTA0 48                   // initial sync run-in (bits); doubles after a mismatch
 
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
@@ -49,12 +53,16 @@ struct ZnFusedLds {
   uint64_t lut[1u << ZN_F_TLMAX];          // multi-symbol decode table
   uint32_t ring[4][ZN_F_RING_DW];          // per-wave output ring; ring[0] holds the 16-bit LUT while tables are built
   uint32_t in[4][ZN_F_IN_DW];              // per-wave staged stream tile
-  ZnTabScratch S;
-  uint8_t symlist[256];
+  uint8_t w[256], symlist[256], cell[64];
   uint32_t rank_start[14], sym_start[14];
   ZnFusedPlane plane[4];
-  int hs; uint32_t nsym, tl, fail;
+  ZnWaveStats st;
 };
+
+// multi-symbol LUT entry: low dword = up to 4 symbols (unused bytes 0); high dword =
+//   cnt (bits 0-2) | total length (4-7) | start offset of symbol 1/2/3 (8-11/12-15/16-19; 15 = absent)
+#define ZN_E_CNT(hi) ((hi) & 7u)
+#define ZN_E_TOT(hi) (((hi) >> 4) & 15u)
 
 // wave-wide exclusive prefix sum (all 64 lanes participate)
 __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
@@ -66,13 +74,12 @@ __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane,
 
 // Decode the symbols whose codes start at bit positions in (stop, pos] of the staged tile.
 // MODE 0: just advance (sync run-in); 1: count symbols; 2: write symbols into the ring at symbol
-// index `wbyte` (LDS atomic OR: neighbouring lanes share boundary dwords).
-// base_bit = absolute bit position of bit 0 of in[0].
+// index `wbyte`.  base_bit = absolute bit position of bit 0 of in[0].
 template <int MODE>
 __device__ __forceinline__ int32_t zn_fused_run(const uint64_t* lut, const uint32_t* in, int32_t base_bit, uint32_t TL,
                                                 int32_t pos, int32_t stop, uint32_t* count, uint32_t* ring, uint32_t wbyte) {
   uint64_t win = 0; int32_t avail = 0;
-  uint64_t acc = 0; uint32_t fill = wbyte & 3u; uint32_t dw = (wbyte >> 2) & (ZN_F_RING_DW - 1u);
+  uint64_t acc = 0; uint32_t fill = wbyte & 3u; uint32_t dw = (wbyte >> 2) % ZN_F_RING_DW;
   uint32_t n = 0;
   while (pos > stop) {
     if (avail < (int32_t)TL) {
@@ -83,14 +90,20 @@ __device__ __forceinline__ int32_t zn_fused_run(const uint64_t* lut, const uint3
     }
     const uint64_t e = lut[(uint32_t)(win >> (64u - TL))];
     const uint32_t hi = (uint32_t)(e >> 32);
-    uint32_t nb, cnt, syms;
-    if (pos - stop >= (int32_t)TL) { nb = (hi >> 4) & 15u; cnt = hi & 7u; syms = (uint32_t)e; }   // every symbol of the group starts above `stop`
-    else { nb = (hi >> 8) & 15u; cnt = 1u; syms = (uint32_t)e & 0xFFu; }                           // near the boundary: one symbol at a time
+    uint32_t nb = ZN_E_TOT(hi), cnt = ZN_E_CNT(hi), syms = (uint32_t)e;
+    const int32_t room = pos - stop;
+    if (room < (int32_t)TL) {
+      // near the boundary: keep only the symbols of this group that START above `stop`
+      const uint32_t r = (uint32_t)room;                    // 1 … TL-1; absent symbols carry start offset 15
+      const uint32_t s1 = (hi >> 8) & 15u, s2 = (hi >> 12) & 15u, s3 = (hi >> 16) & 15u;
+      const uint32_t keep = 1u + (s1 < r ? 1u : 0u) + (s2 < r ? 1u : 0u) + (s3 < r ? 1u : 0u);
+      if (keep < cnt) { nb = (hi >> (4u + 4u * keep)) & 15u; cnt = keep; syms &= (1u << (8u * keep)) - 1u; }
+    }
     win <<= nb; avail -= (int32_t)nb; pos -= (int32_t)nb;
     if (MODE == 1) n += cnt;
     if (MODE == 2) {
       acc |= (uint64_t)syms << (8u * fill); fill += cnt;
-      if (fill >= 4u) { atomicOr(&ring[dw], (uint32_t)acc); acc >>= 32; fill -= 4u; dw = (dw + 1u) & (ZN_F_RING_DW - 1u); }
+      if (fill >= 4u) { atomicOr(&ring[dw], (uint32_t)acc); acc >>= 32; fill -= 4u; dw = (dw + 1u == ZN_F_RING_DW) ? 0u : dw + 1u; }
     }
   }
   if (MODE == 2 && fill > 0u) atomicOr(&ring[dw], (uint32_t)acc);
@@ -98,34 +111,22 @@ __device__ __forceinline__ int32_t zn_fused_run(const uint64_t* lut, const uint3
   return pos;
 }
 
-// EPL = 16/P bytes of plane p for this lane: from the ring (Huffman plane), a splat (RLE) or the body (raw).
-template <int EPL>
-__device__ __forceinline__ void zn_fused_plane_bytes(uint32_t* v, const ZnFusedPlane& pl, bool is_huf, uint32_t* ring,
-                                                     const uint8_t* raw_q, uint32_t sym_index) {
-  if (is_huf) {
-    const uint32_t i = (sym_index >> 2) & (ZN_F_RING_DW - 1u);
-    for (int k = 0; k < EPL / 4; k++) { v[k] = ring[i + k]; ring[i + k] = 0; }
-  } else if (pl.kind == ZN_KIND_RLE) {
-    for (int k = 0; k < EPL / 4; k++) v[k] = ((uint32_t)pl.off & 0xFFu) * 0x01010101u;
-  } else {
-    const uint8_t* a = raw_q + sym_index;
-    if (EPL == 4) v[0] = *(const zn_u32u*)a;
-    else for (int k = 0; k < EPL / 8; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); v[2 * k] = (uint32_t)t; v[2 * k + 1] = (uint32_t)(t >> 32); }
-  }
-}
-
 template <int P>
 __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
                                                                   uint8_t* __restrict__ dst, uint8_t* __restrict__ done,
                                                                   uint32_t* __restrict__ status) {
-  constexpr int EPL = 16 / P;                 // bytes per plane per lane in one flushed row
-  constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row
+  constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
+  constexpr int EW = EPL / 4;                 // … in dwords
+  constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
+  constexpr int RB = (P == 2) ? 14 : 7;       // rows whose raw bytes are kept in flight at once
   __shared__ ZnFusedLds L;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t c = blockIdx.x;
   const uint32_t clen = zn_chunk_len(g, c);
   const uint32_t plen = (uint32_t)(g.chunk / P);
+  const uint8_t* body_end = body + body_len;
+  ZN_PT_DECL;
 
   // ---- metadata: one thread per plane ----
   if (tid < (uint32_t)P) {
@@ -139,14 +140,15 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
     }
     L.plane[tid] = pl;
   }
-  if (tid == 0) L.fail = 0;
   __syncthreads();
+  ZN_PT(0);   // metadata
 
-  int h = -1; uint32_t nhuf = 0; bool elig = (g.chunk % 4096u) == 0 && ((((uint64_t)dst) & 15u) == 0);
+  int h = -1; uint32_t nhuf = 0; uint64_t h_off = 0; uint32_t h_csize = 0; bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
+  ZnFusedPlane pl[P];
   for (int p = 0; p < P; p++) {
-    const uint32_t k = L.plane[p].kind;
-    if (k == 99u) elig = false;
-    if (k == ZN_KIND_HUF) { h = p; nhuf++; }
+    pl[p] = L.plane[p];
+    if (pl[p].kind == 99u) elig = false;
+    if (pl[p].kind == ZN_KIND_HUF) { h = p; nhuf++; h_off = pl[p].off; h_csize = pl[p].csize; }
   }
   if (!elig || nhuf > 1u) { if (tid == 0) done[c] = 0; return; }
 
@@ -156,42 +158,46 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
 
   if (h >= 0) {
     // ---- decode table ----
-    const uint8_t* src = body + L.plane[h].off; const uint32_t csize = L.plane[h].csize;
-    for (uint32_t i = tid; i < 160u; i += ZN_F_THREADS) L.S.hdr[i] = (i < csize) ? src[i] : 0;
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t nsym = 0, tl = 0;
-      L.hs = zn_read_stats(&L.S, L.S.hdr, csize < 160u ? csize : 160u, &nsym, &tl);
-      L.nsym = nsym; L.tl = tl;
+    const uint8_t* src = body + h_off; const uint32_t csize = h_csize;
+    if (wave == 0) {
+      const ZnWaveStats st = zn_wave_read_stats(src, csize, body_end, lane, L.w, L.symlist, L.rank_start, L.sym_start, L.cell);
+      if (lane == 0) L.st = st;
     }
     __syncthreads();
-    const int hs = L.hs; TL = L.tl;
+    ZN_PT(1);   // tree description (wave 0)
+    const ZnWaveStats st = L.st;
+    const int hs = st.hs; TL = st.tl;
     if (hs < 0 || TL > ZN_F_TLMAX || (uint32_t)hs >= csize || csize - (uint32_t)hs < 10u) { if (tid == 0) done[c] = 0; return; }
-    if (wave == 0) zn_order_symbols(L.S.weights, L.nsym, TL, L.symlist, L.rank_start, L.sym_start, lane);
-    __syncthreads();
-    if (L.rank_start[13] != (1u << TL)) { if (tid == 0) done[c] = 0; return; }
     uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
-    for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS)
-      lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist, L.rank_start, L.sym_start);
+    {
+      const ZnRankTab rt = zn_load_ranks(L.rank_start, L.sym_start);
+      for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist, rt, L.rank_start, L.sym_start);
+    }
     __syncthreads();
     {
+      // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
       const uint32_t mask = (1u << TL) - 1u;
-      for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) {
-        uint32_t pos = 0, cnt = 0, syms = 0, len0 = 0;
-        while (cnt < 4u) {
-          const uint32_t e = lut16[(u << pos) & mask]; const uint32_t len = e >> 8;
-          if (pos + len > TL) break;        // the window does not hold this code completely
-          if (cnt == 0) len0 = len;
-          syms |= (e & 0xFFu) << (8u * cnt); pos += len; cnt++;
+      uint32_t pos[8], cnt[8], syms[8], starts[8];
+      for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; starts[k] = 0xFFF00u; }
+      for (int step = 0; step < 4; step++) {
+        for (int k = 0; k < 8; k++) {
+          const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+          if (u <= mask && cnt[k] == (uint32_t)step) {
+            const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
+            if (pos[k] + len <= TL) {             // the window holds this code completely
+              if (step > 0) starts[k] = (starts[k] & ~(15u << (4 + 4 * step))) | (pos[k] << (4 + 4 * step));
+              syms[k] |= (e & 0xFFu) << (8 * step); pos[k] += len; cnt[k]++;
+            }
+          }
         }
-        L.lut[u] = (uint64_t)syms | ((uint64_t)(cnt | (pos << 4) | (len0 << 8)) << 32);
+      }
+      for (int k = 0; k < 8; k++) {
+        const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+        if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)(cnt[k] | (pos[k] << 4) | starts[k]) << 32);
       }
     }
     // shortest code length → how many symbols a tile can hold → sub-block size D (dwords)
-    uint32_t vmax = 1;
-    for (uint32_t v = 1; v <= 12; v++) if (L.rank_start[v + 1] > L.rank_start[v]) vmax = v;
-    const uint32_t lmin = TL + 1u - vmax;
-    D = ((ZN_F_RING_BYTES - UNIT) * lmin) / 2048u;
+    D = ((ZN_F_RING_BYTES - UNIT) * st.lmin) / 2048u;
     if (D > ZN_F_DMAX) D = ZN_F_DMAX;
     if (D < 1u) D = 1u;
     // jump table → this wave's stream
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
     const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
     stream = js + so; slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
     __syncthreads();                         // lut16 (aliasing ring[0]) is dead from here on
+    ZN_PT(2);   // LUT fill
   }
 
   // ---- per-wave: zero the ring, decode the stream tile by tile, flush rows ----
@@ -211,10 +218,9 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
   for (uint32_t i = lane; i < ZN_F_RING_DW; i += 64u) ring[i] = 0;
   __builtin_amdgcn_wave_barrier();
 
-  const uint8_t* rawq[P]; ZnFusedPlane pl[P];
-  for (int p = 0; p < P; p++) { pl[p] = L.plane[p]; rawq[p] = body + pl[p].off + (uint64_t)wave * seg; }
+  const uint8_t* rawq[P];
+  for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
   uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
-  const uint8_t* body_end = body + body_len;
 
   uint32_t J = (h >= 0) ? 0u : seg;           // symbols decoded into the ring so far
   uint32_t JF = 0;                            // symbols flushed to HBM so far
@@ -229,47 +235,86 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
     hi_dw = (carry + 31) >> 5;
   }
   const int32_t Di = (int32_t)D;
-  const int32_t delta = (ZN_F_DELTA < 32 * Di) ? ZN_F_DELTA : 32 * Di;
+  int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
 
-  for (;;) {
-    // flush every complete row the ring holds
-    while (J - JF >= UNIT) {
-      uint32_t v[P][EPL / 4 > 0 ? EPL / 4 : 1];
-      const uint32_t si = JF + (uint32_t)EPL * lane;
-      for (int p = 0; p < P; p++) zn_fused_plane_bytes<EPL>(v[p], pl[p], p == h, ring, rawq[p], si);
-      uint32_t o[4];
-      if (P == 1) { o[0] = v[0][0]; o[1] = v[0][1 % (EPL / 4)]; o[2] = v[0][2 % (EPL / 4)]; o[3] = v[0][3 % (EPL / 4)]; }
-      else if (P == 2) {
-        o[0] = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x05010400u); o[1] = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x07030602u);
-        o[2] = __builtin_amdgcn_perm(v[1 % P][1 % (EPL / 4)], v[0][1 % (EPL / 4)], 0x05010400u);
-        o[3] = __builtin_amdgcn_perm(v[1 % P][1 % (EPL / 4)], v[0][1 % (EPL / 4)], 0x07030602u);
-        if (g.rot) for (int k = 0; k < 4; k++) o[k] = zn_rot_inv16(o[k]);
-      } else {
-        const uint32_t ab_lo = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x05010400u), ab_hi = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x07030602u);
-        const uint32_t cd_lo = __builtin_amdgcn_perm(v[3 % P][0], v[2 % P][0], 0x05010400u), cd_hi = __builtin_amdgcn_perm(v[3 % P][0], v[2 % P][0], 0x07030602u);
-        o[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); o[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
-        o[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); o[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-        if (g.rot) for (int k = 0; k < 4; k++) o[k] = zn_rot_inv32(o[k]);
+  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D
+  // (the stream's top dword may straddle the end of the buffer: that one dword is assembled from bytes)
+  uint32_t nx[ZN_F_DMAX + 1];
+  const int32_t top_dw = hi_dw - 1;
+  const bool top_guard = h >= 0 && ((const uint8_t*)(gdw + hi_dw) > body_end);
+  auto fetch_tile = [&](int32_t lo_dw_, int32_t hi_dw_) {
+    for (int i = 0; i <= ZN_F_DMAX; i++) {
+      const int32_t li = (int32_t)lane + 64 * i, gi = lo_dw_ - 1 + li;
+      uint32_t x = 0;
+      if (li <= 64 * Di && gi >= -1 && gi < hi_dw_) {
+        if (top_guard && gi == top_dw) { const uint8_t* pa = (const uint8_t*)(gdw + gi); for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b); }
+        else x = gdw[gi];
       }
-      *(uint4*)(outq + (uint64_t)JF * P + 16u * lane) = make_uint4(o[0], o[1], o[2], o[3]);
-      JF += UNIT;
+      nx[i] = x;
     }
-    if (h < 0 || !ok || 32 * hi_dw <= b0) break;
+  };
+  if (h >= 0 && ok) fetch_tile(hi_dw - 64 * Di, hi_dw);
 
-    // ---- next tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
+  // raw-plane prefetch registers for up to RB rows
+  uint32_t pre[RB][P][EW];
+  auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
+    for (int r = 0; r < RB; r++) if (r < nrows)
+      for (int p = 0; p < P; p++) if (p != h && pl[p].kind == ZN_KIND_RAW) {
+        const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+        for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
+      }
+  };
+  // interleave one row (ring bytes for the Huffman plane, prefetched bytes for raw planes) and store it
+  auto emit_rows = [&](uint32_t first_row_sym, int nrows) {
+    for (int r = 0; r < RB; r++) if (r < nrows) {
+      const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+      uint32_t v[P][EW];
+      for (int p = 0; p < P; p++) {
+        if (p == h) { const uint32_t i = (si >> 2) % ZN_F_RING_DW; for (int k = 0; k < EW; k++) { v[p][k] = ring[i + k]; ring[i + k] = 0; } }
+        else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) v[p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
+        else { for (int k = 0; k < EW; k++) v[p][k] = pre[r][p][k]; }
+      }
+      uint8_t* o = outq + (uint64_t)si * P;
+      if (P == 1) {
+        *(uint4*)o = make_uint4(v[0][0], v[0][1 % EW], v[0][2 % EW], v[0][3 % EW]);
+      } else if (P == 2) {
+        uint32_t x[4];
+        x[0] = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x07030602u);
+        x[2] = __builtin_amdgcn_perm(v[1 % P][1 % EW], v[0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(v[1 % P][1 % EW], v[0][1 % EW], 0x07030602u);
+        if (g.rot) for (int k = 0; k < 4; k++) x[k] = zn_rot_inv16(x[k]);
+        *(uint4*)o = make_uint4(x[0], x[1], x[2], x[3]);
+      } else {
+        for (int half = 0; half < 2; half++) {
+          const int k = half % EW;
+          const uint32_t ab_lo = __builtin_amdgcn_perm(v[1 % P][k], v[0][k], 0x05010400u), ab_hi = __builtin_amdgcn_perm(v[1 % P][k], v[0][k], 0x07030602u);
+          const uint32_t cd_lo = __builtin_amdgcn_perm(v[3 % P][k], v[2 % P][k], 0x05010400u), cd_hi = __builtin_amdgcn_perm(v[3 % P][k], v[2 % P][k], 0x07030602u);
+          uint32_t x[4];
+          x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+          x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+          if (g.rot) for (int q = 0; q < 4; q++) x[q] = zn_rot_inv32(x[q]);
+          *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+      }
+    }
+  };
+
+  if (h < 0) {
+    // no Huffman plane: the chunk is a pure P-way interleave of raw / RLE planes
+    while (JF < seg) {
+      const uint32_t left = (seg - JF) / UNIT; const int nr = left < (uint32_t)RB ? (int)left : RB;
+      fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT;
+    }
+    ZN_PT(3);
+  }
+
+  while (h >= 0 && ok && 32 * hi_dw > b0) {
+    // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - 64 * Di;
     __builtin_amdgcn_wave_barrier();
-    for (int32_t i = (int32_t)lane; i <= 64 * Di; i += 64) {
-      const int32_t gi = lo_dw - 1 + i;
-      uint32_t x = 0;
-      if (gi >= -1 && gi < hi_dw) {
-        const uint8_t* pa = (const uint8_t*)(gdw + gi);
-        if (pa + 4 <= body_end) x = gdw[gi];
-        else for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b);
-      }
-      in[i] = x;
-    }
+    for (int i = 0; i <= ZN_F_DMAX; i++) { const int32_t li = (int32_t)lane + 64 * i; if (li <= 64 * Di) in[li] = nx[i]; }
     __builtin_amdgcn_wave_barrier();
+    if (32 * lo_dw > b0) fetch_tile(lo_dw - 64 * Di, lo_dw);      // prefetch the next tile while this one is decoded
+    ZN_PT(4);   // stage tile
     const int32_t base_bit = 32 * (lo_dw - 1);
     const int32_t hi_k = 32 * (hi_dw - (int32_t)lane * Di), lo_k = hi_k - 32 * Di;
     const int32_t lo_eff = lo_k > b0 ? lo_k : b0;
@@ -278,6 +323,7 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
     // sync: lanes > 0 guess a start `delta` bits above their sub-block and run into it
     int32_t s = carry;
     if (lane > 0 && active) s = zn_fused_run<0>(L.lut, in, base_bit, TL, hi_k + delta, hi_k, nullptr, nullptr, 0);
+    ZN_PT(5);   // sync run-in
 
     // count, and verify that the lanes form one consistent chain below the true start of lane 0
     uint32_t n = 0; int32_t e = s; bool need = active, chained = false;
@@ -285,9 +331,14 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
       if (need) e = zn_fused_run<1>(L.lut, in, base_bit, TL, s, lo_eff, &n, nullptr, 0);
       const int32_t e_prev = __shfl_up(e, 1u);
       const bool mism = active && lane > 0 && e_prev != s;
+      if (it == 0) ZN_PT(6); else ZN_PT(7);   // first count pass / fix-up passes
       if (!__any(mism)) { chained = true; break; }
+      ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
+      ZN_PT_COUNT(17, __popcll(__ballot(mism)));
+      if (it == 0) { delta *= 2; if (delta > 32 * Di) delta = 32 * Di; }
       need = mism; if (mism) s = e_prev;
     }
+    ZN_PT_COUNT(18, 1);                      // tiles
     if (!active) n = 0;
     uint32_t N = 0;
     const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
@@ -295,15 +346,36 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
     const int32_t e_last = __shfl(e, (int)(nact ? nact - 1u : 0u));
     if (!chained || J + N > seg || J + N - JF > ZN_F_RING_BYTES) { ok = false; break; }
 
+    // rows that will be complete after this tile: request their raw bytes now, use them after the write pass
+    int rows = (int)((J + N - JF) / UNIT);
+    const int first = rows < RB ? rows : RB;
+    fetch_rows(JF, first);
+    ZN_PT(8);   // scans / shuffles / issue loads
+
     // write: second decode of the same sub-block, symbols OR-ed into the ring at their final index
     if (active) zn_fused_run<2>(L.lut, in, base_bit, TL, s, lo_eff, nullptr, ring, J + o_k);
     __builtin_amdgcn_wave_barrier();
+    ZN_PT(9);   // write pass
     J += N; carry = e_last; hi_dw = lo_dw;
+
+    emit_rows(JF, first); JF += (uint32_t)first * UNIT; rows -= first;
+    while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT; rows -= nr; }
+    ZN_PT(3);   // flush rows
   }
 
   if (h >= 0 && (!ok || carry != b0 || J != seg || JF != seg)) atomicOr(status, ZN_DEV_CORRUPT);
   if (tid == 0) done[c] = 1;
+  ZN_PT_COUNT(19, 1);                        // chunks
 }
+
+#ifdef ZN_PHASE_TIMERS
+extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zn_phase_acc), sizeof(unsigned long long) * 64) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(zn_phase_acc), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
 
 void zn_launch_decode_fused(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_dst, uint8_t* d_done,
                             uint32_t* d_status, hipStream_t stream) {

@@ -16,7 +16,7 @@
 // This is the correctness-first path; the bandwidth path for full chunks with one
 // Huffman-coded plane is zn_decode_fused.hip.
 #include "zn_internal.hpp"
-#include "zn_huf_tables.hpp"
+#include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
 
 // ---------------------------------------------------------------------------
@@ -61,11 +61,9 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const ui
                                                               uint8_t* __restrict__ scratch, uint64_t slot,
                                                               ZnPlaneDesc* __restrict__ descs, uint32_t* __restrict__ status,
                                                               const uint8_t* __restrict__ done) {
-  __shared__ ZnTabScratch S;
   __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
-  __shared__ uint8_t sh_symlist[256];
+  __shared__ uint8_t sh_w[256], sh_symlist[256], sh_cell[64];
   __shared__ uint32_t sh_rank_start[14], sh_sym_start[14];
-  __shared__ int sh_hs; __shared__ uint32_t sh_nsym, sh_tl;
 
   const uint32_t lane = threadIdx.x;
   const uint64_t pc = blockIdx.x;
@@ -89,24 +87,13 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const ui
 
   if (!bad && d.kind == ZN_KIND_HUF) {
     const uint8_t* src = body + m.off;
-    // stage the tree description (≤ 129 bytes) and parse it on lane 0
-    for (uint32_t i = lane; i < 160u; i += ZN_WAVE) S.hdr[i] = (i < m.csize) ? src[i] : 0;
-    __syncthreads();
-    if (lane == 0) {
-      uint32_t nsym = 0, tl = 0;
-      sh_hs = zn_read_stats(&S, S.hdr, m.csize < 160u ? m.csize : 160u, &nsym, &tl);
-      sh_nsym = nsym; sh_tl = tl;
-    }
-    __syncthreads();
-    const int hs = sh_hs; const uint32_t tl = sh_tl;
+    const ZnWaveStats st = zn_wave_read_stats(src, m.csize, body + body_len, lane, sh_w, sh_symlist, sh_rank_start, sh_sym_start, sh_cell);
+    const int hs = st.hs; const uint32_t tl = st.tl;
     if (hs < 0 || (uint32_t)hs >= m.csize || m.csize - (uint32_t)hs < 10u) bad = ZN_DEV_CORRUPT;
     else {
-      zn_order_symbols(S.weights, sh_nsym, tl, sh_symlist, sh_rank_start, sh_sym_start, lane);
-      __syncthreads();
-      if (sh_rank_start[13] != (1u << tl)) bad = ZN_DEV_CORRUPT;
-      else {
-        for (uint32_t u = lane; u < (1u << tl); u += ZN_WAVE)
-          lut[u] = (uint16_t)zn_lut_entry(u, tl, sh_symlist, sh_rank_start, sh_sym_start);
+      {
+        const ZnRankTab rt = zn_load_ranks(sh_rank_start, sh_sym_start);
+        for (uint32_t u = lane; u < (1u << tl); u += ZN_WAVE) lut[u] = (uint16_t)zn_lut_entry(u, tl, sh_symlist, rt, sh_rank_start, sh_sym_start);
       }
       __syncthreads();
       if (!bad) {

@@ -1,9 +1,8 @@
-// zn_huf_tables.hpp — huff0 table construction on the device (one lane, LDS scratch).
-//
-// These routines are the serial part of the codec: ≤256 symbols per plane-chunk.
-// They run on lane 0 of a workgroup while the other lanes wait at a barrier; the
-// data-parallel parts (histogram, LUT fill, bit packing, stream decode) live in the
-// kernels.  Everything follows the huff0 format of zstd 1.4.8 exactly, including
+// zn_huf_tables.hpp — huff0 ENCODER table construction on the device (one lane, LDS scratch):
+// histogram → code lengths (exact tie-breaks) → canonical codes → tree description.
+// ≤256 symbols per plane-chunk; runs on lane 0 while the other lanes wait at a barrier; the
+// data-parallel parts (histogram, bit packing) live in the kernels.  The decoder side is
+// zn_huf_wave.hpp.  Everything follows the huff0 format of zstd 1.4.8 exactly, including
 // tie-breaks, because compressed bytes must equal the CPU reference's
 // (reference call sites: csrc/zipnn_core.c:366 HUF_compress, :807 HUF_decompress).
 // Spec: SURVEY.md Appendix B.
@@ -18,7 +17,7 @@ struct ZnHNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nb; };
 
 struct ZnTabScratch {
   uint32_t count[256];       // byte histogram (encoder)
-  uint8_t  weights[256];     // huff0 weights (decoder input / encoder header)
+  uint8_t  weights[256];     // huff0 weights written into the tree description
   uint8_t  nbits[256];       // code length per symbol (encoder)
   uint16_t vals[256];        // code value per symbol (encoder)
   uint8_t  hdr[160];         // tree description bytes (≤ 1 + 128)
@@ -29,24 +28,7 @@ struct ZnTabScratch {
   int32_t  tt_fs[16];
   uint8_t  cell[64];
   uint16_t state[64];
-  uint8_t  dnb[64];
 };
-
-// ---------------------------------------------------------------------------
-// bit helpers over small byte arrays
-// ---------------------------------------------------------------------------
-// nb (≤25) bits starting at bit `bitpos`, LSB-first, zero-filled past the end
-__device__ inline uint32_t zn_bits_at(const uint8_t* p, uint32_t nbytes, uint32_t bitpos, uint32_t nb) {
-  uint32_t byte = bitpos >> 3, v = 0;
-  for (uint32_t i = 0; i < 4; i++) { uint32_t b = byte + i; v |= (b < nbytes ? (uint32_t)p[b] : 0u) << (8 * i); }
-  return (v >> (bitpos & 7)) & ((1u << nb) - 1u);
-}
-// the nb bits just below `pos` of a backward stream (MSB = bit pos-1), zero-filled below bit 0
-__device__ inline uint32_t zn_peek_back(const uint8_t* p, uint32_t nbytes, int32_t pos, uint32_t nb) {
-  if (nb == 0 || pos <= 0) return 0;
-  if ((uint32_t)pos >= nb) return zn_bits_at(p, nbytes, (uint32_t)pos - nb, nb);
-  return zn_bits_at(p, nbytes, 0, (uint32_t)pos) << (nb - (uint32_t)pos);
-}
 
 // FSE_optimalTableLog_internal: 32-bit unsigned arithmetic, wrap-around included
 __device__ inline uint32_t zn_optimal_table_log(uint32_t max_log, uint32_t src_size, uint32_t max_sv, uint32_t minus) {
@@ -59,120 +41,6 @@ __device__ inline uint32_t zn_optimal_table_log(uint32_t max_log, uint32_t src_s
   if (t < ZN_FSE_LOG_MIN) t = ZN_FSE_LOG_MIN;
   if (t > ZN_FSE_LOG_MAX) t = ZN_FSE_LOG_MAX;
   return t;
-}
-
-// ---------------------------------------------------------------------------
-// decoder side: tree description -> weights
-// ---------------------------------------------------------------------------
-// FSE-coded weights (HUF_readStats → FSE_decompress_wksp).  src: n bytes.
-// Returns number of weights written to w (≤255) or -1.
-__device__ inline int zn_fse_decode_weights(ZnTabScratch* S, uint8_t* w, const uint8_t* src, uint32_t n) {
-  uint32_t bitpos = 0, nsym = 0, tl;
-  const uint32_t nbits_total = n * 8u;
-  if (n < 1) return -1;
-  tl = zn_bits_at(src, n, 0, 4) + ZN_FSE_LOG_MIN; bitpos = 4;
-  if (tl > ZN_WEIGHT_FSE_LOG) return -1;
-  {
-    int remaining = (1 << tl) + 1, threshold = 1 << tl, nb_bits = (int)tl + 1, prev0 = 0;
-    while (remaining > 1 && nsym <= 12u) {   // weight alphabet is 0..12 (HUF_TABLELOG_MAX)
-      if (prev0) {
-        uint32_t n0 = nsym;
-        while (zn_bits_at(src, n, bitpos, 16) == 0xFFFFu) { n0 += 24; bitpos += 16; if (bitpos > nbits_total + 64u) return -1; }
-        while (zn_bits_at(src, n, bitpos, 2) == 3u) { n0 += 3; bitpos += 2; if (bitpos > nbits_total + 64u) return -1; }
-        n0 += zn_bits_at(src, n, bitpos, 2); bitpos += 2;
-        if (n0 > 12u) return -1;
-        while (nsym < n0) S->norm[nsym++] = 0;
-      }
-      {
-        const int mx = (2 * threshold - 1) - remaining; int c;
-        const int lo = (int)zn_bits_at(src, n, bitpos, (uint32_t)nb_bits - 1u);
-        if (lo < mx) { c = lo; bitpos += (uint32_t)nb_bits - 1u; }
-        else { c = (int)zn_bits_at(src, n, bitpos, (uint32_t)nb_bits); if (c >= threshold) c -= mx; bitpos += (uint32_t)nb_bits; }
-        c--;
-        remaining -= c < 0 ? -c : c;
-        S->norm[nsym++] = (int16_t)c; prev0 = !c;
-        if (remaining < 1) return -1;
-        while (remaining < threshold) { nb_bits--; threshold >>= 1; }
-      }
-    }
-    if (remaining != 1 || bitpos > nbits_total) return -1;
-  }
-  const uint32_t hdr_bytes = (bitpos + 7u) >> 3;
-  // decode table: cell -> (symbol, nbBits, base)
-  {
-    const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
-    uint32_t high = size - 1u, pos = 0;
-    for (uint32_t s = 0; s < nsym; s++) {
-      if (S->norm[s] == -1) { S->cell[high--] = (uint8_t)s; S->next[s] = 1; } else S->next[s] = (uint16_t)S->norm[s];
-    }
-    for (uint32_t s = 0; s < nsym; s++)
-      for (int i = 0; i < S->norm[s]; i++) {
-        S->cell[pos] = (uint8_t)s; pos = (pos + step) & mask;
-        while (pos > high) pos = (pos + step) & mask;
-      }
-    if (pos != 0) return -1;
-    for (uint32_t u = 0; u < size; u++) {
-      uint32_t ns = S->next[S->cell[u]]++; uint32_t nb = tl - zn_hb32(ns);
-      S->dnb[u] = (uint8_t)nb; S->state[u] = (uint16_t)((ns << nb) - size);
-    }
-  }
-  // two interleaved states over a backward bit stream
-  {
-    const uint8_t* bs = src + hdr_bytes; const uint32_t bn = n - hdr_bytes;
-    if (n <= hdr_bytes || bs[bn - 1] == 0) return -1;
-    int32_t pos = (int32_t)(bn - 1u) * 8 + (int32_t)zn_hb32(bs[bn - 1]);
-    uint32_t s1 = zn_peek_back(bs, bn, pos, tl); pos -= (int32_t)tl;
-    uint32_t s2 = zn_peek_back(bs, bn, pos, tl); pos -= (int32_t)tl;
-    if (pos < 0) return -1;
-    int o = 0;
-    for (;;) {
-      if (o >= 255) return -1;
-      w[o++] = S->cell[s1];
-      { uint32_t nb = S->dnb[s1]; uint32_t v = zn_peek_back(bs, bn, pos, nb); pos -= (int32_t)nb; s1 = S->state[s1] + v; }
-      if (pos < 0) { if (o >= 255) return -1; w[o++] = S->cell[s2]; break; }
-      if (o >= 255) return -1;
-      w[o++] = S->cell[s2];
-      { uint32_t nb = S->dnb[s2]; uint32_t v = zn_peek_back(bs, bn, pos, nb); pos -= (int32_t)nb; s2 = S->state[s2] + v; }
-      if (pos < 0) { if (o >= 255) return -1; w[o++] = S->cell[s1]; break; }
-    }
-    return o;
-  }
-}
-
-// HUF_readStats: src (csize bytes, staged in LDS/global) -> S->weights[0..nsym), tableLog.
-// Returns header size consumed, or -1 on malformed input.
-__device__ inline int zn_read_stats(ZnTabScratch* S, const uint8_t* src, uint32_t csize, uint32_t* nsym_out, uint32_t* tl_out) {
-  uint8_t* w = S->weights;
-  uint32_t isz, osz, total = 0, rank1 = 0;
-  if (csize == 0) return -1;
-  isz = src[0];
-  if (isz >= 128u) {
-    osz = isz - 127u; isz = (osz + 1u) / 2u;
-    if (isz + 1u > csize) return -1;
-    for (uint32_t n = 0; n < osz; n += 2) { w[n] = src[1 + n / 2] >> 4; w[n + 1] = src[1 + n / 2] & 15; }
-  } else {
-    if (isz + 1u > csize) return -1;
-    int r = zn_fse_decode_weights(S, w, src + 1, isz);
-    if (r < 0) return -1;
-    osz = (uint32_t)r;
-  }
-  for (uint32_t n = 0; n < osz; n++) {
-    if (w[n] >= ZN_HUF_LOG_MAX) return -1;
-    total += (1u << w[n]) >> 1; rank1 += (w[n] == 1);
-  }
-  if (total == 0) return -1;
-  {
-    const uint32_t tl = zn_hb32(total) + 1u;
-    if (tl > ZN_HUF_LOG_MAX) return -1;
-    const uint32_t rest = (1u << tl) - total;
-    if ((1u << zn_hb32(rest)) != rest) return -1;
-    const uint32_t last = zn_hb32(rest) + 1u;
-    w[osz] = (uint8_t)last; rank1 += (last == 1);
-    *tl_out = tl;
-  }
-  if (rank1 < 2 || (rank1 & 1)) return -1;
-  *nsym_out = osz + 1u;
-  return (int)(isz + 1u);
 }
 
 // ---------------------------------------------------------------------------
