@@ -228,6 +228,7 @@ static inline uint32_t zn_simt_perm(uint32_t a, uint32_t b, uint32_t sel) {
 #define __builtin_amdgcn_perm(a, b, c) zn_simt_perm((a), (b), (c))
 // v_readlane with a wave-uniform index: every lane gets lane idx's value
 #define __builtin_amdgcn_readlane(v, idx) __shfl((v), (int)(idx))
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
 // used by the kernels only on values that are already wave-uniform
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)

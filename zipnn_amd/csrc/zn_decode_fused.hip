@@ -72,53 +72,246 @@ __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane,
   return x - v;
 }
 
-// Decode the symbols whose codes start at bit positions in (stop, pos] of the staged tile.
-// MODE 0: just advance (sync run-in); 1: count symbols; 2: write symbols into the ring at symbol
-// index `wbyte`.  base_bit = absolute bit position of bit 0 of in[0].
+// One decode chain = one sub-block of the tile being walked by one lane.
+struct ZnChain {
+  int32_t pos, stop;          // next unread bit / boundary: symbols starting in (stop, pos] belong to this chain
+  uint64_t win; int32_t avail;
+  uint32_t n;                 // MODE 1: symbols counted
+  uint64_t acc; uint32_t fill, dw;   // MODE 2: bytes pending for the ring
+};
+
+__device__ __forceinline__ void zn_chain_init(ZnChain& c, int32_t pos, int32_t stop, uint32_t wbyte) {
+  c.pos = pos; c.stop = stop; c.win = 0; c.avail = 0; c.n = 0; c.acc = 0; c.fill = wbyte & 3u; c.dw = (wbyte >> 2) % ZN_F_RING_DW;
+}
+__device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, int32_t base_bit) {
+  const int32_t q = c.pos - 1 - base_bit;                 // ≥ 32 here: in[0] is one dword below the tile
+  const int32_t j = q >> 5, r = q & 31;
+  c.win = ((((uint64_t)in[j]) << 32) | in[j - 1]) << (31 - r);
+  c.avail = 33 + r;
+}
 template <int MODE>
-__device__ __forceinline__ int32_t zn_fused_run(const uint64_t* lut, const uint32_t* in, int32_t base_bit, uint32_t TL,
-                                                int32_t pos, int32_t stop, uint32_t* count, uint32_t* ring, uint32_t wbyte) {
-  uint64_t win = 0; int32_t avail = 0;
-  uint64_t acc = 0; uint32_t fill = wbyte & 3u; uint32_t dw = (wbyte >> 2) % ZN_F_RING_DW;
-  uint32_t n = 0;
-  while (pos > stop) {
-    if (avail < (int32_t)TL) {
-      const int32_t q = pos - 1 - base_bit;                 // ≥ 32 here: in[0] is one dword below the tile
-      const int32_t j = q >> 5, r = q & 31;
-      win = ((((uint64_t)in[j]) << 32) | in[j - 1]) << (31 - r);
-      avail = 33 + r;
-    }
-    const uint64_t e = lut[(uint32_t)(win >> (64u - TL))];
-    const uint32_t hi = (uint32_t)(e >> 32);
-    uint32_t nb = ZN_E_TOT(hi), cnt = ZN_E_CNT(hi), syms = (uint32_t)e;
-    const int32_t room = pos - stop;
-    if (room < (int32_t)TL) {
-      // near the boundary: keep only the symbols of this group that START above `stop`
-      const uint32_t r = (uint32_t)room;                    // 1 … TL-1; absent symbols carry start offset 15
-      const uint32_t s1 = (hi >> 8) & 15u, s2 = (hi >> 12) & 15u, s3 = (hi >> 16) & 15u;
-      const uint32_t keep = 1u + (s1 < r ? 1u : 0u) + (s2 < r ? 1u : 0u) + (s3 < r ? 1u : 0u);
-      if (keep < cnt) { nb = (hi >> (4u + 4u * keep)) & 15u; cnt = keep; syms &= (1u << (8u * keep)) - 1u; }
-    }
-    win <<= nb; avail -= (int32_t)nb; pos -= (int32_t)nb;
-    if (MODE == 1) n += cnt;
-    if (MODE == 2) {
-      acc |= (uint64_t)syms << (8u * fill); fill += cnt;
-      if (fill >= 4u) { atomicOr(&ring[dw], (uint32_t)acc); acc >>= 32; fill -= 4u; dw = (dw + 1u == ZN_F_RING_DW) ? 0u : dw + 1u; }
-    }
+__device__ __forceinline__ void zn_chain_step(ZnChain& c, uint64_t e, uint32_t TL, uint32_t* ring) {
+  const uint32_t hi = (uint32_t)(e >> 32);
+  uint32_t nb = ZN_E_TOT(hi), cnt = ZN_E_CNT(hi), syms = (uint32_t)e;
+  const int32_t room = c.pos - c.stop;
+  if (room < (int32_t)TL) {
+    // near the boundary: keep only the symbols of this group that START above `stop`
+    const uint32_t r = (uint32_t)room;                    // 1 … TL-1; absent symbols carry start offset 15
+    const uint32_t s1 = (hi >> 8) & 15u, s2 = (hi >> 12) & 15u, s3 = (hi >> 16) & 15u;
+    const uint32_t keep = 1u + (s1 < r ? 1u : 0u) + (s2 < r ? 1u : 0u) + (s3 < r ? 1u : 0u);
+    if (keep < cnt) { nb = (hi >> (4u + 4u * keep)) & 15u; cnt = keep; syms &= (1u << (8u * keep)) - 1u; }
   }
-  if (MODE == 2 && fill > 0u) atomicOr(&ring[dw], (uint32_t)acc);
-  if (MODE == 1) *count = n;
-  return pos;
+  c.win <<= nb; c.avail -= (int32_t)nb; c.pos -= (int32_t)nb;
+  if (MODE == 1) c.n += cnt;
+  if (MODE == 2) {
+    c.acc |= (uint64_t)syms << (8u * c.fill); c.fill += cnt;
+    if (c.fill >= 4u) { atomicOr(&ring[c.dw], (uint32_t)c.acc); c.acc >>= 32; c.fill -= 4u; c.dw = (c.dw + 1u == ZN_F_RING_DW) ? 0u : c.dw + 1u; }
+  }
 }
 
-template <int P>
-__global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
-                                                                  uint8_t* __restrict__ dst, uint8_t* __restrict__ done,
-                                                                  uint32_t* __restrict__ status) {
+// Walk two independent chains (the lane's two sub-blocks) in one loop, so that their dependent LUT
+// reads overlap.  MODE 0: just advance (sync run-in); 1: count symbols; 2: write symbols into the ring
+// (ds_or_b32: neighbouring chains share boundary dwords).  base_bit = absolute bit position of in[0] bit 0.
+template <int MODE>
+__device__ __forceinline__ void zn_fused_run2(const uint64_t* lut, const uint32_t* in, int32_t base_bit, uint32_t TL,
+                                              ZnChain& A, ZnChain& B, uint32_t* ring) {
+  const uint32_t sh = 64u - TL;
+  for (;;) {
+    const bool a = A.pos > A.stop, b = B.pos > B.stop;
+    if (!a && !b) break;
+    const bool ra = a && A.avail < (int32_t)TL, rb = b && B.avail < (int32_t)TL;
+    if (ra || rb) { if (ra) zn_chain_refill(A, in, base_bit); if (rb) zn_chain_refill(B, in, base_bit); }
+    const uint64_t eA = lut[(uint32_t)(A.win >> sh)], eB = lut[(uint32_t)(B.win >> sh)];   // both in flight before either is used
+    if (a) zn_chain_step<MODE>(A, eA, TL, ring);
+    if (b) zn_chain_step<MODE>(B, eB, TL, ring);
+  }
+  if (MODE == 2) {
+    if (A.fill > 0u) atomicOr(&ring[A.dw], (uint32_t)A.acc);
+    if (B.fill > 0u) atomicOr(&ring[B.dw], (uint32_t)B.acc);
+  }
+}
+
+// Everything one wave does for its quarter of the chunk, with the Huffman plane index H known at
+// compile time (H = -1: no Huffman plane) so that register arrays are statically indexed.
+template <int P, int H>
+__device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
+                                              uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
+                                              const uint64_t* lut, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
+                                              uint32_t TL, uint32_t D2u, const uint8_t* stream, uint32_t slen) {
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
-  constexpr int RB = (P == 2) ? 14 : 7;       // rows whose raw bytes are kept in flight at once
+  constexpr int RB = (P == 2) ? 14 : 7;       // rows kept in registers at once
+  ZN_PT_DECL;
+
+  // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
+  uint32_t pre[RB][P][EW];
+  auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
+    for (int r = 0; r < RB; r++) if (r < nrows)
+      for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
+        const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+        for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
+      }
+  };
+  // interleave rows (ring bytes for the Huffman plane, fetched bytes for raw planes) and store them.
+  // All loads are complete before the first store is issued, so no store latency is ever waited on.
+  auto emit_rows = [&](uint32_t first_row_sym, int nrows) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
+    for (int r = 0; r < RB; r++) if (r < nrows) {
+      const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+      for (int p = 0; p < P; p++) {
+        if (p == H) { const uint32_t i = (si >> 2) % ZN_F_RING_DW; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
+        else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) pre[r][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
+      }
+    }
+    for (int r = 0; r < RB; r++) if (r < nrows) {
+      const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+      uint8_t* o = outq + (uint64_t)si * P;
+      if (P == 1) {
+        *(uint4*)o = make_uint4(pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
+      } else if (P == 2) {
+        uint32_t x[4];
+        x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
+        x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
+        if (g.rot) for (int k = 0; k < 4; k++) x[k] = zn_rot_inv16(x[k]);
+        *(uint4*)o = make_uint4(x[0], x[1], x[2], x[3]);
+      } else {
+        for (int half = 0; half < 2; half++) {
+          const int k = half % EW;
+          const uint32_t ab_lo = __builtin_amdgcn_perm(pre[r][1 % P][k], pre[r][0][k], 0x05010400u), ab_hi = __builtin_amdgcn_perm(pre[r][1 % P][k], pre[r][0][k], 0x07030602u);
+          const uint32_t cd_lo = __builtin_amdgcn_perm(pre[r][3 % P][k], pre[r][2 % P][k], 0x05010400u), cd_hi = __builtin_amdgcn_perm(pre[r][3 % P][k], pre[r][2 % P][k], 0x07030602u);
+          uint32_t x[4];
+          x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+          x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+          if (g.rot) for (int q = 0; q < 4; q++) x[q] = zn_rot_inv32(x[q]);
+          *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);
+        }
+      }
+    }
+  };
+
+  uint32_t JF = 0;                            // symbols flushed to HBM so far
+  if (H < 0) {
+    // no Huffman plane: the chunk is a pure P-way interleave of raw / RLE planes
+    while (JF < seg) {
+      const uint32_t left = (seg - JF) / UNIT; const int nr = left < (uint32_t)RB ? (int)left : RB;
+      fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT;
+    }
+    ZN_PT(3);
+    return true;
+  }
+
+  for (uint32_t i = lane; i < ZN_F_RING_DW; i += 64u) ring[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+
+  uint32_t J = 0;                             // symbols decoded into the ring so far
+  const uint8_t last = stream[slen - 1];
+  if (last == 0) return false;
+  const uint64_t sa = (uint64_t)stream;
+  const uint32_t* gdw = (const uint32_t*)(sa & ~(uint64_t)3);
+  const int32_t b0 = (int32_t)(8u * (uint32_t)(sa & 3u));
+  int32_t carry = b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last);
+  int32_t hi_dw = (carry + 31) >> 5;
+  const int32_t D2 = (int32_t)D2u, TD = 128 * D2;          // dwords per sub-block / per tile
+  int32_t delta = (ZN_F_DELTA0 < 32 * D2) ? ZN_F_DELTA0 : 32 * D2;
+
+  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..2*D2
+  // (the stream's top dword may straddle the end of the buffer: that one dword is assembled from bytes)
+  uint32_t nx[ZN_F_DMAX + 1];
+  const int32_t top_dw = hi_dw - 1;
+  const bool top_guard = ((const uint8_t*)(gdw + hi_dw) > body_end);
+  auto fetch_tile = [&](int32_t lo_dw_, int32_t hi_dw_) {
+    for (int i = 0; i <= ZN_F_DMAX; i++) {
+      const int32_t li = (int32_t)lane + 64 * i, gi = lo_dw_ - 1 + li;
+      uint32_t x = 0;
+      if (li <= TD && gi >= -1 && gi < hi_dw_) {
+        if (top_guard && gi == top_dw) { const uint8_t* pa = (const uint8_t*)(gdw + gi); for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b); }
+        else x = gdw[gi];
+      }
+      nx[i] = x;
+    }
+  };
+  fetch_tile(hi_dw - TD, hi_dw);
+
+  bool ok = true;
+  while (32 * hi_dw > b0) {
+    // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
+    const int32_t lo_dw = hi_dw - TD;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i <= ZN_F_DMAX; i++) { const int32_t li = (int32_t)lane + 64 * i; if (li <= TD) in[li] = nx[i]; }
+    __builtin_amdgcn_wave_barrier();
+    if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
+    ZN_PT(4);   // stage tile
+    const int32_t base_bit = 32 * (lo_dw - 1);
+    // this lane's two sub-blocks: A = sub-block 2*lane (upper), B = 2*lane+1 (lower)
+    const int32_t hiA = 32 * (hi_dw - 2 * (int32_t)lane * D2), hiB = hiA - 32 * D2, loB = hiB - 32 * D2;
+    const int32_t stopA = hiB > b0 ? hiB : b0, stopB = loB > b0 ? loB : b0;
+    const bool actA = hiA > b0, actB = hiB > b0;
+
+    // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it
+    ZnChain A, B;
+    zn_chain_init(A, (lane > 0 && actA) ? hiA + delta : hiA, hiA, 0);
+    zn_chain_init(B, actB ? hiB + delta : hiB, hiB, 0);
+    zn_fused_run2<0>(lut, in, base_bit, TL, A, B, nullptr);
+    int32_t sA = (lane > 0) ? A.pos : carry, sB = B.pos;
+    ZN_PT(5);   // sync run-in
+
+    // count, and verify that the 128 sub-blocks form one consistent chain below the true start of the first
+    uint32_t nA = 0, nB = 0; int32_t eA = sA, eB = sB; bool needA = actA, needB = actB, chained = false;
+    for (int it = 0; it < 130; it++) {
+      zn_chain_init(A, needA ? sA : stopA, stopA, 0);
+      zn_chain_init(B, needB ? sB : stopB, stopB, 0);
+      zn_fused_run2<1>(lut, in, base_bit, TL, A, B, nullptr);
+      if (needA) { eA = A.pos; nA = A.n; }
+      if (needB) { eB = B.pos; nB = B.n; }
+      const int32_t eB_prev = __shfl_up(eB, 1u);
+      const bool misA = actA && lane > 0 && eB_prev != sA;
+      const bool misB = actB && eA != sB;
+      if (it == 0) ZN_PT(6); else ZN_PT(7);   // first count pass / fix-up passes
+      if (!__any(misA || misB)) { chained = true; break; }
+      ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
+      ZN_PT_COUNT(17, __popcll(__ballot(misA)) + __popcll(__ballot(misB)));
+      if (it == 0) { delta *= 2; if (delta > 32 * D2) delta = 32 * D2; }
+      needA = misA; needB = misB;
+      if (misA) sA = eB_prev;
+      if (misB) sB = eA;
+    }
+    ZN_PT_COUNT(18, 1);                      // tiles
+    if (!actA) nA = 0;
+    if (!actB) nB = 0;
+    uint32_t N = 0;
+    const uint32_t o_k = zn_wave_excl_scan(nA + nB, lane, &N);
+    const uint32_t nact = (uint32_t)__popcll(__ballot(actA));
+    const int32_t e_last = __shfl(actB ? eB : eA, (int)(nact ? nact - 1u : 0u));
+    if (!chained || J + N > seg || J + N - JF > ZN_F_RING_BYTES) { ok = false; break; }
+
+    // rows that will be complete after this tile: request their raw bytes now, use them after the write pass
+    int rows = (int)((J + N - JF) / UNIT);
+    const int first = rows < RB ? rows : RB;
+    fetch_rows(JF, first);
+    ZN_PT(8);   // scans / shuffles / issue loads
+
+    // write: second decode of the same sub-blocks, symbols OR-ed into the ring at their final index
+    zn_chain_init(A, actA ? sA : stopA, stopA, J + o_k);
+    zn_chain_init(B, actB ? sB : stopB, stopB, J + o_k + nA);
+    zn_fused_run2<2>(lut, in, base_bit, TL, A, B, ring);
+    __builtin_amdgcn_wave_barrier();
+    ZN_PT(9);   // write pass
+    J += N; carry = e_last; hi_dw = lo_dw;
+
+    emit_rows(JF, first); JF += (uint32_t)first * UNIT; rows -= first;
+    while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT; rows -= nr; }
+    ZN_PT(3);   // flush rows
+  }
+  return ok && carry == b0 && J == seg && JF == seg;
+}
+
+template <int P>
+__global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
+                                                                  uint8_t* __restrict__ dst, uint8_t* __restrict__ done,
+                                                                  uint32_t* __restrict__ status) {
+  constexpr int EPL = (P == 1) ? 16 : 8;
+  constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -143,7 +336,8 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
   __syncthreads();
   ZN_PT(0);   // metadata
 
-  int h = -1; uint32_t nhuf = 0; uint64_t h_off = 0; uint32_t h_csize = 0; bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
+  int h = -1; uint32_t nhuf = 0; uint64_t h_off = 0; uint32_t h_csize = 0;
+  bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
   ZnFusedPlane pl[P];
   for (int p = 0; p < P; p++) {
     pl[p] = L.plane[p];
@@ -153,7 +347,7 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
   if (!elig || nhuf > 1u) { if (tid == 0) done[c] = 0; return; }
 
   const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
-  uint32_t TL = 0, D = ZN_F_DMAX;
+  uint32_t TL = 0, D2 = 1;
   const uint8_t* stream = nullptr; uint32_t slen = 0;
 
   if (h >= 0) {
@@ -196,10 +390,10 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
         if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)(cnt[k] | (pos[k] << 4) | starts[k]) << 32);
       }
     }
-    // shortest code length → how many symbols a tile can hold → sub-block size D (dwords)
-    D = ((ZN_F_RING_BYTES - UNIT) * st.lmin) / 2048u;
-    if (D > ZN_F_DMAX) D = ZN_F_DMAX;
-    if (D < 1u) D = 1u;
+    // shortest code length → how many symbols a tile can hold → sub-block size (dwords; two sub-blocks per lane)
+    D2 = (((ZN_F_RING_BYTES - UNIT) * st.lmin) / 2048u) / 2u;
+    if (D2 > ZN_F_DMAX / 2) D2 = ZN_F_DMAX / 2;
+    if (D2 < 1u) D2 = 1u;
     // jump table → this wave's stream
     const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
     const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
@@ -212,158 +406,20 @@ __global__ __launch_bounds__(ZN_F_THREADS) void zn_k_decode_fused(ZnGeom g, cons
     ZN_PT(2);   // LUT fill
   }
 
-  // ---- per-wave: zero the ring, decode the stream tile by tile, flush rows ----
-  uint32_t* ring = L.ring[wave];
-  uint32_t* in = L.in[wave];
-  for (uint32_t i = lane; i < ZN_F_RING_DW; i += 64u) ring[i] = 0;
-  __builtin_amdgcn_wave_barrier();
-
+  // ---- per-wave: decode the stream tile by tile, flush rows ----
   const uint8_t* rawq[P];
   for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
   uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
-
-  uint32_t J = (h >= 0) ? 0u : seg;           // symbols decoded into the ring so far
-  uint32_t JF = 0;                            // symbols flushed to HBM so far
-  bool ok = true;
-  int32_t b0 = 0, carry = 0, hi_dw = 0; const uint32_t* gdw = nullptr;
-  if (h >= 0) {
-    const uint8_t last = stream[slen - 1];
-    if (last == 0) ok = false;
-    const uint64_t a = (uint64_t)stream;
-    gdw = (const uint32_t*)(a & ~(uint64_t)3); b0 = (int32_t)(8u * (uint32_t)(a & 3u));
-    carry = b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last ? last : 1u);
-    hi_dw = (carry + 31) >> 5;
-  }
-  const int32_t Di = (int32_t)D;
-  int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
-
-  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D
-  // (the stream's top dword may straddle the end of the buffer: that one dword is assembled from bytes)
-  uint32_t nx[ZN_F_DMAX + 1];
-  const int32_t top_dw = hi_dw - 1;
-  const bool top_guard = h >= 0 && ((const uint8_t*)(gdw + hi_dw) > body_end);
-  auto fetch_tile = [&](int32_t lo_dw_, int32_t hi_dw_) {
-    for (int i = 0; i <= ZN_F_DMAX; i++) {
-      const int32_t li = (int32_t)lane + 64 * i, gi = lo_dw_ - 1 + li;
-      uint32_t x = 0;
-      if (li <= 64 * Di && gi >= -1 && gi < hi_dw_) {
-        if (top_guard && gi == top_dw) { const uint8_t* pa = (const uint8_t*)(gdw + gi); for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b); }
-        else x = gdw[gi];
-      }
-      nx[i] = x;
-    }
-  };
-  if (h >= 0 && ok) fetch_tile(hi_dw - 64 * Di, hi_dw);
-
-  // raw-plane prefetch registers for up to RB rows
-  uint32_t pre[RB][P][EW];
-  auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
-    for (int r = 0; r < RB; r++) if (r < nrows)
-      for (int p = 0; p < P; p++) if (p != h && pl[p].kind == ZN_KIND_RAW) {
-        const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
-        for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
-      }
-  };
-  // interleave one row (ring bytes for the Huffman plane, prefetched bytes for raw planes) and store it
-  auto emit_rows = [&](uint32_t first_row_sym, int nrows) {
-    for (int r = 0; r < RB; r++) if (r < nrows) {
-      const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
-      uint32_t v[P][EW];
-      for (int p = 0; p < P; p++) {
-        if (p == h) { const uint32_t i = (si >> 2) % ZN_F_RING_DW; for (int k = 0; k < EW; k++) { v[p][k] = ring[i + k]; ring[i + k] = 0; } }
-        else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) v[p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
-        else { for (int k = 0; k < EW; k++) v[p][k] = pre[r][p][k]; }
-      }
-      uint8_t* o = outq + (uint64_t)si * P;
-      if (P == 1) {
-        *(uint4*)o = make_uint4(v[0][0], v[0][1 % EW], v[0][2 % EW], v[0][3 % EW]);
-      } else if (P == 2) {
-        uint32_t x[4];
-        x[0] = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(v[1 % P][0], v[0][0], 0x07030602u);
-        x[2] = __builtin_amdgcn_perm(v[1 % P][1 % EW], v[0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(v[1 % P][1 % EW], v[0][1 % EW], 0x07030602u);
-        if (g.rot) for (int k = 0; k < 4; k++) x[k] = zn_rot_inv16(x[k]);
-        *(uint4*)o = make_uint4(x[0], x[1], x[2], x[3]);
-      } else {
-        for (int half = 0; half < 2; half++) {
-          const int k = half % EW;
-          const uint32_t ab_lo = __builtin_amdgcn_perm(v[1 % P][k], v[0][k], 0x05010400u), ab_hi = __builtin_amdgcn_perm(v[1 % P][k], v[0][k], 0x07030602u);
-          const uint32_t cd_lo = __builtin_amdgcn_perm(v[3 % P][k], v[2 % P][k], 0x05010400u), cd_hi = __builtin_amdgcn_perm(v[3 % P][k], v[2 % P][k], 0x07030602u);
-          uint32_t x[4];
-          x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
-          x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-          if (g.rot) for (int q = 0; q < 4; q++) x[q] = zn_rot_inv32(x[q]);
-          *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);
-        }
-      }
-    }
-  };
-
-  if (h < 0) {
-    // no Huffman plane: the chunk is a pure P-way interleave of raw / RLE planes
-    while (JF < seg) {
-      const uint32_t left = (seg - JF) / UNIT; const int nr = left < (uint32_t)RB ? (int)left : RB;
-      fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT;
-    }
-    ZN_PT(3);
-  }
-
-  while (h >= 0 && ok && 32 * hi_dw > b0) {
-    // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
-    const int32_t lo_dw = hi_dw - 64 * Di;
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i <= ZN_F_DMAX; i++) { const int32_t li = (int32_t)lane + 64 * i; if (li <= 64 * Di) in[li] = nx[i]; }
-    __builtin_amdgcn_wave_barrier();
-    if (32 * lo_dw > b0) fetch_tile(lo_dw - 64 * Di, lo_dw);      // prefetch the next tile while this one is decoded
-    ZN_PT(4);   // stage tile
-    const int32_t base_bit = 32 * (lo_dw - 1);
-    const int32_t hi_k = 32 * (hi_dw - (int32_t)lane * Di), lo_k = hi_k - 32 * Di;
-    const int32_t lo_eff = lo_k > b0 ? lo_k : b0;
-    const bool active = hi_k > b0;
-
-    // sync: lanes > 0 guess a start `delta` bits above their sub-block and run into it
-    int32_t s = carry;
-    if (lane > 0 && active) s = zn_fused_run<0>(L.lut, in, base_bit, TL, hi_k + delta, hi_k, nullptr, nullptr, 0);
-    ZN_PT(5);   // sync run-in
-
-    // count, and verify that the lanes form one consistent chain below the true start of lane 0
-    uint32_t n = 0; int32_t e = s; bool need = active, chained = false;
-    for (int it = 0; it < 66; it++) {
-      if (need) e = zn_fused_run<1>(L.lut, in, base_bit, TL, s, lo_eff, &n, nullptr, 0);
-      const int32_t e_prev = __shfl_up(e, 1u);
-      const bool mism = active && lane > 0 && e_prev != s;
-      if (it == 0) ZN_PT(6); else ZN_PT(7);   // first count pass / fix-up passes
-      if (!__any(mism)) { chained = true; break; }
-      ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
-      ZN_PT_COUNT(17, __popcll(__ballot(mism)));
-      if (it == 0) { delta *= 2; if (delta > 32 * Di) delta = 32 * Di; }
-      need = mism; if (mism) s = e_prev;
-    }
-    ZN_PT_COUNT(18, 1);                      // tiles
-    if (!active) n = 0;
-    uint32_t N = 0;
-    const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
-    const uint32_t nact = (uint32_t)__popcll(__ballot(active));
-    const int32_t e_last = __shfl(e, (int)(nact ? nact - 1u : 0u));
-    if (!chained || J + N > seg || J + N - JF > ZN_F_RING_BYTES) { ok = false; break; }
-
-    // rows that will be complete after this tile: request their raw bytes now, use them after the write pass
-    int rows = (int)((J + N - JF) / UNIT);
-    const int first = rows < RB ? rows : RB;
-    fetch_rows(JF, first);
-    ZN_PT(8);   // scans / shuffles / issue loads
-
-    // write: second decode of the same sub-block, symbols OR-ed into the ring at their final index
-    if (active) zn_fused_run<2>(L.lut, in, base_bit, TL, s, lo_eff, nullptr, ring, J + o_k);
-    __builtin_amdgcn_wave_barrier();
-    ZN_PT(9);   // write pass
-    J += N; carry = e_last; hi_dw = lo_dw;
-
-    emit_rows(JF, first); JF += (uint32_t)first * UNIT; rows -= first;
-    while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT; rows -= nr; }
-    ZN_PT(3);   // flush rows
-  }
-
-  if (h >= 0 && (!ok || carry != b0 || J != seg || JF != seg)) atomicOr(status, ZN_DEV_CORRUPT);
+  uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
+  bool ok;
+#define ZN_WAVE_CASE(H_) ok = zn_fused_wave<P, H_>(g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, D2, stream, slen)
+  if (h < 0) ZN_WAVE_CASE(-1);
+  else if (h == 0) ZN_WAVE_CASE(0);
+  else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
+  else if (P >= 4 && h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
+  else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
+#undef ZN_WAVE_CASE
+  if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
   if (tid == 0) done[c] = 1;
   ZN_PT_COUNT(19, 1);                        // chunks
 }

@@ -98,28 +98,52 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
     entry = (cs & 0xFFu) | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16);
   }
 
-  // ---- two interleaved states over the backward stream, all on wave-uniform values ----
+  // ---- two interleaved states over the backward stream, all on wave-uniform (scalar) values ----
+  // `win` holds the next unread bits top-aligned (MSB = bit pos-1 of the stream), zero below bit 0;
+  // decoded weights are dropped into lanes of four VGPRs (compare + select) and stored once at the end.
   const uint32_t bn = (FEND - B0) >> 3;
   const uint32_t lastb = zn_wbits(H, FEND - 8u, 8, FEND);
   if (lastb == 0) return -1;
   int32_t pos = (int32_t)(8u * (bn - 1u)) + (int32_t)zn_hb32(lastb);
-#define ZN_WPEEK(nb_) (((nb_) == 0u || pos <= 0) ? 0u : ((uint32_t)pos >= (nb_)) ? zn_wbits(H, B0 + (uint32_t)pos - (nb_), (nb_), FEND) \
-                       : (zn_wbits(H, B0, (uint32_t)pos, FEND) << ((nb_) - (uint32_t)pos)))
-  uint32_t s1 = ZN_WPEEK(tl); pos -= (int32_t)tl;
-  uint32_t s2 = ZN_WPEEK(tl); pos -= (int32_t)tl;
+  uint64_t win = 0; int32_t avail = 0;
+  uint32_t wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
+#define ZN_WREFILL() do { \
+    const uint32_t abs_ = B0 + (uint32_t)pos - 1u; const uint32_t k_ = abs_ >> 5, r_ = abs_ & 31u; \
+    const uint64_t hi_ = ((uint64_t)zn_rl(H.v, k_ & 63u) << 32) | (k_ >= 1u ? zn_rl(H.v, (k_ - 1u) & 63u) : 0u); \
+    const uint64_t lo_ = (k_ >= 2u) ? zn_rl(H.v, (k_ - 2u) & 63u) : 0u; \
+    win = (hi_ << (31u - r_)) | (lo_ >> (r_ + 1u)); \
+    avail = pos < 64 ? pos : 64; \
+    if (pos < 64) win &= ~0ull << (64 - pos); } while (0)
+#define ZN_WTAKE(nb_, out_) do { const uint32_t n_ = (nb_); \
+    if (avail < (int32_t)n_ && pos > avail) ZN_WREFILL(); \
+    out_ = n_ ? (uint32_t)(win >> (64u - n_)) : 0u; win = n_ ? (win << n_) : win; avail -= (int32_t)n_; pos -= (int32_t)n_; } while (0)
+#define ZN_WPUT(sym_) do { const uint32_t y_ = (sym_) & 0xFFu; const uint32_t l_ = (uint32_t)o & 63u; \
+    if (o < 64) wv0 = (lane == l_) ? y_ : wv0; \
+    else if (o < 128) wv1 = (lane == l_) ? y_ : wv1; \
+    else if (o < 192) wv2 = (lane == l_) ? y_ : wv2; \
+    else wv3 = (lane == l_) ? y_ : wv3; \
+    o++; } while (0)
+  if (pos > 0) ZN_WREFILL();
+  uint32_t s1, s2;
+  ZN_WTAKE(tl, s1);
+  ZN_WTAKE(tl, s2);
   if (pos < 0) return -1;
   int o = 0;
   for (;;) {
     if (o >= 254) return -1;
-    { const uint32_t e = zn_rl(entry, s1 & 63u); if (lane == 0) sh_w[o] = (uint8_t)e; o++;
-      const uint32_t nb = (e >> 8) & 0xFFu; const uint32_t v = ZN_WPEEK(nb); pos -= (int32_t)nb; s1 = (e >> 16) + v; }
-    if (pos < 0) { const uint32_t e = zn_rl(entry, s2 & 63u); if (lane == 0) sh_w[o] = (uint8_t)e; o++; break; }
+    { const uint32_t e = zn_rl(entry, s1 & 63u); ZN_WPUT(e); uint32_t v; ZN_WTAKE((e >> 8) & 0xFFu, v); s1 = (e >> 16) + v; }
+    if (pos < 0) { const uint32_t e = zn_rl(entry, s2 & 63u); ZN_WPUT(e); break; }
     if (o >= 254) return -1;
-    { const uint32_t e = zn_rl(entry, s2 & 63u); if (lane == 0) sh_w[o] = (uint8_t)e; o++;
-      const uint32_t nb = (e >> 8) & 0xFFu; const uint32_t v = ZN_WPEEK(nb); pos -= (int32_t)nb; s2 = (e >> 16) + v; }
-    if (pos < 0) { const uint32_t e = zn_rl(entry, s1 & 63u); if (lane == 0) sh_w[o] = (uint8_t)e; o++; break; }
+    { const uint32_t e = zn_rl(entry, s2 & 63u); ZN_WPUT(e); uint32_t v; ZN_WTAKE((e >> 8) & 0xFFu, v); s2 = (e >> 16) + v; }
+    if (pos < 0) { const uint32_t e = zn_rl(entry, s1 & 63u); ZN_WPUT(e); break; }
   }
-#undef ZN_WPEEK
+#undef ZN_WREFILL
+#undef ZN_WTAKE
+#undef ZN_WPUT
+  if ((int)lane < o) sh_w[lane] = (uint8_t)wv0;
+  if ((int)lane + 64 < o) sh_w[lane + 64u] = (uint8_t)wv1;
+  if ((int)lane + 128 < o) sh_w[lane + 128u] = (uint8_t)wv2;
+  if ((int)lane + 192 < o) sh_w[lane + 192u] = (uint8_t)wv3;
   return o;
 }
 
