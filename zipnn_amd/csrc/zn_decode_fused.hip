@@ -59,10 +59,9 @@ struct ZnFusedLds {
   ZnWaveStats st;
 };
 
-// multi-symbol LUT entry: low dword = up to 4 symbols (unused bytes 0); high dword =
-//   cnt (bits 0-2) | total length (4-7) | start offset of symbol 1/2/3 (8-11/12-15/16-19; 15 = absent)
-#define ZN_E_CNT(hi) ((hi) & 7u)
-#define ZN_E_TOT(hi) (((hi) >> 4) & 15u)
+// multi-symbol LUT entry: low dword = up to 4 symbols (unused bytes 0); high dword ("meta") =
+//   total length (bits 0-3) | start offset of symbol 1/2/3 (8-11 / 12-15 / 16-19; 15 = absent) | count (29-31)
+#define ZN_E_META(cnt, total, starts) ((total) | (starts) | ((cnt) << 29))
 
 // wave-wide exclusive prefix sum (all 64 lanes participate)
 __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
@@ -72,62 +71,66 @@ __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane,
   return x - v;
 }
 
-// One decode chain = one sub-block of the tile being walked by one lane.
+// One decode chain = one sub-block of the tile being walked by one lane.  All 32-bit arithmetic:
+// the unread bits sit MSB-aligned in (whi:wlo) and are consumed with v_alignbit_b32.
 struct ZnChain {
   int32_t pos, stop;          // next unread bit / boundary: symbols starting in (stop, pos] belong to this chain
-  uint64_t win; int32_t avail;
+  int32_t lim;                // refill when pos < lim (fewer than TL valid bits left in the window)
+  int32_t tail;               // stop + TL: below this, a lookup group may reach past the boundary
+  uint32_t whi, wlo;
   uint32_t n;                 // MODE 1: symbols counted
-  uint64_t acc; uint32_t fill, dw;   // MODE 2: bytes pending for the ring
+  uint32_t wpos;              // MODE 2: byte offset in the staging buffer of the next symbol
 };
 
-__device__ __forceinline__ void zn_chain_init(ZnChain& c, int32_t pos, int32_t stop, uint32_t wbyte) {
-  c.pos = pos; c.stop = stop; c.win = 0; c.avail = 0; c.n = 0; c.acc = 0; c.fill = wbyte & 3u; c.dw = (wbyte >> 2) % ZN_F_RING_DW;
+__device__ __forceinline__ void zn_chain_init(ZnChain& c, int32_t pos, int32_t stop, uint32_t TL, uint32_t wpos) {
+  c.pos = pos; c.stop = stop; c.lim = 0x7FFFFFFF; c.tail = stop + (int32_t)TL; c.whi = 0; c.wlo = 0; c.n = 0; c.wpos = wpos;
 }
-__device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, int32_t base_bit) {
+__device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, int32_t base_bit, uint32_t TL) {
   const int32_t q = c.pos - 1 - base_bit;                 // ≥ 32 here: in[0] is one dword below the tile
   const int32_t j = q >> 5, r = q & 31;
-  c.win = ((((uint64_t)in[j]) << 32) | in[j - 1]) << (31 - r);
-  c.avail = 33 + r;
+  const uint64_t w = ((((uint64_t)in[j]) << 32) | in[j - 1]) << (31 - r);
+  c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w;
+  c.lim = c.pos - (33 + r) + (int32_t)TL;                 // 33 + r valid bits from here
 }
 template <int MODE>
-__device__ __forceinline__ void zn_chain_step(ZnChain& c, uint64_t e, uint32_t TL, uint32_t* ring) {
-  const uint32_t hi = (uint32_t)(e >> 32);
-  uint32_t nb = ZN_E_TOT(hi), cnt = ZN_E_CNT(hi), syms = (uint32_t)e;
-  const int32_t room = c.pos - c.stop;
-  if (room < (int32_t)TL) {
+__device__ __forceinline__ void zn_chain_step(ZnChain& c, uint32_t meta, uint32_t syms, uint32_t* stage) {
+  uint32_t nb = meta & 15u, cnt = meta >> 29;
+  if (c.pos < c.tail) {
     // near the boundary: keep only the symbols of this group that START above `stop`
-    const uint32_t r = (uint32_t)room;                    // 1 … TL-1; absent symbols carry start offset 15
-    const uint32_t s1 = (hi >> 8) & 15u, s2 = (hi >> 12) & 15u, s3 = (hi >> 16) & 15u;
+    const uint32_t r = (uint32_t)(c.pos - c.stop);        // 1 … TL-1; absent symbols carry start offset 15
+    const uint32_t s1 = (meta >> 8) & 15u, s2 = (meta >> 12) & 15u, s3 = (meta >> 16) & 15u;
     const uint32_t keep = 1u + (s1 < r ? 1u : 0u) + (s2 < r ? 1u : 0u) + (s3 < r ? 1u : 0u);
-    if (keep < cnt) { nb = (hi >> (4u + 4u * keep)) & 15u; cnt = keep; syms &= (1u << (8u * keep)) - 1u; }
+    if (keep < cnt) { nb = (meta >> (4u + 4u * keep)) & 15u; cnt = keep; syms &= (1u << (8u * keep)) - 1u; }
   }
-  c.win <<= nb; c.avail -= (int32_t)nb; c.pos -= (int32_t)nb;
+  c.whi = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb); c.wlo <<= nb; c.pos -= (int32_t)nb;   // nb ≥ 1
   if (MODE == 1) c.n += cnt;
   if (MODE == 2) {
-    c.acc |= (uint64_t)syms << (8u * c.fill); c.fill += cnt;
-    if (c.fill >= 4u) { atomicOr(&ring[c.dw], (uint32_t)c.acc); c.acc >>= 32; c.fill -= 4u; c.dw = (c.dw + 1u == ZN_F_RING_DW) ? 0u : c.dw + 1u; }
+    const uint32_t fill = c.wpos & 3u, sh8 = fill << 3, dw = c.wpos >> 2;
+    atomicOr(&stage[dw], syms << sh8);
+    if (fill + cnt > 4u) atomicOr(&stage[dw + 1u], syms >> (32u - sh8));     // fill ≥ 1 here
+    c.wpos += cnt;
   }
 }
 
 // Walk two independent chains (the lane's two sub-blocks) in one loop, so that their dependent LUT
-// reads overlap.  MODE 0: just advance (sync run-in); 1: count symbols; 2: write symbols into the ring
-// (ds_or_b32: neighbouring chains share boundary dwords).  base_bit = absolute bit position of in[0] bit 0.
+// reads overlap.  MODE 0: just advance (sync run-in); 1: count symbols; 2: OR the symbols into the
+// staging buffer (ds_or_b32: neighbouring chains share boundary dwords).
+// base_bit = absolute bit position of bit 0 of in[0].
 template <int MODE>
-__device__ __forceinline__ void zn_fused_run2(const uint64_t* lut, const uint32_t* in, int32_t base_bit, uint32_t TL,
-                                              ZnChain& A, ZnChain& B, uint32_t* ring) {
-  const uint32_t sh = 64u - TL;
+__device__ __forceinline__ void zn_fused_run2(const uint32_t* lut32, const uint32_t* in, int32_t base_bit, uint32_t TL,
+                                              ZnChain& A, ZnChain& B, uint32_t* stage) {
+  const uint32_t sh = 32u - TL;
   for (;;) {
     const bool a = A.pos > A.stop, b = B.pos > B.stop;
     if (!a && !b) break;
-    const bool ra = a && A.avail < (int32_t)TL, rb = b && B.avail < (int32_t)TL;
-    if (ra || rb) { if (ra) zn_chain_refill(A, in, base_bit); if (rb) zn_chain_refill(B, in, base_bit); }
-    const uint64_t eA = lut[(uint32_t)(A.win >> sh)], eB = lut[(uint32_t)(B.win >> sh)];   // both in flight before either is used
-    if (a) zn_chain_step<MODE>(A, eA, TL, ring);
-    if (b) zn_chain_step<MODE>(B, eB, TL, ring);
-  }
-  if (MODE == 2) {
-    if (A.fill > 0u) atomicOr(&ring[A.dw], (uint32_t)A.acc);
-    if (B.fill > 0u) atomicOr(&ring[B.dw], (uint32_t)B.acc);
+    const bool ra = a && A.pos < A.lim, rb = b && B.pos < B.lim;
+    if (ra || rb) { if (ra) zn_chain_refill(A, in, base_bit, TL); if (rb) zn_chain_refill(B, in, base_bit, TL); }
+    const uint32_t ia = 2u * (A.whi >> sh), ib = 2u * (B.whi >> sh);
+    const uint32_t mA = lut32[ia + 1u], mB = lut32[ib + 1u];      // both in flight before either is used
+    uint32_t sA = 0, sB = 0;
+    if (MODE == 2) { sA = lut32[ia]; sB = lut32[ib]; }
+    if (a) zn_chain_step<MODE>(A, mA, sA, stage);
+    if (b) zn_chain_step<MODE>(B, mB, sB, stage);
   }
 }
 
@@ -136,7 +139,7 @@ __device__ __forceinline__ void zn_fused_run2(const uint64_t* lut, const uint32_
 template <int P, int H>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
-                                              const uint64_t* lut, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
+                                              const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
                                               uint32_t TL, uint32_t D2u, const uint8_t* stream, uint32_t slen) {
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
@@ -155,12 +158,12 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   };
   // interleave rows (ring bytes for the Huffman plane, fetched bytes for raw planes) and store them.
   // All loads are complete before the first store is issued, so no store latency is ever waited on.
-  auto emit_rows = [&](uint32_t first_row_sym, int nrows) {
+  // `stage_row0` = staging-buffer row that holds symbol `first_row_sym`.
+  auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0) {
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
     for (int r = 0; r < RB; r++) if (r < nrows) {
-      const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
       for (int p = 0; p < P; p++) {
-        if (p == H) { const uint32_t i = (si >> 2) % ZN_F_RING_DW; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
+        if (p == H) { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
         else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) pre[r][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
       }
     }
@@ -195,7 +198,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     // no Huffman plane: the chunk is a pure P-way interleave of raw / RLE planes
     while (JF < seg) {
       const uint32_t left = (seg - JF) / UNIT; const int nr = left < (uint32_t)RB ? (int)left : RB;
-      fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT;
+      fetch_rows(JF, nr); emit_rows(JF, nr, 0); JF += (uint32_t)nr * UNIT;
     }
     ZN_PT(3);
     return true;
@@ -250,18 +253,18 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
     // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it
     ZnChain A, B;
-    zn_chain_init(A, (lane > 0 && actA) ? hiA + delta : hiA, hiA, 0);
-    zn_chain_init(B, actB ? hiB + delta : hiB, hiB, 0);
-    zn_fused_run2<0>(lut, in, base_bit, TL, A, B, nullptr);
+    zn_chain_init(A, (lane > 0 && actA) ? hiA + delta : hiA, hiA, TL, 0);
+    zn_chain_init(B, actB ? hiB + delta : hiB, hiB, TL, 0);
+    zn_fused_run2<0>(lut32, in, base_bit, TL, A, B, nullptr);
     int32_t sA = (lane > 0) ? A.pos : carry, sB = B.pos;
     ZN_PT(5);   // sync run-in
 
     // count, and verify that the 128 sub-blocks form one consistent chain below the true start of the first
     uint32_t nA = 0, nB = 0; int32_t eA = sA, eB = sB; bool needA = actA, needB = actB, chained = false;
     for (int it = 0; it < 130; it++) {
-      zn_chain_init(A, needA ? sA : stopA, stopA, 0);
-      zn_chain_init(B, needB ? sB : stopB, stopB, 0);
-      zn_fused_run2<1>(lut, in, base_bit, TL, A, B, nullptr);
+      zn_chain_init(A, needA ? sA : stopA, stopA, TL, 0);
+      zn_chain_init(B, needB ? sB : stopB, stopB, TL, 0);
+      zn_fused_run2<1>(lut32, in, base_bit, TL, A, B, nullptr);
       if (needA) { eA = A.pos; nA = A.n; }
       if (needB) { eB = B.pos; nB = B.n; }
       const int32_t eB_prev = __shfl_up(eB, 1u);
@@ -291,16 +294,28 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     fetch_rows(JF, first);
     ZN_PT(8);   // scans / shuffles / issue loads
 
-    // write: second decode of the same sub-blocks, symbols OR-ed into the ring at their final index
-    zn_chain_init(A, actA ? sA : stopA, stopA, J + o_k);
-    zn_chain_init(B, actB ? sB : stopB, stopB, J + o_k + nA);
-    zn_fused_run2<2>(lut, in, base_bit, TL, A, B, ring);
+    // write: second decode of the same sub-blocks, symbols OR-ed into the staging buffer; the buffer is
+    // linear: its byte 0 holds symbol JF (the unflushed remainder of the previous tile sits at its start)
+    zn_chain_init(A, actA ? sA : stopA, stopA, TL, J - JF + o_k);
+    zn_chain_init(B, actB ? sB : stopB, stopB, TL, J - JF + o_k + nA);
+    zn_fused_run2<2>(lut32, in, base_bit, TL, A, B, ring);
     __builtin_amdgcn_wave_barrier();
     ZN_PT(9);   // write pass
     J += N; carry = e_last; hi_dw = lo_dw;
 
-    emit_rows(JF, first); JF += (uint32_t)first * UNIT; rows -= first;
-    while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr); JF += (uint32_t)nr * UNIT; rows -= nr; }
+    const int total_rows = rows;
+    uint32_t srow = 0;
+    emit_rows(JF, first, srow); JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
+    while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
+    if (total_rows > 0 && J > JF) {
+      // move the incomplete last row (< UNIT symbols) to the start of the staging buffer
+      const uint32_t i = ((uint32_t)total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
+      uint32_t t[EW];
+      for (int k = 0; k < EW; k++) { t[k] = ring[i + k]; ring[i + k] = 0; }
+      __builtin_amdgcn_wave_barrier();
+      for (int k = 0; k < EW; k++) ring[((uint32_t)EPL * lane >> 2) + k] = t[k];
+      __builtin_amdgcn_wave_barrier();
+    }
     ZN_PT(3);   // flush rows
   }
   return ok && carry == b0 && J == seg && JF == seg;
@@ -387,7 +402,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
       }
       for (int k = 0; k < 8; k++) {
         const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-        if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)(cnt[k] | (pos[k] << 4) | starts[k]) << 32);
+        if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k]) << 32);
       }
     }
     // shortest code length → how many symbols a tile can hold → sub-block size (dwords; two sub-blocks per lane)
@@ -412,7 +427,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
   uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
   uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
   bool ok;
-#define ZN_WAVE_CASE(H_) ok = zn_fused_wave<P, H_>(g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, D2, stream, slen)
+#define ZN_WAVE_CASE(H_) ok = zn_fused_wave<P, H_>(g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, D2, stream, slen)
   if (h < 0) ZN_WAVE_CASE(-1);
   else if (h == 0) ZN_WAVE_CASE(0);
   else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
