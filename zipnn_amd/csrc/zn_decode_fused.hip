@@ -201,6 +201,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       fetch_rows(JF, nr); emit_rows(JF, nr, 0); JF += (uint32_t)nr * UNIT;
     }
     ZN_PT(3);
+    ZN_PT_FLUSH();
     return true;
   }
 
@@ -318,6 +319,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     }
     ZN_PT(3);   // flush rows
   }
+  ZN_PT_FLUSH();
   return ok && carry == b0 && J == seg && JF == seg;
 }
 
@@ -437,6 +439,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
   if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
   if (tid == 0) done[c] = 1;
   ZN_PT_COUNT(19, 1);                        // chunks
+  ZN_PT_FLUSH();
 }
 
 #ifdef ZN_PHASE_TIMERS
