@@ -1,0 +1,90 @@
+"""CPU tests (-m "not gpu") of the safetensors surface, driven through the SIMT-emulated kernels:
+file round trip like the reference's tests/simple_stress_tests.py:205-264 (fp16 / bf16 / fp8 matrices,
+half constant, half random) and load through zipnn_safetensors() + safe_open."""
+import os
+
+import pytest
+import torch
+
+
+def _model(seed):
+    g = torch.Generator().manual_seed(seed)
+    base = torch.ones(100, 100)
+    base[50:] = torch.rand(50, 100, generator=g) * 2 - 1
+    return {
+        "w_bf16": base.to(torch.bfloat16),
+        "w_fp16": base.to(torch.float16),
+        "w_fp8": base.to(torch.float8_e4m3fn),
+        "w_fp32": (torch.randn(300, 40, generator=g) * 0.02),
+        "ids": torch.arange(1000, dtype=torch.int64),
+        "tiny": torch.randn(3, generator=g).to(torch.bfloat16),
+    }
+
+
+def test_safetensors_file_roundtrip_and_plugin(use_simt, tmp_path):
+    import safetensors
+    import safetensors.torch
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    from zipnn_amd.zipnn import METADATA_KEY
+    tensors = _model(3)
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    znn_path = safetensors_io.compress_safetensors_file(src)
+    assert znn_path.endswith(".znn.safetensors") and os.path.getsize(znn_path) < os.path.getsize(src)
+    with safetensors.safe_open(znn_path, "pt", "cpu") as f:       # raw view: frames are uint8 tensors
+        meta = f.metadata()
+        assert METADATA_KEY in meta and "w_bf16" in meta[METADATA_KEY] and "ids" not in meta[METADATA_KEY]
+        assert f.get_tensor("w_bf16").dtype == torch.uint8
+    # file -> file
+    back = safetensors_io.decompress_safetensors_file(znn_path, out_path=os.path.join(tmp_path, "back.safetensors"))
+    with safetensors.safe_open(back, "pt", "cpu") as f:
+        for k, v in tensors.items():
+            got = f.get_tensor(k)
+            assert got.dtype == v.dtype and got.shape == v.shape
+            assert got.view(torch.uint8).numpy().tobytes() == v.contiguous().view(torch.uint8).numpy().tobytes()
+    # plugin: patched safe_open decompresses on access
+    orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
+    try:
+        zipnn_safetensors()
+        with safetensors.torch.safe_open(znn_path, "pt", "cpu") as f:
+            for k, v in tensors.items():
+                got = f.get_tensor(k)
+                assert got.dtype == v.dtype and torch.equal(got.view(torch.uint8), v.contiguous().view(torch.uint8)), k
+            assert f.get_slice("ids")[:10].tolist() == list(range(10))
+            assert f.get_slice("w_bf16") is NotImplementedError      # reference behaviour, zipnn.py:1617
+        with safetensors.safe_open(znn_path, framework="pt", device="cpu") as f:   # keyword form used by newer callers
+            assert torch.equal(f.get_tensor("w_fp32"), tensors["w_fp32"])
+    finally:
+        safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+
+
+def test_zipnn_api_errors_and_types(use_simt):
+    from zipnn_amd import ZipNN
+    with pytest.raises(ValueError):
+        ZipNN(compression_chunk=3000)
+    with pytest.raises(ValueError):
+        ZipNN(input_format="torch", is_streaming=True)
+    with pytest.raises(ValueError):
+        ZipNN(method="nope")
+    with pytest.raises(ValueError):
+        ZipNN(input_format="torch").compress(torch.arange(10))
+    with pytest.raises(ValueError):
+        ZipNN().decompress(b"XX" + bytes(40))
+    z = ZipNN(bytearray_dtype="float32")
+    raw = (torch.rand(8192) * 2 - 1).numpy().tobytes()
+    frame = z.compress(raw)
+    assert isinstance(frame, memoryview) and bytes(frame[:2]) == b"ZN" and frame[5] == 220 and frame[15] == 1
+    assert int.from_bytes(frame[24:32], "little") == len(frame)
+    assert bytes(ZipNN(bytearray_dtype="float32").decompress(frame)) == raw
+    import numpy as np
+    a = (np.random.default_rng(0).standard_normal((33, 77)) * 0.02).astype(np.float16)
+    back = ZipNN(input_format="numpy").decompress(ZipNN(input_format="numpy").compress(a))
+    assert isinstance(back, np.ndarray) and back.dtype == a.dtype and back.shape == a.shape and (back == a).all()
+    # delta (XOR) and streaming compose at the Python level exactly like the reference
+    b2 = bytes(x ^ 0x5A for x in raw[:4096]) + raw[4096:]
+    zd = ZipNN(bytearray_dtype="float32", delta_compressed_type="byte")
+    assert bytes(ZipNN(bytearray_dtype="float32", delta_compressed_type="byte").decompress(zd.compress(raw, delta_second_data=b2), delta_second_data=b2)) == raw
+    zs = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 12)
+    blob = zs.compress(raw)
+    assert isinstance(blob, bytearray) and bytes(ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 12).decompress(blob)) == raw

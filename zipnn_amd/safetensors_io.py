@@ -1,0 +1,64 @@
+"""Tensor-by-tensor safetensors compression (the file producer/consumer either side of the hot path;
+SURVEY.md §8f-1).  Same file layout as the reference's scripts/zipnn_compress_safetensors.py:37-148 and
+scripts/zipnn_decompress_safetensors.py:34-136: every floating-point tensor that shrinks is stored as a
+1-D uint8 tensor holding one TORCH-format ZN frame, and listed (dtype, shape) in the file metadata under
+`znn_compressed_vectors`; everything else is stored untouched.  Suffix: `.znn.safetensors`.
+"""
+import os
+
+import torch
+
+from .zipnn import (COMPRESSED_DTYPE, COMPRESSION_METHOD, METADATA_KEY, ZipNN, build_compressed_tensor_info,
+                    get_compressed_tensors_metadata, set_compressed_tensors_metadata)
+
+SUFFIX = ".znn.safetensors"
+
+
+def compress_safetensors_file(filename, out_path=None, device="cpu", method=None):
+    """-> path of the compressed file.  `device` = where tensors are staged for compression
+    ("cuda:N" compresses in HBM; the compressed frames come back to the host for writing)."""
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    assert filename.endswith(".safetensors")
+    out_path = out_path or filename[: -len(".safetensors")] + SUFFIX
+    tensors, infos = {}, {}
+    with safe_open(filename, "pt", device) as f:
+        for name in f.keys():
+            t = f.get_tensor(name)
+            if not torch.is_floating_point(t) or t.dtype == torch.float64 or t.numel() == 0:
+                tensors[name] = t.cpu()
+                continue
+            znn = ZipNN(input_format="torch", bytearray_dtype=t.dtype, method=method or COMPRESSION_METHOD)
+            frame = znn.compress(t)                       # our compress never modifies `t`
+            if len(frame) >= t.element_size() * t.nelement():
+                tensors[name] = t.cpu()
+                continue
+            tensors[name] = torch.frombuffer(bytearray(frame), dtype=COMPRESSED_DTYPE)
+            infos[name] = build_compressed_tensor_info(t)
+        metadata = dict(f.metadata() or {})
+    if not metadata:
+        metadata = {"format": "pt"}                       # the reference silently drops the list when a file has no metadata
+    set_compressed_tensors_metadata(infos, metadata)
+    save_file(tensors, out_path, metadata)
+    return out_path
+
+
+def decompress_safetensors_file(filename, out_path=None, device="cpu"):
+    """Inverse of compress_safetensors_file -> path of the plain .safetensors file."""
+    from safetensors import safe_open
+    from safetensors.torch import save_file
+    assert filename.endswith(SUFFIX)
+    out_path = out_path or filename[: -len(SUFFIX)] + ".safetensors"
+    tensors = {}
+    with safe_open(filename, "pt", "cpu") as f:
+        metadata = dict(f.metadata() or {})
+        infos = get_compressed_tensors_metadata(metadata)
+        for name in f.keys():
+            t = f.get_tensor(name)
+            if name in infos:
+                znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
+                t = znn.decompress(t, decompress_cpu_gpu=device)
+            tensors[name] = t.cpu() if isinstance(t, torch.Tensor) else t
+    metadata.pop(METADATA_KEY, None)
+    save_file(tensors, out_path, metadata or None)
+    return out_path

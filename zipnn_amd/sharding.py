@@ -1,0 +1,69 @@
+"""Chunk-range sharding of one ZN frame body across GPUs (host-side bookkeeping only).
+
+Chunks are independent, so G ranks can code disjoint chunk ranges with no data-path collective
+(SURVEY.md §8e).  The wire format is plane-major, so a rank's output lands in `num_buf` disjoint
+regions of the final payload; these helpers do that arithmetic:
+
+  chunk_ranges(K, G)                 contiguous ranges [g*K/G, (g+1)*K/G)
+  split_body(body, P, chunk, n, G)   one standalone body per rank (types / re-based cumSizes / payload slices)
+  merge_bodies(parts, P)             the inverse: bodies of consecutive chunk ranges -> one body
+
+A merged body is byte-identical to the body a single device produces for the whole buffer.
+"""
+import numpy as np
+
+
+def chunk_ranges(num_chunks, world):
+    return [(g * num_chunks // world, (g + 1) * num_chunks // world) for g in range(world)]
+
+
+def _parse(body, P, K):
+    b = np.frombuffer(body, dtype=np.uint8)
+    types = b[: P * K].reshape(P, K)
+    cum = np.frombuffer(b[P * K: 9 * P * K].tobytes(), dtype=np.uint64).reshape(P, K).astype(np.int64)
+    payload = b[9 * P * K:]
+    return types, cum, payload
+
+
+def split_body(body, num_buf, chunk, orig_size, world):
+    """-> list of (sub_body: bytes, byte_offset, byte_length) for each rank's chunk range."""
+    P = num_buf
+    K = (orig_size + chunk - 1) // chunk
+    types, cum, payload = _parse(body, P, K)
+    plane_base = np.concatenate([[0], np.cumsum(cum[:, -1])[:-1]]) if K else np.zeros(P, dtype=np.int64)
+    out = []
+    for lo, hi in chunk_ranges(K, world):
+        k = hi - lo
+        pieces, cums = [], []
+        for p in range(P):
+            start = int(cum[p, lo - 1]) if lo else 0
+            end = int(cum[p, hi - 1]) if hi else 0
+            pieces.append(payload[int(plane_base[p]) + start: int(plane_base[p]) + end])
+            cums.append((cum[p, lo:hi] - start).astype(np.uint64))
+        sub = b"".join([types[:, lo:hi].tobytes()] + [c.tobytes() for c in cums] + [x.tobytes() for x in pieces]) if k else b""
+        off = lo * chunk
+        length = min(hi * chunk, orig_size) - off if k else 0
+        out.append((sub, off, length))
+    return out
+
+
+def merge_bodies(parts, num_buf):
+    """parts: list of (body: bytes-like, num_chunks) for consecutive chunk ranges -> one body (bytes)."""
+    P = num_buf
+    types_all, cum_all, pay_all = [[] for _ in range(P)], [[] for _ in range(P)], [[] for _ in range(P)]
+    run = np.zeros(P, dtype=np.int64)
+    for body, k in parts:
+        if k == 0:
+            continue
+        types, cum, payload = _parse(body, P, k)
+        base = 0
+        for p in range(P):
+            tot = int(cum[p, -1])
+            types_all[p].append(types[p])
+            cum_all[p].append((cum[p] + run[p]).astype(np.uint64))
+            pay_all[p].append(payload[base: base + tot])
+            run[p] += tot
+            base += tot
+    cat = lambda xs, dt: (np.concatenate(xs).astype(dt).tobytes() if xs else b"")  # noqa: E731
+    return (b"".join(cat(types_all[p], np.uint8) for p in range(P)) + b"".join(cat(cum_all[p], np.uint64) for p in range(P))
+            + b"".join(cat(pay_all[p], np.uint8) for p in range(P)))
