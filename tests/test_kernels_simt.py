@@ -118,3 +118,27 @@ def test_fused_detects_corrupt_stream(simt_lib):
     except RuntimeError:
         same = False
     assert not same    # either flagged corrupt or (self-synchronising code) different bytes; never a crash or hang
+
+
+ENC = [("bf16", 3 * C + 100, 2, 1, 10, C), ("fp16", 2 * C, 2, 0, 10, C), ("fp32", 2 * C, 4, 1, 220, C), ("fp8", 2 * C, 1, 1, 10, C),
+       ("u11", 2 * C, 2, 1, 10, C), ("skew", 2 * C, 1, 1, 10, C), ("skew", 2 * C, 2, 0, 10, C), ("rand", 2 * C, 4, 1, 220, C),
+       ("const", 2 * C + 2, 2, 1, 10, C), ("bf16", 256 * 1024, 2, 1, 10, 256 * 1024), ("bf16", 3 * 16384, 2, 1, 10, 16384),
+       ("bf16", 3 * 8192, 2, 1, 10, 8192)]
+
+
+@pytest.mark.parametrize("case", ENC, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
+def test_fused_encode_path_bit_exact(simt_lib, case):
+    """Full chunks go through zn_k_encode_stats/_emit (when the geometry allows) and must equal the oracle."""
+    kind, nb, P, rot, bm, chunk = case
+    d = _gen2(kind, nb, 21)
+    want = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8)
+    src16 = torch.empty(nb + 64, dtype=torch.uint8)
+    off = (-src16.data_ptr()) % 16
+    src16[off:off + nb] = src                                    # 16-byte aligned "device" buffer
+    cap = simt_lib.compress_bound(nb, P, chunk, 0)
+    body = torch.zeros(cap, dtype=torch.uint8)
+    used = simt_lib.compress_dev(src16.data_ptr() + off, nb, P, rot, bm, chunk, 0.95, body.data_ptr(), cap)
+    assert body[:used].numpy().tobytes() == want[32:]
+    if chunk % (8192 * P) == 0 and chunk // P <= 128 * 1024:
+        assert "zn_k_encode_stats" in simt_lib.last_kernels() and "zn_k_encode_emit" in simt_lib.last_kernels()

@@ -27,12 +27,12 @@ thread_local std::string t_kernels;
 // device serialise on their workspace — independent GPUs run in independent processes).
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
-  void* buf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[6] = {0, 0, 0, 0, 0, 0};
+  void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
 };
-enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS };
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC };
 
 std::mutex g_mu;
 Workspace g_ws[64];
@@ -116,21 +116,32 @@ int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int
   Workspace& w = g_ws[dev];
   const size_t slot = zn_plane_slot(chunk, num_buf);
   const size_t PK = (size_t)g.P * g.K;
-  if ((rc = ws_reserve(w, WS_PLANES, PK * slot))) return rc;
-  if ((rc = ws_reserve(w, WS_ENC, PK * slot))) return rc;
+  // full chunks go through the fused encoder, the partial tail (or everything, for geometries the fused
+  // kernels do not take) through the generic one
+  const uint64_t nfull = zn_encode_fused_ok(g, d_src) ? (uint64_t)(n / chunk) : 0;
+  const size_t PKL = (size_t)g.P * (g.K - nfull);
+  if ((rc = ws_reserve(w, WS_PLANES, PKL * slot))) return rc;
+  if ((rc = ws_reserve(w, WS_ENC, PKL * slot))) return rc;
   if ((rc = ws_reserve(w, WS_META_A, PK * sizeof(uint32_t)))) return rc;   // stored sizes
   if ((rc = ws_reserve(w, WS_META_B, PK))) return rc;                      // types
   if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(uint64_t)))) return rc;   // payload offsets
+  if ((rc = ws_reserve(w, WS_DESC, (nfull ? PK : 0) * sizeof(ZnEncDesc)))) return rc;   // indexed like csize/type (plane-major over all K)
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
   uint64_t* d_total = (uint64_t*)w.buf[WS_WORDS];
-  zn_launch_encode_generic(g, (const uint8_t*)d_src, threshold, (uint8_t*)w.buf[WS_PLANES], (uint8_t*)w.buf[WS_ENC],
-                           (uint32_t*)w.buf[WS_META_A], (uint8_t*)w.buf[WS_META_B], (uint64_t*)w.buf[WS_META_C], d_total,
-                           (uint8_t*)d_body, stream);
+  uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
+  uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
+  ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+  zn_launch_encode_fused_stats(g, nfull, (const uint8_t*)d_src, threshold, d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], stream);
+  zn_launch_encode_generic_stats(g, nfull, (const uint8_t*)d_src, threshold, (uint8_t*)w.buf[WS_PLANES], (uint8_t*)w.buf[WS_ENC], d_csize, d_type, stream);
+  zn_launch_scan_sizes(g, d_csize, d_type, d_offs, d_total, (uint8_t*)d_body, stream);
+  zn_launch_encode_fused_emit(g, nfull, (const uint8_t*)d_src, d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], (uint8_t*)d_body, d_status, stream);
+  zn_launch_encode_generic_gather(g, nfull, (const uint8_t*)w.buf[WS_PLANES], (const uint8_t*)w.buf[WS_ENC], d_csize, d_type, d_offs, (uint8_t*)d_body, stream);
   ZN_HIP(hipGetLastError());
-  ZN_HIP(hipMemcpyAsync(w.h_total, d_total, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  ZN_HIP(hipMemcpyAsync(w.h_total, d_total, 40, hipMemcpyDeviceToHost, stream));   // total length (bytes 0-7) and the status word (bytes 32-35)
   ZN_HIP(hipStreamSynchronize(stream));
   *body_len = (size_t)*w.h_total;
+  if (*w.h_status) return ZN_E_CORRUPT;   // internal consistency check of the encoder failed
   return ZN_OK;
 }
 
@@ -237,10 +248,10 @@ int zn_release_workspace(void) {
   for (int d = 0; d < 64; d++) {
     Workspace& w = g_ws[d];
     bool any = w.h_total != nullptr;
-    for (int i = 0; i < 6; i++) any = any || w.buf[i];
+    for (int i = 0; i < 7; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
-    for (int i = 0; i < 6; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
+    for (int i = 0; i < 7; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
   }
   return ZN_OK;

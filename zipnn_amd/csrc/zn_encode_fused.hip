@@ -1,0 +1,341 @@
+// zn_encode_fused.hip — the bandwidth path of compress: two kernels around one tiny scan, no scratch
+// planes, every compressed byte written once, directly at its final position in the frame body.
+//
+// The wire format is plane-major (all chunks of plane 0, then plane 1, …), so where a chunk's bytes go
+// depends on the stored sizes of ALL chunks.  huff0's output size, however, is known without encoding:
+// header size + Σ_streams ceil((Σ_s hist_stream[s]·len[s] + 1) / 8).  Hence:
+//
+//   zn_k_encode_stats<P>   one workgroup per full chunk, wave w = quarter w = stream w:
+//                          rotate + split on the fly, per-stream byte histograms (LDS atomics on packed
+//                          16-bit counters, 4 copies per wave against same-address serialisation);
+//                          HUF_compress control flow per plane (RLE / "not compressible" heuristic /
+//                          exact code lengths + tree description, zn_huf_tables.hpp), stream sizes from the
+//                          histograms, capacity and threshold rules → type + stored size per (plane, chunk);
+//                          kept planes leave their code table + tree description in a small descriptor.
+//   zn_k_scan_sizes        (zn_encode_generic.hip) per-plane inclusive scan → types, cumSizes, offsets, total.
+//   zn_k_encode_emit<P>    one workgroup per full chunk: re-reads the chunk (L2 / Infinity Cache), writes raw
+//                          planes straight to their payload position and bit-packs the 4 streams of a Huffman
+//                          plane in place: each lane packs the codes of 32 consecutive symbols in registers,
+//                          a wave prefix sum of the bit counts gives its bit offset in the tile, `ds_or_b32`
+//                          merges the lanes' words in an LDS tile buffer, full dwords go out coalesced.
+//
+// Algorithmic HBM bytes: N in + C out; this design reads N twice (second read mostly cache-resident).
+// Chunks these kernels do not take (the partial tail; or everything when chunk % (8192·P) ≠ 0 or planes
+// exceed 128 KiB) are handled by zn_encode_generic.hip — the host splits the chunk range.
+//
+// Replaces: compression_worker + HUF_compress call (reference csrc/zipnn_core.c:294-390), split_bytearray_*
+// (data_manipulation_dtype16.c:33-138, dtype32.c:78-133), prepare_python_return_buffer (:105-244).
+#include "zn_internal.hpp"
+#include "zn_huf_tables.hpp"
+
+#define ZN_E_THREADS 256
+#define ZN_E_COPIES 4                      // histogram copies per wave (lane & 3)
+#define ZN_E_SPL 32                        // symbols per lane per tile
+#define ZN_E_TILE (64 * ZN_E_SPL)          // symbols per tile
+#define ZN_E_BUF_DW 768                    // tile bit buffer: 2048 symbols × ≤12 bits = 768 dwords, + carry
+
+typedef uint64_t __attribute__((aligned(1))) zn_eu64u;
+typedef uint32_t __attribute__((aligned(1))) zn_eu32u;
+struct __attribute__((aligned(1))) zn_eu128u { uint32_t x, y, z, w; };
+
+// rotated dword → the reference's forward bit reorder for this plane count
+template <int P> __device__ __forceinline__ uint32_t zn_rot_fwd(uint32_t u, uint32_t rot) {
+  if (!rot) return u;
+  return (P == 2) ? zn_rot_fwd16(u) : (P == 4) ? zn_rot_fwd32(u) : u;
+}
+
+// ---------------------------------------------------------------------------
+// kernel A: statistics → type, stored size, code table
+// ---------------------------------------------------------------------------
+template <int P>
+struct ZnStatsLds {
+  uint32_t hist16[4][P][ZN_E_COPIES][128];   // packed u16 counters: bin b → dword b>>1, half b&1
+  uint16_t hq[4][P][256];                    // per-stream histograms (≤ 32768 each)
+  uint32_t count[P][256];                    // per-plane histograms
+  ZnTabScratch S;
+  ZnHNode nodes[513];
+  uint32_t kind[P], cs[P], largest[P], maxsv[P];
+  uint32_t go, hdr, bits[4];
+};
+
+template <int P>
+__global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, const uint8_t* __restrict__ src, float threshold,
+                                                                  uint32_t* __restrict__ csize_out, uint8_t* __restrict__ type_out,
+                                                                  ZnEncDesc* __restrict__ descs) {
+  __shared__ ZnStatsLds<P> L;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t c = blockIdx.x;
+  const uint32_t n = (uint32_t)(g.chunk / P);                 // plane length of a full chunk (the host launches full, eligible chunks only)
+
+  for (uint32_t i = tid; i < 4u * P * ZN_E_COPIES * 128u; i += ZN_E_THREADS) (&L.hist16[0][0][0][0])[i] = 0;
+  __syncthreads();
+
+  // ---- histograms: wave w reads quarter w of the chunk, 16 bytes per lane per step ----
+  {
+    const uint8_t* q = src + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
+    const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;
+    uint32_t* hbase = &L.hist16[wave][0][lane & (ZN_E_COPIES - 1)][0];
+    for (uint32_t v = lane; v < nvec; v += 64u) {
+      const uint4 x = *(const uint4*)(q + 16ull * v);
+      const uint32_t d[4] = {zn_rot_fwd<P>(x.x, g.rot), zn_rot_fwd<P>(x.y, g.rot), zn_rot_fwd<P>(x.z, g.rot), zn_rot_fwd<P>(x.w, g.rot)};
+      for (int k = 0; k < 4; k++)
+        for (int t = 0; t < 4; t++) {
+          const uint32_t b = (d[k] >> (8 * t)) & 0xFFu;
+          const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;
+          atomicAdd(hbase + (uint32_t)p * (ZN_E_COPIES * 128u) + (b >> 1), 1u << (16u * (b & 1u)));
+        }
+    }
+  }
+  __syncthreads();
+  // ---- reduce the copies: per-stream and per-plane histograms (thread = bin) ----
+  for (int p = 0; p < P; p++) {
+    uint32_t tot = 0;
+    for (int w = 0; w < 4; w++) {
+      uint32_t s = 0;
+      for (int r = 0; r < ZN_E_COPIES; r++) s += (L.hist16[w][p][r][tid >> 1] >> (16u * (tid & 1u))) & 0xFFFFu;
+      L.hq[w][p][tid] = (uint16_t)s; tot += s;
+    }
+    L.count[p][tid] = tot;
+  }
+  __syncthreads();
+  // ---- per plane: largest count, highest symbol, and the cheap exits of HUF_compress ----
+  if (wave < (uint32_t)P) {
+    const int p = (int)wave;
+    uint32_t mx = 0, hi = 0;
+    for (int k = 0; k < 4; k++) { const uint32_t b = lane + 64u * (uint32_t)k, v = L.count[p][b]; if (v > mx) mx = v; if (v && b > hi) hi = b; }
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d), h2 = __shfl_xor(hi, d); if (m2 > mx) mx = m2; if (h2 > hi) hi = h2; }
+    if (lane == 0) {
+      uint32_t kind = 0, cs = 0;                 // kind: 0 = store raw (cs = HUF return value), 1 = RLE, 2 = build a table
+      if (mx == n) { kind = 1; cs = 1; }
+      else if (mx <= (n >> 7) + 4u) cs = 0;      // "probably not compressible"
+      else kind = 2;
+      L.kind[p] = kind; L.cs[p] = cs; L.largest[p] = mx; L.maxsv[p] = hi;
+    }
+  }
+  __syncthreads();
+
+  const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
+  for (int p = 0; p < P; p++) {
+    const uint64_t pc = (uint64_t)p * g.K + c;
+    if (L.kind[p] == 2u) {                       // uniform across the workgroup
+      if (tid == 0) {
+        for (int i = 0; i < 256; i++) L.S.count[i] = L.count[p][i];
+        const uint32_t max_sv = L.maxsv[p];
+        uint32_t huff_log = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
+        huff_log = zn_huf_build_ctable(&L.S, L.nodes, max_sv, huff_log);
+        const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log);
+        uint32_t go = 0, cs = 0;
+        if (h < 0) cs = 0xFFFFFFFFu;             // huff0 error → fails the threshold test → raw
+        else if ((uint32_t)h + 12u >= n) cs = 0;
+        else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u) cs = 0;
+        else go = 1;
+        L.go = go; L.hdr = (uint32_t)(h > 0 ? h : 0); L.cs[p] = cs;
+        for (uint32_t s = max_sv + 1u; s < 256u; s++) { L.S.nbits[s] = 0; L.S.vals[s] = 0; }
+      }
+      __syncthreads();
+      if (L.go) {
+        // stream k's size from its histogram: Σ_s hq[k][s]·len[s] bits + end mark
+        uint32_t bits = 0;
+        for (int k = 0; k < 4; k++) { const uint32_t b = lane + 64u * (uint32_t)k; bits += (uint32_t)L.hq[wave][p][b] * (uint32_t)L.S.nbits[b]; }
+        for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d);
+        if (lane == 0) L.bits[wave] = bits + 1u;
+        __syncthreads();
+        uint32_t sz[4]; uint32_t pos = L.hdr + 6u; bool fail = false;
+        for (int k = 0; k < 4; k++) {            // BIT_closeCStream's capacity rule, stream by stream
+          const uint64_t cap_rem = cap - pos;
+          if (cap_rem <= 8u || (uint64_t)(L.bits[k] >> 3) >= cap_rem - 8u) { fail = true; sz[k] = 0; break; }
+          sz[k] = (L.bits[k] + 7u) >> 3; pos += sz[k];
+        }
+        uint32_t cs = fail ? 0u : pos;
+        if (!fail && pos >= n - 1u) cs = 0;
+        const bool keep = cs != 0 && (double)cs < (double)n * (double)threshold;
+        if (keep) {
+          ZnEncDesc* D = descs + pc;
+          D->code[tid] = (uint32_t)L.S.vals[tid] | ((uint32_t)L.S.nbits[tid] << 16);
+          if (tid < 136u) D->hdr[tid] = (tid < L.hdr) ? L.S.hdr[tid] : 0;
+          if (tid == 0) { D->hdr_len = L.hdr; for (int k = 0; k < 4; k++) D->ssize[k] = sz[k]; }
+        }
+        if (tid == 0) L.cs[p] = cs;
+        __syncthreads();
+      }
+    }
+    if (tid == 0) {
+      // threshold rule of compression_worker (zipnn_core.c:371-385)
+      const uint32_t cs = L.cs[p];
+      const bool huf = cs != 0 && (double)cs < (double)n * (double)threshold;
+      type_out[pc] = huf ? 1 : 0;
+      csize_out[pc] = huf ? cs : n;
+      if (huf && cs == 1u) descs[pc].hdr[0] = (uint8_t)L.maxsv[p];   // RLE: the byte
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// kernel C: emit
+// ---------------------------------------------------------------------------
+template <int P>
+struct ZnEmitLds {
+  uint32_t code[256];
+  uint32_t buf[4][ZN_E_BUF_DW + 4];
+};
+
+// H = plane to Huffman-encode in this pass (or -1: raw planes only); raw planes are written when `do_raw`.
+template <int P>
+__device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __restrict__ chunk_src, uint8_t* __restrict__ body,
+                                             const uint64_t (&off)[P], const uint32_t (&kind)[P], int H, bool do_raw,
+                                             const ZnEncDesc* D, const uint32_t* code, uint32_t* buf, uint32_t lane, uint32_t wave) {
+  const uint32_t n = (uint32_t)(g.chunk / P), seg = n / 4u;
+  const uint8_t* qsrc = chunk_src + (uint64_t)wave * (g.chunk / 4u);       // source bytes of this quarter
+  uint8_t* sdst = nullptr; uint32_t ssize = 0;
+  if (H >= 0) {
+    uint32_t so = D->hdr_len + 6u;
+    for (uint32_t k = 0; k < wave; k++) so += D->ssize[k];
+    ssize = D->ssize[wave];
+    uint64_t offH = 0;
+    for (int p = 0; p < P; p++) if (p == H) offH = off[p];
+    sdst = body + offH + so;
+    for (uint32_t i = lane; i < ZN_E_BUF_DW + 4u; i += 64u) buf[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+  }
+  uint32_t carry = 0;          // bits already in buf[0] from the previous tile (< 32)
+  uint32_t written = 0;        // stream bytes already stored
+  // tiles from the END of the segment to its start: huff0 packs the last symbol first
+  for (int32_t base = (int32_t)seg - ZN_E_TILE; base >= 0; base -= ZN_E_TILE) {
+    // this lane's 32 consecutive elements = 32·P source bytes
+    uint32_t d[8 * P];
+    const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + ZN_E_SPL * lane);
+    for (int k = 0; k < 2 * P; k++) { const uint4 x = *(const uint4*)(a + 16 * k); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w; }
+    for (int k = 0; k < 8 * P; k++) d[k] = zn_rot_fwd<P>(d[k], g.rot);
+    // raw planes: 32 bytes per lane, contiguous across the wave
+    if (do_raw) {
+      for (int p = 0; p < P; p++) if (kind[p] == 0u) {
+        uint32_t o[8];
+        for (int j = 0; j < 8; j++) {
+          uint32_t v = 0;
+          for (int t = 0; t < 4; t++) { const int e = 4 * j + t, k = P * e + p; v |= ((d[k >> 2] >> (8 * (k & 3))) & 0xFFu) << (8 * t); }
+          o[j] = v;
+        }
+        uint8_t* r = body + off[p] + (uint64_t)wave * seg + (uint32_t)base + ZN_E_SPL * lane;
+        zn_eu128u s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
+        *(zn_eu128u*)r = s0; *(zn_eu128u*)(r + 16) = s1;
+      }
+    }
+    if (H < 0) continue;
+    // codes of this lane's 32 symbols (val | len << 16) and their total length
+    uint32_t cw[ZN_E_SPL]; uint32_t T = 0;
+    for (int e = 0; e < ZN_E_SPL; e++) {
+      uint32_t sym = 0;
+      for (int p = 0; p < P; p++) if (p == H) { const int k = P * e + p; sym = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu; }
+      cw[e] = code[sym]; T += cw[e] >> 16;
+    }
+    // bit offset of this lane in the tile: lanes are packed from lane 63 down to lane 0
+    uint32_t incl = T;
+    for (uint32_t dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
+    const uint32_t total = __shfl(incl, 63);
+    uint32_t b = carry + (total - incl);
+    {
+      uint32_t idx = b >> 5, sh = b & 31u, acc = 0;
+      for (int e = ZN_E_SPL - 1; e >= 0; e--) {
+        const uint32_t v = cw[e] & 0xFFFFu, nb = cw[e] >> 16;
+        acc |= v << sh;
+        if (sh + nb >= 32u) { atomicOr(&buf[idx], acc); idx++; acc = v >> (32u - sh); sh = sh + nb - 32u; }   // sh ≥ 20 here
+        else sh += nb;
+      }
+      if (sh > 0u) atomicOr(&buf[idx], acc);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // flush whole dwords, keep the remainder (< 32 bits) at buf[0]
+    const uint32_t bits = carry + total, nd = bits >> 5;
+    if (written + 4u * nd > ssize) return false;
+    uint32_t tail = 0;
+    for (uint32_t i = lane; i <= nd; i += 64u) {
+      const uint32_t x = buf[i];
+      if (i < nd) { *(zn_eu32u*)(sdst + written + 4u * i) = x; }
+      if (i == nd) tail = x;
+      buf[i] = 0;
+    }
+    tail = __shfl(tail, (int)(nd & 63u));
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) buf[0] = tail;
+    __builtin_amdgcn_wave_barrier();
+    written += 4u * nd; carry = bits & 31u;
+  }
+  if (H >= 0) {
+    // end mark + zero padding: the stream ends in a non-zero byte
+    if (lane == 0) {
+      const uint32_t x = buf[0] | (1u << carry);
+      const uint32_t nbytes = (carry + 1u + 7u) >> 3;
+      if (written + nbytes != ssize) { buf[1] = 0xDEAD; }
+      else for (uint32_t k = 0; k < nbytes; k++) sdst[written + k] = (uint8_t)(x >> (8 * k));
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (buf[1] == 0xDEAD) return false;
+  }
+  return true;
+}
+
+template <int P>
+__global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnGeom g, const uint8_t* __restrict__ src,
+                                                                 const uint32_t* __restrict__ csize, const uint8_t* __restrict__ type,
+                                                                 const uint64_t* __restrict__ offs, const ZnEncDesc* __restrict__ descs,
+                                                                 uint8_t* __restrict__ body, uint32_t* __restrict__ status) {
+  __shared__ ZnEmitLds<P> L;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint64_t c = blockIdx.x;
+  const uint8_t* chunk_src = src + c * g.chunk;
+  uint64_t off[P]; uint32_t kind[P]; int nhuf = 0;           // kind: 0 raw, 1 RLE, 2 huff0
+  for (int p = 0; p < P; p++) {
+    const uint64_t pc = (uint64_t)p * g.K + c;
+    off[p] = offs[pc];
+    kind[p] = !type[pc] ? 0u : (csize[pc] == 1u ? 1u : 2u);
+    nhuf += kind[p] == 2u;
+  }
+  for (int p = 0; p < P; p++) {
+    const uint64_t pc = (uint64_t)p * g.K + c;
+    if (kind[p] == 1u && tid == 0) body[off[p]] = descs[pc].hdr[0];
+    if (kind[p] == 2u) {                                       // tree description + jump table
+      const ZnEncDesc* D = descs + pc;
+      const uint32_t hl = D->hdr_len;
+      for (uint32_t i = tid; i < hl; i += ZN_E_THREADS) body[off[p] + i] = D->hdr[i];
+      if (tid < 3u) { const uint32_t s = D->ssize[tid]; body[off[p] + hl + 2u * tid] = (uint8_t)s; body[off[p] + hl + 2u * tid + 1u] = (uint8_t)(s >> 8); }
+    }
+  }
+  bool ok = true, raw_done = false;
+  if (nhuf == 0) ok = zn_emit_pass<P>(g, chunk_src, body, off, kind, -1, true, nullptr, L.code, L.buf[wave], lane, wave);
+  else {
+    for (int p = 0; p < P; p++) if (kind[p] == 2u) {
+      const ZnEncDesc* D = descs + ((uint64_t)p * g.K + c);
+      __syncthreads();
+      L.code[tid] = D->code[tid];
+      __syncthreads();
+      ok = zn_emit_pass<P>(g, chunk_src, body, off, kind, p, !raw_done, D, L.code, L.buf[wave], lane, wave) && ok;
+      raw_done = true;
+    }
+  }
+  if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
+}
+
+// The fused encoder takes chunks [0, nfull): full chunks of a geometry zn_encode_fused_ok() accepted.
+bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src) {
+  const uint64_t n = g.chunk / g.P;
+  return (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
+}
+
+void zn_launch_encode_fused_stats(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, float threshold, uint32_t* d_csize,
+                                  uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream) {
+  if (nfull == 0) return;
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_encode_stats<1>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_encode_stats<2>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
+  else hipLaunchKernelGGL(zn_k_encode_stats<4>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
+  zn_note_kernel("zn_k_encode_stats");
+}
+
+void zn_launch_encode_fused_emit(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, const uint32_t* d_csize, const uint8_t* d_type,
+                                 const uint64_t* d_offs, const ZnEncDesc* d_descs, uint8_t* d_body, uint32_t* d_status, hipStream_t stream) {
+  if (nfull == 0) return;
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_encode_emit<1>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, d_csize, d_type, d_offs, d_descs, d_body, d_status);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_encode_emit<2>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, d_csize, d_type, d_offs, d_descs, d_body, d_status);
+  else hipLaunchKernelGGL(zn_k_encode_emit<4>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, d_csize, d_type, d_offs, d_descs, d_body, d_status);
+  zn_note_kernel("zn_k_encode_emit");
+}

@@ -21,14 +21,14 @@
 // kernel 1: rotate + split
 // ---------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void zn_k_split_planes(ZnGeom g, const uint8_t* __restrict__ src,
+__global__ __launch_bounds__(256) void zn_k_split_planes(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ src,
                                                          uint8_t* __restrict__ planes, uint64_t slot) {
-  const uint64_t c = blockIdx.x;
+  const uint64_t c = c0 + blockIdx.x, KL = g.K - c0;          // scratch slots are indexed relative to c0
   const uint32_t clen = zn_chunk_len(g, c);
   const uint8_t* in = src + c * g.chunk;
   const uint32_t nwords = clen / 4u;
   uint8_t* pl[P];
-  for (int p = 0; p < P; p++) pl[p] = planes + ((uint64_t)p * g.K + c) * slot;
+  for (int p = 0; p < P; p++) pl[p] = planes + ((uint64_t)p * KL + (c - c0)) * slot;
   const bool aligned = (((uint64_t)in) & 3u) == 0;
   for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
     uint32_t w = aligned ? *(const uint32_t*)(in + 4ull * wi) : zn_ld32(in + 4ull * wi);
@@ -61,7 +61,7 @@ __device__ inline void zn_encode_stream_serial(uint8_t* dst, const uint8_t* src,
   if (nacc) dst[o++] = (uint8_t)acc;
 }
 
-__global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, const uint8_t* __restrict__ planes,
+__global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ planes,
                                                               uint8_t* __restrict__ enc, uint64_t slot, float threshold,
                                                               uint32_t* __restrict__ csize_out, uint8_t* __restrict__ type_out) {
   __shared__ ZnTabScratch S;
@@ -69,12 +69,13 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, const ui
   __shared__ uint32_t sh_hdr, sh_go, sh_bits[4];
 
   const uint32_t lane = threadIdx.x;
-  const uint64_t pc = blockIdx.x;
-  const uint32_t p = (uint32_t)(pc / g.K);
-  const uint64_t c = pc % g.K;
+  const uint64_t KL = g.K - c0, pcl = blockIdx.x;              // local (scratch) index
+  const uint32_t p = (uint32_t)(pcl / KL);
+  const uint64_t c = c0 + pcl % KL;
+  const uint64_t pc = (uint64_t)p * g.K + c;                   // global index
   const uint32_t n = zn_plane_len(zn_chunk_len(g, c), g.P, p);
-  const uint8_t* src = planes + pc * slot;
-  uint8_t* dst = enc + pc * slot;
+  const uint8_t* src = planes + pcl * slot;
+  uint8_t* dst = enc + pcl * slot;
   const uint64_t cap = g.chunk;   // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
 
   for (uint32_t i = lane; i < 256u; i += ZN_WAVE) S.count[i] = 0;
@@ -188,34 +189,43 @@ __global__ __launch_bounds__(256) void zn_k_scan_sizes(ZnGeom g, const uint32_t*
 // ---------------------------------------------------------------------------
 // kernel 4: payload gather
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void zn_k_gather_payload(ZnGeom g, const uint8_t* __restrict__ planes,
+__global__ __launch_bounds__(256) void zn_k_gather_payload(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ planes,
                                                            const uint8_t* __restrict__ enc, uint64_t slot,
                                                            const uint32_t* __restrict__ csize, const uint8_t* __restrict__ type,
                                                            const uint64_t* __restrict__ offs, uint8_t* __restrict__ body) {
-  const uint64_t pc = blockIdx.x;
-  const uint8_t* s = (type[pc] ? enc : planes) + pc * slot;
+  const uint64_t KL = g.K - c0, pcl = blockIdx.x;
+  const uint64_t pc = (pcl / KL) * g.K + c0 + pcl % KL;
+  const uint8_t* s = (type[pc] ? enc : planes) + pcl * slot;
   uint8_t* d = body + offs[pc];
   const uint32_t n = csize[pc];
   for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
 }
 
-void zn_launch_encode_generic(const ZnGeom& g, const uint8_t* d_src, float threshold, uint8_t* d_planes,
-                              uint8_t* d_enc, uint32_t* d_csize, uint8_t* d_type, uint64_t* d_offs,
-                              uint64_t* d_total, uint8_t* d_body, hipStream_t stream) {
+void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t* d_src, float threshold, uint8_t* d_planes,
+                                    uint8_t* d_enc, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream) {
+  if (c0 >= g.K) return;
   const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
-  const uint32_t PK = (uint32_t)(g.P * g.K);
-  if (g.K) {
-    if (g.P == 1) hipLaunchKernelGGL(zn_k_split_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_src, d_planes, slot);
-    else if (g.P == 2) hipLaunchKernelGGL(zn_k_split_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_src, d_planes, slot);
-    else hipLaunchKernelGGL(zn_k_split_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_src, d_planes, slot);
-    zn_note_kernel("zn_k_split_planes");
-    hipLaunchKernelGGL(zn_k_encode_planes, dim3(PK), dim3(ZN_WAVE), 0, stream, g, d_planes, d_enc, slot, threshold, d_csize, d_type);
-    zn_note_kernel("zn_k_encode_planes");
-  }
+  const uint32_t KL = (uint32_t)(g.K - c0), PKL = (uint32_t)g.P * KL;
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_split_planes<1>, dim3(KL), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_split_planes<2>, dim3(KL), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+  else hipLaunchKernelGGL(zn_k_split_planes<4>, dim3(KL), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+  zn_note_kernel("zn_k_split_planes");
+  hipLaunchKernelGGL(zn_k_encode_planes, dim3(PKL), dim3(ZN_WAVE), 0, stream, g, c0, d_planes, d_enc, slot, threshold, d_csize, d_type);
+  zn_note_kernel("zn_k_encode_planes");
+}
+
+void zn_launch_scan_sizes(const ZnGeom& g, const uint32_t* d_csize, const uint8_t* d_type, uint64_t* d_offs,
+                          uint64_t* d_total, uint8_t* d_body, hipStream_t stream) {
   hipLaunchKernelGGL(zn_k_scan_sizes, dim3(1), dim3(256), 0, stream, g, d_csize, d_type, d_offs, d_total, d_body);
   zn_note_kernel("zn_k_scan_sizes");
-  if (g.K) {
-    hipLaunchKernelGGL(zn_k_gather_payload, dim3(PK), dim3(256), 0, stream, g, d_planes, d_enc, slot, d_csize, d_type, d_offs, d_body);
-    zn_note_kernel("zn_k_gather_payload");
-  }
+}
+
+void zn_launch_encode_generic_gather(const ZnGeom& g, uint64_t c0, const uint8_t* d_planes, const uint8_t* d_enc,
+                                     const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, uint8_t* d_body,
+                                     hipStream_t stream) {
+  if (c0 >= g.K) return;
+  const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
+  const uint32_t PKL = (uint32_t)(g.P * (g.K - c0));
+  hipLaunchKernelGGL(zn_k_gather_payload, dim3(PKL), dim3(256), 0, stream, g, c0, d_planes, d_enc, slot, d_csize, d_type, d_offs, d_body);
+  zn_note_kernel("zn_k_gather_payload");
 }
