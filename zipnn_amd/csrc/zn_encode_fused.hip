@@ -118,11 +118,24 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
   for (int p = 0; p < P; p++) {
     const uint64_t pc = (uint64_t)p * g.K + c;
     if (L.kind[p] == 2u) {                       // uniform across the workgroup
+      {
+        // HUF_sort, in parallel: a symbol's position is the number of symbols that sort before it
+        // (larger count, or equal count and smaller symbol value)
+        const uint32_t max_sv = L.maxsv[p];
+        for (uint32_t i = tid; i < 513u; i += ZN_E_THREADS) { ZnHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nb = 0; L.nodes[i] = z; }
+        __syncthreads();
+        if (tid <= max_sv) {
+          const uint32_t cme = L.count[p][tid]; uint32_t rank = 0;
+          for (uint32_t u = 0; u <= max_sv; u++) { const uint32_t cu = L.count[p][u]; rank += (cu > cme || (cu == cme && u < tid)) ? 1u : 0u; }
+          ZnHNode z; z.count = cme; z.parent = 0; z.byte = (uint8_t)tid; z.nb = 0;
+          L.nodes[1u + rank] = z;
+        }
+        __syncthreads();
+      }
       if (tid == 0) {
-        for (int i = 0; i < 256; i++) L.S.count[i] = L.count[p][i];
         const uint32_t max_sv = L.maxsv[p];
         uint32_t huff_log = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
-        huff_log = zn_huf_build_ctable(&L.S, L.nodes, max_sv, huff_log);
+        huff_log = zn_huf_build_from_sorted(&L.S, L.nodes, max_sv, huff_log);
         const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log);
         uint32_t go = 0, cs = 0;
         if (h < 0) cs = 0xFFFFFFFFu;             // huff0 error → fails the threshold test → raw

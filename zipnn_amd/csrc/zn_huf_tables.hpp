@@ -28,6 +28,11 @@ struct ZnTabScratch {
   int32_t  tt_fs[16];
   uint8_t  cell[64];
   uint16_t state[64];
+  // small work arrays of the serial builders (kept in LDS: dynamically indexed private arrays would
+  // otherwise live in scratch memory)
+  uint32_t rk_base[33], rk_cur[33], rank_last[ZN_HUF_LOG_MAX + 2];
+  uint16_t per_rank[ZN_HUF_LOG_MAX + 2], val_rank[ZN_HUF_LOG_MAX + 2];
+  uint32_t wcount[ZN_HUF_LOG_MAX + 2], cumul[ZN_HUF_LOG_MAX + 4];
 };
 
 // FSE_optimalTableLog_internal: 32-bit unsigned arithmetic, wrap-around included
@@ -47,8 +52,8 @@ __device__ inline uint32_t zn_optimal_table_log(uint32_t max_log, uint32_t src_s
 // encoder side: histogram -> code lengths/values -> tree description
 // ---------------------------------------------------------------------------
 // order: count descending, equal counts keep ascending symbol order (HUF_sort)
-__device__ inline void zn_huf_sort(ZnHNode* node, const uint32_t* count, uint32_t max_sv) {
-  uint32_t base[33], cur[33];
+__device__ inline void zn_huf_sort(ZnTabScratch* S, ZnHNode* node, const uint32_t* count, uint32_t max_sv) {
+  uint32_t* base = S->rk_base; uint32_t* cur = S->rk_cur;
   for (int i = 0; i < 33; i++) base[i] = 0;
   for (uint32_t n = 0; n <= max_sv; n++) base[zn_hb32(count[n] + 1u)]++;
   for (int n = 30; n > 0; n--) base[n - 1] += base[n];
@@ -62,7 +67,7 @@ __device__ inline void zn_huf_sort(ZnHNode* node, const uint32_t* count, uint32_
 }
 
 // HUF_setMaxHeight
-__device__ inline uint32_t zn_huf_limit_height(ZnHNode* node, uint32_t last, uint32_t max_nb) {
+__device__ inline uint32_t zn_huf_limit_height(ZnTabScratch* S, ZnHNode* node, uint32_t last, uint32_t max_nb) {
   const uint32_t largest = node[last].nb;
   if (largest <= max_nb) return largest;
   int cost = 0; const uint32_t base_cost = 1u << (largest - max_nb);
@@ -71,7 +76,7 @@ __device__ inline uint32_t zn_huf_limit_height(ZnHNode* node, uint32_t last, uin
   while (node[n].nb == max_nb) n--;
   cost >>= (largest - max_nb);
   const uint32_t NONE = 0xF0F0F0F0u;
-  uint32_t rank_last[ZN_HUF_LOG_MAX + 2];
+  uint32_t* rank_last = S->rank_last;
   for (uint32_t i = 0; i < ZN_HUF_LOG_MAX + 2; i++) rank_last[i] = NONE;
   { uint32_t cur = max_nb;
     for (int pos = n; pos >= 0; pos--) { if (node[pos].nb >= cur) continue; cur = node[pos].nb; rank_last[max_nb - cur] = (uint32_t)pos; } }
@@ -100,13 +105,22 @@ __device__ inline uint32_t zn_huf_limit_height(ZnHNode* node, uint32_t last, uin
   return max_nb;
 }
 
+// Code lengths and canonical values from symbols ALREADY sorted into tab0[1..] (count descending, equal
+// counts in ascending symbol order; every other field of the 513 nodes zero): the part of HUF_buildCTable
+// after HUF_sort.  Returns the maximum code length.
+__device__ inline uint32_t zn_huf_build_from_sorted(ZnTabScratch* S, ZnHNode* tab0, uint32_t max_sv, uint32_t max_nb_bits);
+
 // HUF_buildCTable: S->count[0..max_sv] -> S->nbits/S->vals; tab0 = 513 nodes of LDS.
 // Returns the maximum code length.
 __device__ inline uint32_t zn_huf_build_ctable(ZnTabScratch* S, ZnHNode* tab0, uint32_t max_sv, uint32_t max_nb_bits) {
+  for (int i = 0; i < 513; i++) { tab0[i].count = 0; tab0[i].parent = 0; tab0[i].byte = 0; tab0[i].nb = 0; }
+  zn_huf_sort(S, tab0 + 1, S->count, max_sv);
+  return zn_huf_build_from_sorted(S, tab0, max_sv, max_nb_bits);
+}
+
+__device__ inline uint32_t zn_huf_build_from_sorted(ZnTabScratch* S, ZnHNode* tab0, uint32_t max_sv, uint32_t max_nb_bits) {
   const int START = 256;
   ZnHNode* node = tab0 + 1;
-  for (int i = 0; i < 513; i++) { tab0[i].count = 0; tab0[i].parent = 0; tab0[i].byte = 0; tab0[i].nb = 0; }
-  zn_huf_sort(node, S->count, max_sv);
   int non_null = (int)max_sv;
   while (node[non_null].count == 0) non_null--;
   int low_s = non_null, node_nb = START, low_n = START;
@@ -126,8 +140,8 @@ __device__ inline uint32_t zn_huf_build_ctable(ZnTabScratch* S, ZnHNode* tab0, u
   node[root].nb = 0;
   for (int n = root - 1; n >= START; n--) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
   for (int n = 0; n <= non_null; n++) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
-  max_nb_bits = zn_huf_limit_height(node, (uint32_t)non_null, max_nb_bits);
-  uint16_t per_rank[ZN_HUF_LOG_MAX + 1], val_rank[ZN_HUF_LOG_MAX + 1];
+  max_nb_bits = zn_huf_limit_height(S, node, (uint32_t)non_null, max_nb_bits);
+  uint16_t* per_rank = S->per_rank; uint16_t* val_rank = S->val_rank;
   for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) { per_rank[i] = 0; val_rank[i] = 0; }
   for (int n = 0; n <= non_null; n++) per_rank[node[n].nb]++;
   { uint16_t mn = 0; for (int n = (int)max_nb_bits; n > 0; n--) { val_rank[n] = mn; mn = (uint16_t)(mn + per_rank[n]); mn >>= 1; } }
@@ -147,7 +161,7 @@ __device__ inline void zn_sbw_add(ZnSmallBitW* w, uint32_t v, uint32_t nb) {
 // FSE_normalizeCount (+ FSE_normalizeM2) for the weight histogram; low-probability
 // symbols get +1 (huff0 of zstd ≥ 1.4.7).  Returns 0 ok, 1 = rle, -1 = error.
 __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_t* count, uint32_t total_in, uint32_t max_sv) {
-  const uint32_t rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+#define ZN_RTB(p_) ((p_) == 0 ? 0u : (p_) == 1 ? 473195u : (p_) == 2 ? 504333u : (p_) == 3 ? 520860u : (p_) == 4 ? 550000u : (p_) == 5 ? 700000u : (p_) == 6 ? 750000u : 830000u)
   uint64_t total = total_in;
   const uint64_t scale = 62 - tl, step = (1ULL << 62) / (uint32_t)total, vstep = 1ULL << (scale - 20);
   int still = 1 << tl; uint32_t largest = 0; int16_t largest_p = 0;
@@ -157,7 +171,7 @@ __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_
     if (count[s] == 0) { norm[s] = 0; continue; }
     if (count[s] <= low_thr) { norm[s] = 1; still--; continue; }
     int16_t p = (int16_t)(((uint64_t)count[s] * step) >> scale);
-    if (p < 8) { const uint64_t beat = vstep * rtb[p]; p += ((uint64_t)count[s] * step) - ((uint64_t)p << scale) > beat; }
+    if (p < 8) { const uint64_t beat = vstep * ZN_RTB(p); p += ((uint64_t)count[s] * step) - ((uint64_t)p << scale) > beat; }
     if (p > largest_p) { largest_p = p; largest = s; }
     norm[s] = p; still -= p;
   }
@@ -208,7 +222,7 @@ __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_
 // HUF_compressWeights: weights w[0..nw) -> dst.  0 = not compressible, 1 = single value,
 // >1 = size (1000 = "too long to be kept"), -1 = error.
 __device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint8_t* w, uint32_t nw) {
-  uint32_t count[ZN_HUF_LOG_MAX + 1];
+  uint32_t* count = S->wcount;
   uint32_t max_sv = ZN_HUF_LOG_MAX, max_c = 0;
   if (nw <= 1) return 0;
   for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) count[i] = 0;
@@ -256,7 +270,7 @@ __device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uin
   // FSE_buildCTable
   {
     const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
-    uint32_t cumul[ZN_HUF_LOG_MAX + 3];
+    uint32_t* cumul = S->cumul;
     uint32_t high = size - 1u;
     cumul[0] = 0;
     for (uint32_t u = 1; u <= max_sv + 1; u++) {
