@@ -49,6 +49,16 @@ def main():
     print(f"  total                        {tot / chunks:10.0f} cyc/chunk")
     print(f"  tiles/chunk(wave0) {acc[18] / chunks:.2f}  fix-up iterations/tile {acc[16] / max(acc[18], 1):.3f}  "
           f"mismatching lanes/tile {acc[17] / max(acc[18], 1):.3f}")
+    # encoder statistics kernel
+    raw.zn_debug_phase_read_enc(acc, 1)
+    codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)
+    raw.zn_debug_phase_read_enc(acc, 1)
+    ch = acc[19] or 1
+    en = {0: "zero + histogram", 1: "reduce + decisions", 2: "parallel sort", 3: "serial tree/lengths/description", 4: "stream sizes + descriptor"}
+    tot = sum(acc[i] for i in range(5))
+    print(f"encode stats kernel, {ch} chunks")
+    for i in range(5):
+        print(f"  {en[i]:32s} {acc[i] / ch:10.0f} cyc/chunk  {100.0 * acc[i] / max(tot, 1):5.1f} %")
 
 
 if __name__ == "__main__":

@@ -10,9 +10,9 @@
 //      LUT: one 64-bit entry per 11-bit window = up to 4 symbols, their start offsets, total.
 //   2. each wave decodes its backward bit-stream IN PARALLEL ACROSS ITS 64 LANES.  huff0 has no
 //      gap array, so this uses Huffman self-synchronisation, format-transparently: the stream
-//      is cut into tiles of 64 sub-blocks of D dwords; lane k guesses a start a few dozen bits
+//      is cut into tiles of 64 sub-blocks of D dwords; lane k guesses a start 48 bits
 //      above its sub-block, decodes until it crosses into it ("sync"), then decodes its
-//      sub-block counting symbols; a wave shuffle checks that every lane's exit position is the
+//      sub-block counting symbols (branch-free steps, "refill + 3 lookups" unrolled); a wave shuffle checks that every lane's exit position is the
 //      next lane's start (mismatching lanes restart from the exact position until the chain is
 //      consistent, and the run-in is doubled for the rest of the stream — the top lane always
 //      starts from the true position carried from the previous tile); a prefix sum of the
@@ -71,66 +71,70 @@ __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane,
   return x - v;
 }
 
-// One decode chain = one sub-block of the tile being walked by one lane.  All 32-bit arithmetic:
-// the unread bits sit MSB-aligned in (whi:wlo) and are consumed with v_alignbit_b32.
+// One decode chain = the sub-block of the tile walked by one lane.  All 32-bit arithmetic: the unread
+// bits sit MSB-aligned in (whi:wlo) and are consumed with v_alignbit_b32.  The loops are BRANCH-FREE per
+// step (lanes that are done keep executing with a zero-length step) and unrolled as "refill + 3 steps":
+// a refill leaves ≥ 33 valid bits and a step consumes ≤ TL ≤ 11, so no per-step refill test is needed.
 struct ZnChain {
   int32_t pos, stop;          // next unread bit / boundary: symbols starting in (stop, pos] belong to this chain
-  int32_t lim;                // refill when pos < lim (fewer than TL valid bits left in the window)
-  int32_t tail;               // stop + TL: below this, a lookup group may reach past the boundary
   uint32_t whi, wlo;
   uint32_t n;                 // MODE 1: symbols counted
   uint32_t wpos;              // MODE 2: byte offset in the staging buffer of the next symbol
 };
 
-__device__ __forceinline__ void zn_chain_init(ZnChain& c, int32_t pos, int32_t stop, uint32_t TL, uint32_t wpos) {
-  c.pos = pos; c.stop = stop; c.lim = 0x7FFFFFFF; c.tail = stop + (int32_t)TL; c.whi = 0; c.wlo = 0; c.n = 0; c.wpos = wpos;
+__device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, int32_t base_bit) {
+  int32_t q = c.pos - 1 - base_bit;
+  q = q < 32 ? 32 : q;                                     // (only lanes that are done can be below; keeps in[j-1] in range)
+  const int32_t j = q >> 5; const uint32_t sh = 31u - (uint32_t)(q & 31);
+  const uint32_t d1 = in[j], d0 = in[j - 1];
+  const uint32_t t = __builtin_amdgcn_alignbit(d1, d0, 32u - sh);   // (d1:d0) << sh, upper dword — wrong for sh == 0 …
+  c.whi = sh ? t : d1;                                              // … where alignbit's shift wraps to 0
+  c.wlo = d0 << sh;
 }
-__device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, int32_t base_bit, uint32_t TL) {
-  const int32_t q = c.pos - 1 - base_bit;                 // ≥ 32 here: in[0] is one dword below the tile
-  const int32_t j = q >> 5, r = q & 31;
-  const uint64_t w = ((((uint64_t)in[j]) << 32) | in[j - 1]) << (31 - r);
-  c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w;
-  c.lim = c.pos - (33 + r) + (int32_t)TL;                 // 33 + r valid bits from here
-}
-template <int MODE>
-__device__ __forceinline__ void zn_chain_step(ZnChain& c, uint32_t meta, uint32_t syms, uint32_t* stage) {
-  uint32_t nb = meta & 15u, cnt = meta >> 29;
-  if (c.pos < c.tail) {
-    // near the boundary: keep only the symbols of this group that START above `stop`
-    const uint32_t r = (uint32_t)(c.pos - c.stop);        // 1 … TL-1; absent symbols carry start offset 15
-    const uint32_t s1 = (meta >> 8) & 15u, s2 = (meta >> 12) & 15u, s3 = (meta >> 16) & 15u;
-    const uint32_t keep = 1u + (s1 < r ? 1u : 0u) + (s2 < r ? 1u : 0u) + (s3 < r ? 1u : 0u);
-    if (keep < cnt) { nb = (meta >> (4u + 4u * keep)) & 15u; cnt = keep; syms &= (1u << (8u * keep)) - 1u; }
-  }
-  c.whi = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb); c.wlo <<= nb; c.pos -= (int32_t)nb;   // nb ≥ 1
-  if (MODE == 1) c.n += cnt;
+// one step; `multi`: take the whole group of the LUT entry (else only its first symbol)
+template <int MODE, bool MULTI>
+__device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32, uint32_t sh, int32_t bound, uint32_t* stage) {
+  const uint32_t idx = 2u * (c.whi >> sh);
+  const uint32_t meta = lut32[idx + 1u];
+  const bool act = c.pos > bound;                                   // MULTI: bound = stop + TL - 1; single: bound = stop
+  uint32_t nb, cnt;
+  if (MULTI) { nb = meta & 15u; cnt = meta >> 29; }
+  else { const uint32_t s1 = (meta >> 8) & 15u; nb = (meta >> 29) > 1u ? s1 : (meta & 15u); cnt = 1u; }   // length of the first symbol
+  nb = act ? nb : 0u; cnt = act ? cnt : 0u;
   if (MODE == 2) {
-    const uint32_t fill = c.wpos & 3u, sh8 = fill << 3, dw = c.wpos >> 2;
-    atomicOr(&stage[dw], syms << sh8);
-    if (fill + cnt > 4u) atomicOr(&stage[dw + 1u], syms >> (32u - sh8));     // fill ≥ 1 here
+    uint32_t syms = lut32[idx];
+    if (!MULTI) syms &= 0xFFu;
+    syms = act ? syms : 0u;
+    const uint32_t sh8 = (c.wpos & 3u) << 3; uint32_t* d = stage + (c.wpos >> 2);
+    atomicOr(d, syms << sh8);
+    atomicOr(d + 1, (syms >> 1) >> (31u - sh8));                    // bytes that spill into the next dword (0 when none)
     c.wpos += cnt;
   }
+  const uint32_t t = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb);
+  c.whi = nb ? t : c.whi; c.wlo <<= nb; c.pos -= (int32_t)nb;
+  if (MODE == 1) c.n += cnt;
 }
 
-// Walk two independent chains (the lane's two sub-blocks) in one loop, so that their dependent LUT
-// reads overlap.  MODE 0: just advance (sync run-in); 1: count symbols; 2: OR the symbols into the
-// staging buffer (ds_or_b32: neighbouring chains share boundary dwords).
-// base_bit = absolute bit position of bit 0 of in[0].
+// Decode every symbol that starts in (stop, pos]: groups of up to 4 symbols while the whole group provably
+// starts above `stop`, single symbols for the last < TL bits.  MODE 0: advance only (sync run-in);
+// 1: count symbols; 2: OR the symbols into the staging buffer (ds_or_b32: neighbouring lanes share dwords).
+// base_bit = absolute bit position of bit 0 of in[0].  All 64 lanes call this together.
 template <int MODE>
-__device__ __forceinline__ void zn_fused_run2(const uint32_t* lut32, const uint32_t* in, int32_t base_bit, uint32_t TL,
-                                              ZnChain& A, ZnChain& B, uint32_t* stage) {
+__device__ __forceinline__ void zn_fused_run(const uint32_t* lut32, const uint32_t* in, int32_t base_bit, uint32_t TL,
+                                             ZnChain& c, uint32_t* stage) {
   const uint32_t sh = 32u - TL;
-  for (;;) {
-    const bool a = A.pos > A.stop, b = B.pos > B.stop;
-    if (!a && !b) break;
-    const bool ra = a && A.pos < A.lim, rb = b && B.pos < B.lim;
-    if (ra || rb) { if (ra) zn_chain_refill(A, in, base_bit, TL); if (rb) zn_chain_refill(B, in, base_bit, TL); }
-    const uint32_t ia = 2u * (A.whi >> sh), ib = 2u * (B.whi >> sh);
-    const uint32_t mA = lut32[ia + 1u], mB = lut32[ib + 1u];      // both in flight before either is used
-    uint32_t sA = 0, sB = 0;
-    if (MODE == 2) { sA = lut32[ia]; sB = lut32[ib]; }
-    if (a) zn_chain_step<MODE>(A, mA, sA, stage);
-    if (b) zn_chain_step<MODE>(B, mB, sB, stage);
+  const int32_t mb = c.stop + (int32_t)TL - 1;
+  while (__any(c.pos > mb)) {
+    zn_chain_refill(c, in, base_bit);
+    zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
+    zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
+    zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
+  }
+  while (__any(c.pos > c.stop)) {
+    zn_chain_refill(c, in, base_bit);
+    zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
+    zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
+    zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
   }
 }
 
@@ -140,7 +144,7 @@ template <int P, int H>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
                                               const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
-                                              uint32_t TL, uint32_t D2u, const uint8_t* stream, uint32_t slen) {
+                                              uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen) {
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
@@ -216,10 +220,10 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t b0 = (int32_t)(8u * (uint32_t)(sa & 3u));
   int32_t carry = b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last);
   int32_t hi_dw = (carry + 31) >> 5;
-  const int32_t D2 = (int32_t)D2u, TD = 128 * D2;          // dwords per sub-block / per tile
-  int32_t delta = (ZN_F_DELTA0 < 32 * D2) ? ZN_F_DELTA0 : 32 * D2;
+  const int32_t Di = (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
+  int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
 
-  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..2*D2
+  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D
   // (the stream's top dword may straddle the end of the buffer: that one dword is assembled from bytes)
   uint32_t nx[ZN_F_DMAX + 1];
   const int32_t top_dw = hi_dw - 1;
@@ -247,46 +251,39 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
     ZN_PT(4);   // stage tile
     const int32_t base_bit = 32 * (lo_dw - 1);
-    // this lane's two sub-blocks: A = sub-block 2*lane (upper), B = 2*lane+1 (lower)
-    const int32_t hiA = 32 * (hi_dw - 2 * (int32_t)lane * D2), hiB = hiA - 32 * D2, loB = hiB - 32 * D2;
-    const int32_t stopA = hiB > b0 ? hiB : b0, stopB = loB > b0 ? loB : b0;
-    const bool actA = hiA > b0, actB = hiB > b0;
+    const int32_t hi_k = 32 * (hi_dw - (int32_t)lane * Di), lo_k = hi_k - 32 * Di;
+    const int32_t stop = lo_k > b0 ? lo_k : b0;
+    const bool active = hi_k > b0;
 
     // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it
-    ZnChain A, B;
-    zn_chain_init(A, (lane > 0 && actA) ? hiA + delta : hiA, hiA, TL, 0);
-    zn_chain_init(B, actB ? hiB + delta : hiB, hiB, TL, 0);
-    zn_fused_run2<0>(lut32, in, base_bit, TL, A, B, nullptr);
-    int32_t sA = (lane > 0) ? A.pos : carry, sB = B.pos;
+    ZnChain A;
+    A.pos = (lane > 0 && active) ? hi_k + delta : hi_k; A.stop = hi_k; A.n = 0; A.wpos = 0; A.whi = 0; A.wlo = 0;
+    zn_fused_run<0>(lut32, in, base_bit, TL, A, nullptr);
+    int32_t s = (lane > 0) ? A.pos : carry;
     ZN_PT(5);   // sync run-in
 
-    // count, and verify that the 128 sub-blocks form one consistent chain below the true start of the first
-    uint32_t nA = 0, nB = 0; int32_t eA = sA, eB = sB; bool needA = actA, needB = actB, chained = false;
-    for (int it = 0; it < 130; it++) {
-      zn_chain_init(A, needA ? sA : stopA, stopA, TL, 0);
-      zn_chain_init(B, needB ? sB : stopB, stopB, TL, 0);
-      zn_fused_run2<1>(lut32, in, base_bit, TL, A, B, nullptr);
-      if (needA) { eA = A.pos; nA = A.n; }
-      if (needB) { eB = B.pos; nB = B.n; }
-      const int32_t eB_prev = __shfl_up(eB, 1u);
-      const bool misA = actA && lane > 0 && eB_prev != sA;
-      const bool misB = actB && eA != sB;
+    // count, and verify that the 64 sub-blocks form one consistent chain below the true start of the first
+    uint32_t n = 0; int32_t e = s; bool need = active, chained = false;
+    for (int it = 0; it < 66; it++) {
+      A.pos = need ? s : stop; A.stop = stop; A.n = 0;
+      zn_fused_run<1>(lut32, in, base_bit, TL, A, nullptr);
+      if (need) { e = A.pos; n = A.n; }
+      const int32_t e_prev = __shfl_up(e, 1u);
+      const bool mism = active && lane > 0 && e_prev != s;
       if (it == 0) ZN_PT(6); else ZN_PT(7);   // first count pass / fix-up passes
-      if (!__any(misA || misB)) { chained = true; break; }
+      if (!__any(mism)) { chained = true; break; }
       ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
-      ZN_PT_COUNT(17, __popcll(__ballot(misA)) + __popcll(__ballot(misB)));
-      if (it == 0) { delta *= 2; if (delta > 32 * D2) delta = 32 * D2; }
-      needA = misA; needB = misB;
-      if (misA) sA = eB_prev;
-      if (misB) sB = eA;
+      ZN_PT_COUNT(17, __popcll(__ballot(mism)));
+      if (it == 0) { delta *= 2; if (delta > 32 * Di) delta = 32 * Di; }
+      need = mism;
+      if (mism) s = e_prev;
     }
     ZN_PT_COUNT(18, 1);                      // tiles
-    if (!actA) nA = 0;
-    if (!actB) nB = 0;
+    if (!active) n = 0;
     uint32_t N = 0;
-    const uint32_t o_k = zn_wave_excl_scan(nA + nB, lane, &N);
-    const uint32_t nact = (uint32_t)__popcll(__ballot(actA));
-    const int32_t e_last = __shfl(actB ? eB : eA, (int)(nact ? nact - 1u : 0u));
+    const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
+    const uint32_t nact = (uint32_t)__popcll(__ballot(active));
+    const int32_t e_last = __shfl(e, (int)(nact ? nact - 1u : 0u));
     if (!chained || J + N > seg || J + N - JF > ZN_F_RING_BYTES) { ok = false; break; }
 
     // rows that will be complete after this tile: request their raw bytes now, use them after the write pass
@@ -295,11 +292,10 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     fetch_rows(JF, first);
     ZN_PT(8);   // scans / shuffles / issue loads
 
-    // write: second decode of the same sub-blocks, symbols OR-ed into the staging buffer; the buffer is
+    // write: second decode of the same sub-block, symbols OR-ed into the staging buffer; the buffer is
     // linear: its byte 0 holds symbol JF (the unflushed remainder of the previous tile sits at its start)
-    zn_chain_init(A, actA ? sA : stopA, stopA, TL, J - JF + o_k);
-    zn_chain_init(B, actB ? sB : stopB, stopB, TL, J - JF + o_k + nA);
-    zn_fused_run2<2>(lut32, in, base_bit, TL, A, B, ring);
+    A.pos = active ? s : stop; A.stop = stop; A.wpos = J - JF + o_k;
+    zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
     __builtin_amdgcn_wave_barrier();
     ZN_PT(9);   // write pass
     J += N; carry = e_last; hi_dw = lo_dw;
@@ -364,7 +360,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
   if (!elig || nhuf > 1u) { if (tid == 0) done[c] = 0; return; }
 
   const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
-  uint32_t TL = 0, D2 = 1;
+  uint32_t TL = 0, D = 1;
   const uint8_t* stream = nullptr; uint32_t slen = 0;
 
   if (h >= 0) {
@@ -407,10 +403,10 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
         if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k]) << 32);
       }
     }
-    // shortest code length → how many symbols a tile can hold → sub-block size (dwords; two sub-blocks per lane)
-    D2 = (((ZN_F_RING_BYTES - UNIT) * st.lmin) / 2048u) / 2u;
-    if (D2 > ZN_F_DMAX / 2) D2 = ZN_F_DMAX / 2;
-    if (D2 < 1u) D2 = 1u;
+    // shortest code length → how many symbols a tile can hold → sub-block size D (dwords)
+    D = ((ZN_F_RING_BYTES - UNIT - 8u) * st.lmin) / 2048u;
+    if (D > ZN_F_DMAX) D = ZN_F_DMAX;
+    if (D < 1u) D = 1u;
     // jump table → this wave's stream
     const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
     const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
@@ -429,7 +425,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
   uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
   uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
   bool ok;
-#define ZN_WAVE_CASE(H_) ok = zn_fused_wave<P, H_>(g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, D2, stream, slen)
+#define ZN_WAVE_CASE(H_) ok = zn_fused_wave<P, H_>(g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, D, stream, slen)
   if (h < 0) ZN_WAVE_CASE(-1);
   else if (h == 0) ZN_WAVE_CASE(0);
   else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));

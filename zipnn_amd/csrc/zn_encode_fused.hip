@@ -66,6 +66,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t c = blockIdx.x;
   const uint32_t n = (uint32_t)(g.chunk / P);                 // plane length of a full chunk (the host launches full, eligible chunks only)
+  ZN_PT_DECL;
 
   for (uint32_t i = tid; i < 4u * P * ZN_E_COPIES * 128u; i += ZN_E_THREADS) (&L.hist16[0][0][0][0])[i] = 0;
   __syncthreads();
@@ -87,6 +88,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
     }
   }
   __syncthreads();
+  ZN_PT(0);   // zero + histogram
   // ---- reduce the copies: per-stream and per-plane histograms (thread = bin) ----
   for (int p = 0; p < P; p++) {
     uint32_t tot = 0;
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
     }
   }
   __syncthreads();
+  ZN_PT(1);   // reduce + plane decisions
 
   const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
   for (int p = 0; p < P; p++) {
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
           L.nodes[1u + rank] = z;
         }
         __syncthreads();
+        ZN_PT(2);   // parallel sort
       }
       if (tid == 0) {
         const uint32_t max_sv = L.maxsv[p];
@@ -146,6 +150,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
         for (uint32_t s = max_sv + 1u; s < 256u; s++) { L.S.nbits[s] = 0; L.S.vals[s] = 0; }
       }
       __syncthreads();
+      ZN_PT(3);   // serial: tree, lengths, tree description
       if (L.go) {
         // stream k's size from its histogram: Σ_s hq[k][s]·len[s] bits + end mark
         uint32_t bits = 0;
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
         }
         if (tid == 0) L.cs[p] = cs;
         __syncthreads();
+        ZN_PT(4);   // stream sizes + descriptor
       }
     }
     if (tid == 0) {
@@ -182,6 +188,8 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
     }
     __syncthreads();
   }
+  ZN_PT_COUNT(19, 1);
+  ZN_PT_FLUSH();
 }
 
 // ---------------------------------------------------------------------------
@@ -328,6 +336,15 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnGeom g, const
   }
   if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
 }
+
+#ifdef ZN_PHASE_TIMERS
+extern "C" int zn_debug_phase_read_enc(unsigned long long* out, int reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(zn_phase_acc), sizeof(unsigned long long) * 64) != hipSuccess) return -2;
+  if (reset) { unsigned long long z[64] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(zn_phase_acc), z, sizeof(z)) != hipSuccess) return -2; }
+  return 0;
+}
+#endif
 
 // The fused encoder takes chunks [0, nfull): full chunks of a geometry zn_encode_fused_ok() accepted.
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src) {

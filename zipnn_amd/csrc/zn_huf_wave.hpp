@@ -100,13 +100,13 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
 
   // ---- two interleaved states over the backward stream, all on wave-uniform (scalar) values ----
   // `win` holds the next unread bits top-aligned (MSB = bit pos-1 of the stream), zero below bit 0;
-  // decoded weights are dropped into lanes of four VGPRs (compare + select) and stored once at the end.
+  // decoded weights are packed as nibbles into one VGPR (lane o>>3, nibble o&7) and stored once at the end.
   const uint32_t bn = (FEND - B0) >> 3;
   const uint32_t lastb = zn_wbits(H, FEND - 8u, 8, FEND);
   if (lastb == 0) return -1;
   int32_t pos = (int32_t)(8u * (bn - 1u)) + (int32_t)zn_hb32(lastb);
   uint64_t win = 0; int32_t avail = 0;
-  uint32_t wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
+  uint32_t wv = 0;                                     // 8 four-bit weights per lane (weights are ≤ 12)
 #define ZN_WREFILL() do { \
     const uint32_t abs_ = B0 + (uint32_t)pos - 1u; const uint32_t k_ = abs_ >> 5, r_ = abs_ & 31u; \
     const uint64_t hi_ = ((uint64_t)zn_rl(H.v, k_ & 63u) << 32) | (k_ >= 1u ? zn_rl(H.v, (k_ - 1u) & 63u) : 0u); \
@@ -117,12 +117,8 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
 #define ZN_WTAKE(nb_, out_) do { const uint32_t n_ = (nb_); \
     if (avail < (int32_t)n_ && pos > avail) ZN_WREFILL(); \
     out_ = n_ ? (uint32_t)(win >> (64u - n_)) : 0u; win = n_ ? (win << n_) : win; avail -= (int32_t)n_; pos -= (int32_t)n_; } while (0)
-#define ZN_WPUT(sym_) do { const uint32_t y_ = (sym_) & 0xFFu; const uint32_t l_ = (uint32_t)o & 63u; \
-    if (o < 64) wv0 = (lane == l_) ? y_ : wv0; \
-    else if (o < 128) wv1 = (lane == l_) ? y_ : wv1; \
-    else if (o < 192) wv2 = (lane == l_) ? y_ : wv2; \
-    else wv3 = (lane == l_) ? y_ : wv3; \
-    o++; } while (0)
+#define ZN_WPUT(sym_) do { const uint32_t sv_ = ((sym_) & 0xFu) << (4u * ((uint32_t)o & 7u)); \
+    wv |= (lane == ((uint32_t)o >> 3)) ? sv_ : 0u; o++; } while (0)          /* weight o → nibble o&7 of lane o>>3 */
   if (pos > 0) ZN_WREFILL();
   uint32_t s1, s2;
   ZN_WTAKE(tl, s1);
@@ -140,10 +136,8 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
 #undef ZN_WREFILL
 #undef ZN_WTAKE
 #undef ZN_WPUT
-  if ((int)lane < o) sh_w[lane] = (uint8_t)wv0;
-  if ((int)lane + 64 < o) sh_w[lane + 64u] = (uint8_t)wv1;
-  if ((int)lane + 128 < o) sh_w[lane + 128u] = (uint8_t)wv2;
-  if ((int)lane + 192 < o) sh_w[lane + 192u] = (uint8_t)wv3;
+  if (lane < 32u)                                      // unpack: lane l holds weights 8l … 8l+7
+    for (uint32_t k = 0; k < 8u; k++) sh_w[8u * lane + k] = (uint8_t)((wv >> (4u * k)) & 0xFu);
   return o;
 }
 
