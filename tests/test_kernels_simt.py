@@ -140,5 +140,5 @@ def test_fused_encode_path_bit_exact(simt_lib, case):
     body = torch.zeros(cap, dtype=torch.uint8)
     used = simt_lib.compress_dev(src16.data_ptr() + off, nb, P, rot, bm, chunk, 0.95, body.data_ptr(), cap)
     assert body[:used].numpy().tobytes() == want[32:]
-    if chunk % (8192 * P) == 0 and chunk // P <= 128 * 1024:
+    if chunk % 16384 == 0 and chunk % (8192 * P) == 0 and chunk // P <= 128 * 1024:
         assert "zn_k_encode_stats" in simt_lib.last_kernels() and "zn_k_encode_emit" in simt_lib.last_kernels()

@@ -3,14 +3,14 @@
 //
 // The wire format is plane-major (all chunks of plane 0, then plane 1, …), so where a chunk's bytes go
 // depends on the stored sizes of ALL chunks.  huff0's output size, however, is known without encoding:
-// header size + Σ_streams ceil((Σ_s hist_stream[s]·len[s] + 1) / 8).  Hence:
+// header size + Σ_streams ceil((Σ_{symbols of the stream} len[sym] + 1) / 8).  Hence:
 //
 //   zn_k_encode_stats<P>   one workgroup per full chunk, wave w = quarter w = stream w:
-//                          rotate + split on the fly, per-stream byte histograms (LDS atomics on packed
-//                          16-bit counters, 4 copies per wave against same-address serialisation);
+//                          rotate + split on the fly, byte histograms with bank-conflict-free LDS atomics
+//                          (packed 16-bit counters, one column per lane of a half-wave);
 //                          HUF_compress control flow per plane (RLE / "not compressible" heuristic /
-//                          exact code lengths + tree description, zn_huf_tables.hpp), stream sizes from the
-//                          histograms, capacity and threshold rules → type + stored size per (plane, chunk);
+//                          exact code lengths + tree description, zn_huf_tables.hpp), stream sizes by summing
+//                          code lengths over each quarter, capacity and threshold rules → type + stored size per (plane, chunk);
 //                          kept planes leave their code table + tree description in a small descriptor.
 //   zn_k_scan_sizes        (zn_encode_generic.hip) per-plane inclusive scan → types, cumSizes, offsets, total.
 //   zn_k_encode_emit<P>    one workgroup per full chunk: re-reads the chunk (L2 / Infinity Cache), writes raw
@@ -29,7 +29,6 @@
 #include "zn_huf_tables.hpp"
 
 #define ZN_E_THREADS 256
-#define ZN_E_COPIES 4                      // histogram copies per wave (lane & 3)
 #define ZN_E_SPL 32                        // symbols per lane per tile
 #define ZN_E_TILE (64 * ZN_E_SPL)          // symbols per tile
 #define ZN_E_BUF_DW 768                    // tile bit buffer: 2048 symbols × ≤12 bits = 768 dwords, + carry
@@ -49,8 +48,11 @@ template <int P> __device__ __forceinline__ uint32_t zn_rot_fwd(uint32_t u, uint
 // ---------------------------------------------------------------------------
 template <int P>
 struct ZnStatsLds {
-  uint32_t hist16[4][P][ZN_E_COPIES][128];   // packed u16 counters: bin b → dword b>>1, half b&1
-  uint16_t hq[4][P][256];                    // per-stream histograms (≤ 32768 each)
+  // workgroup-shared histograms, one column per lane of a half-wave so that a wave's 32 concurrent LDS
+  // atomics always hit 32 different banks: counter(bin, col) = 16-bit half (bin & 1) of dword
+  // (bin >> 1) * COLS + col.  A column sees ≤ 8192 symbols, so the packed halves cannot carry over.
+  static constexpr int COLS = (P == 4) ? 16 : 32;
+  uint32_t hist16[P][128 * COLS];
   uint32_t count[P][256];                    // per-plane histograms
   ZnTabScratch S;
   ZnHNode nodes[513];
@@ -68,35 +70,37 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
   const uint32_t n = (uint32_t)(g.chunk / P);                 // plane length of a full chunk (the host launches full, eligible chunks only)
   ZN_PT_DECL;
 
-  for (uint32_t i = tid; i < 4u * P * ZN_E_COPIES * 128u; i += ZN_E_THREADS) (&L.hist16[0][0][0][0])[i] = 0;
+  constexpr uint32_t COLS = ZnStatsLds<P>::COLS;
+  for (uint32_t i = tid; i < (uint32_t)P * 128u * COLS; i += ZN_E_THREADS) (&L.hist16[0][0])[i] = 0;
   __syncthreads();
 
   // ---- histograms: wave w reads quarter w of the chunk, 16 bytes per lane per step ----
   {
     const uint8_t* q = src + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
     const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;
-    uint32_t* hbase = &L.hist16[wave][0][lane & (ZN_E_COPIES - 1)][0];
-    for (uint32_t v = lane; v < nvec; v += 64u) {
-      const uint4 x = *(const uint4*)(q + 16ull * v);
-      const uint32_t d[4] = {zn_rot_fwd<P>(x.x, g.rot), zn_rot_fwd<P>(x.y, g.rot), zn_rot_fwd<P>(x.z, g.rot), zn_rot_fwd<P>(x.w, g.rot)};
-      for (int k = 0; k < 4; k++)
-        for (int t = 0; t < 4; t++) {
-          const uint32_t b = (d[k] >> (8 * t)) & 0xFFu;
-          const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;
-          atomicAdd(hbase + (uint32_t)p * (ZN_E_COPIES * 128u) + (b >> 1), 1u << (16u * (b & 1u)));
-        }
+    uint32_t* hbase = &L.hist16[0][lane & (COLS - 1u)];
+    // 4 independent 16-byte loads in flight per lane per step (nvec is a multiple of 256)
+    for (uint32_t v0 = lane; v0 < nvec; v0 += 256u) {
+      uint4 xs[4];
+      for (int u = 0; u < 4; u++) xs[u] = *(const uint4*)(q + 16ull * (v0 + 64u * (uint32_t)u));
+      for (int u = 0; u < 4; u++) {
+        const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
+        for (int k = 0; k < 4; k++)
+          for (int t = 0; t < 4; t++) {
+            const uint32_t b = (d[k] >> (8 * t)) & 0xFFu;
+            const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;
+            atomicAdd(hbase + (uint32_t)p * (128u * COLS) + (b >> 1) * COLS, 1u << (16u * (b & 1u)));
+          }
+      }
     }
   }
   __syncthreads();
   ZN_PT(0);   // zero + histogram
-  // ---- reduce the copies: per-stream and per-plane histograms (thread = bin) ----
+  // ---- reduce the columns: per-plane histograms (thread = bin; column order staggered per lane so that
+  //      the 64 lanes of a wave read different banks) ----
   for (int p = 0; p < P; p++) {
     uint32_t tot = 0;
-    for (int w = 0; w < 4; w++) {
-      uint32_t s = 0;
-      for (int r = 0; r < ZN_E_COPIES; r++) s += (L.hist16[w][p][r][tid >> 1] >> (16u * (tid & 1u))) & 0xFFFFu;
-      L.hq[w][p][tid] = (uint16_t)s; tot += s;
-    }
+    for (uint32_t r = 0; r < COLS; r++) tot += (L.hist16[p][(tid >> 1) * COLS + ((r + (tid >> 1)) & (COLS - 1u))] >> (16u * (tid & 1u))) & 0xFFFFu;
     L.count[p][tid] = tot;
   }
   __syncthreads();
@@ -152,9 +156,26 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
       __syncthreads();
       ZN_PT(3);   // serial: tree, lengths, tree description
       if (L.go) {
-        // stream k's size from its histogram: Σ_s hq[k][s]·len[s] bits + end mark
+        // stream k's size: wave k re-reads its quarter (cache-resident) and sums the code lengths
         uint32_t bits = 0;
-        for (int k = 0; k < 4; k++) { const uint32_t b = lane + 64u * (uint32_t)k; bits += (uint32_t)L.hq[wave][p][b] * (uint32_t)L.S.nbits[b]; }
+        {
+          const uint8_t* q = src + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
+          const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;
+          const uint8_t* nbt = L.S.nbits;
+          for (uint32_t v0 = lane; v0 < nvec; v0 += 256u) {
+            uint4 xs[4];
+            for (int u = 0; u < 4; u++) xs[u] = *(const uint4*)(q + 16ull * (v0 + 64u * (uint32_t)u));
+            for (int u = 0; u < 4; u++) {
+              const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
+              // the bytes of plane p inside a dword: P = 1: all four; P = 2: bytes p, p+2; P = 4: byte p
+              for (int k = 0; k < 4; k++) {
+                if (P == 1) { for (int t = 0; t < 4; t++) bits += nbt[(d[k] >> (8 * t)) & 0xFFu]; }
+                else if (P == 2) { const uint32_t w2 = d[k] >> (8u * (uint32_t)p); bits += nbt[w2 & 0xFFu]; bits += nbt[(w2 >> 16) & 0xFFu]; }
+                else bits += nbt[(d[k] >> (8u * (uint32_t)p)) & 0xFFu];
+              }
+            }
+          }
+        }
         for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d);
         if (lane == 0) L.bits[wave] = bits + 1u;
         __syncthreads();
@@ -349,7 +370,8 @@ extern "C" int zn_debug_phase_read_enc(unsigned long long* out, int reset) {
 // The fused encoder takes chunks [0, nfull): full chunks of a geometry zn_encode_fused_ok() accepted.
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src) {
   const uint64_t n = g.chunk / g.P;
-  return (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
+  // quarters are read 256 vectors of 16 bytes at a time; streams are packed in tiles of 2048 symbols
+  return (g.chunk % 16384ull) == 0 && (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
 }
 
 void zn_launch_encode_fused_stats(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, float threshold, uint32_t* d_csize,

@@ -16,6 +16,14 @@
 
 typedef uint32_t __attribute__((aligned(1))) zn_u32u_w;
 
+#ifdef ZN_PHASE_TIMERS
+#define ZN_WT_DECL unsigned long long zn_wt0_ = __builtin_readcyclecounter()
+#define ZN_WT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&zn_phase_acc[i], t_ - zn_wt0_); zn_wt0_ = t_; } while (0)
+#else
+#define ZN_WT_DECL do { } while (0)
+#define ZN_WT(i) do { } while (0)
+#endif
+
 struct ZnWaveHdr { uint32_t v; uint32_t limit_bits; };   // v: lane i holds bytes [4i, 4i+4) of the block
 
 __device__ __forceinline__ uint32_t zn_rl(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
@@ -36,6 +44,7 @@ __device__ __forceinline__ uint32_t zn_wbits(const ZnWaveHdr& H, uint32_t bitpos
 __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint32_t lane, uint8_t* sh_w, uint8_t* sh_cell) {
   const uint32_t F0 = 8u, FEND = 8u * (1u + isz);     // the FSE block occupies bits [F0, FEND)
   if (isz < 2u) return -1;
+  ZN_WT_DECL;
   // ---- FSE_readNCount (uniform) ----
   int norm[13];
   for (int i = 0; i < 13; i++) norm[i] = 0;
@@ -68,6 +77,7 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
   }
   const uint32_t B0 = (bitpos + 7u) & ~7u;             // backward bit-stream starts at the next byte
   if (B0 >= FEND) return -1;
+  ZN_WT(10);   // readNCount
 
   // ---- FSE decode table, lane = cell ----
   const uint32_t size = 1u << tl, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
@@ -98,6 +108,7 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
     entry = (cs & 0xFFu) | (nb << 8) | ((((ns << nb) - size) & 0xFFFFu) << 16);
   }
 
+  ZN_WT(11);   // FSE decode table
   // ---- two interleaved states over the backward stream, all on wave-uniform (scalar) values ----
   // `win` holds the next unread bits top-aligned (MSB = bit pos-1 of the stream), zero below bit 0;
   // decoded weights are packed as nibbles into one VGPR (lane o>>3, nibble o&7) and stored once at the end.
@@ -136,6 +147,7 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
 #undef ZN_WREFILL
 #undef ZN_WTAKE
 #undef ZN_WPUT
+  ZN_WT(12);   // FSE state chain
   if (lane < 32u)                                      // unpack: lane l holds weights 8l … 8l+7
     for (uint32_t k = 0; k < 8u; k++) sh_w[8u * lane + k] = (uint8_t)((wv >> (4u * k)) & 0xFu);
   return o;
@@ -155,6 +167,7 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
                                                  uint32_t* sh_sym_start, uint8_t* sh_cell) {
   ZnWaveStats R; R.hs = -1; R.nsym = 0; R.tl = 0; R.lmin = 1;
   if (csize == 0) return R;
+  ZN_WT_DECL;
   // stage the first 256 bytes of the block across the lanes
   ZnWaveHdr H; H.v = 0; H.limit_bits = 0;
   {
@@ -180,6 +193,7 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
     osz = (uint32_t)r;
   }
   __builtin_amdgcn_wave_barrier();
+  ZN_WT(13);   // stage + weights (incl. 10-12)
 
   // ---- weight statistics (ballots) ----
   uint32_t cnt[13]; bool bad = false;
@@ -203,6 +217,7 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
   if (cnt[1] < 2u || (cnt[1] & 1u)) return R;
   const uint32_t nsym = osz + 1u;
   __builtin_amdgcn_wave_barrier();
+  ZN_WT(14);   // weight statistics
 
   // ---- canonical order: by weight ascending (longest codes first), symbol ascending inside ----
   uint32_t rs[14], ss[14]; uint32_t cells = 0, syms = 0, vmax = 1;
@@ -223,6 +238,7 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
     }
   }
   __builtin_amdgcn_wave_barrier();
+  ZN_WT(15);   // canonical order
   R.hs = (int)(isz + 1u); R.nsym = nsym; R.tl = tl; R.lmin = tl + 1u - vmax;
   return R;
 }
