@@ -162,6 +162,13 @@ def main():
         value = total_bytes * args.steps / elapsed / 1e9
         cvalue = total_bytes * csteps / c_elapsed / 1e9
         achieved = (n_bytes + c_payload) / (avg_kernel_ms * 1e-3) / 1e9
+        traffic = None     # HBM bytes per launch from the committed PMC pass (FETCH_SIZE x2 + WRITE_SIZE), scaled to this size
+        try:
+            with open(os.path.join(ROOT, "profiles", "decode_traffic_pmc.json")) as f:
+                t = json.load(f)
+            traffic = int(t["hbm_bytes_per_gib_launch"] * (n_bytes / (1 << 30)) / t["gib"])
+        except Exception:
+            pass
         line = {
             "metric": "bf16 decompress GB/s (uncompressed bytes / s; compress GB/s beside it)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -173,7 +180,7 @@ def main():
             "compress_GBps": round(cvalue, 2), "compress_ms_per_step": round(c_elapsed / csteps * 1e3, 3),
             "ratio": round((body.numel() + 32) / n_bytes, 5), "bit_exact_roundtrip": True,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": decode_kernels, "avg_launch_ms": round(avg_kernel_ms, 4),
                          "algorithmic_bytes": n_bytes + c_payload},
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},

@@ -56,10 +56,11 @@ def main():
     codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)
     raw.zn_debug_phase_read_enc(acc, 1)
     ch = acc[19] or 1
-    en = {0: "zero + histogram", 1: "reduce + decisions", 2: "parallel sort", 3: "serial tree/lengths/description", 4: "stream sizes + descriptor"}
-    tot = sum(acc[i] for i in range(5))
+    en = {0: "zero + histogram", 1: "reduce + decisions", 2: "parallel sort", 3: "serial rest (barrier wait etc.)", 4: "stream sizes + descriptor",
+          5: "  serial: tree + lengths + values", 6: "  serial: tree description (FSE)"}
+    tot = sum(acc[i] for i in range(7))
     print(f"encode stats kernel, {ch} chunks")
-    for i in range(5):
+    for i in range(7):
         print(f"  {en[i]:32s} {acc[i] / ch:10.0f} cyc/chunk  {100.0 * acc[i] / max(tot, 1):5.1f} %")
 
 

@@ -144,7 +144,9 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
         const uint32_t max_sv = L.maxsv[p];
         uint32_t huff_log = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
         huff_log = zn_huf_build_from_sorted(&L.S, L.nodes, max_sv, huff_log);
+        ZN_PT(5);   // (thread 0) tree + code lengths + values
         const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log);
+        ZN_PT(6);   // (thread 0) tree description
         uint32_t go = 0, cs = 0;
         if (h < 0) cs = 0xFFFFFFFFu;             // huff0 error → fails the threshold test → raw
         else if ((uint32_t)h + 12u >= n) cs = 0;
