@@ -22,8 +22,9 @@ NAMES = {0: "metadata", 1: "tree description (serial)", 2: "LUT fill", 3: "flush
 def main():
     gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     so = os.path.join(ROOT, "zipnn_amd", "libzipnn_hip_prof.so")
+    extra = [a for a in sys.argv[2:] if a.startswith("-D")]
     subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZN_PHASE_TIMERS",
-                    "-o", so] + sources(), check=True)
+                    "-o", so] + extra + sources(), check=True)
     lib = _capi.ZnLib(so)
     raw = ctypes.CDLL(so)
     n = int(gib * (1 << 30)) // (256 * 1024) * (256 * 1024)

@@ -48,6 +48,23 @@ def test_c_abi_bit_exact_vs_oracle(lib, case):
         assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
 
 
+EDGE = [("skew", 4 * C, 1, 1, 10, 128 * KB, 8), ("skew", 4 * C, 2, 0, 10, C, 0), ("burst", 4 * C, 1, 1, 10, 128 * KB, 8),
+        ("burst16", 8 * C, 2, 0, 10, C, 8), ("u11", 8 * C, 2, 1, 10, C, 8), ("burst16", 3 * 65536, 2, 0, 10, 65536, 3)]
+
+
+@pytest.mark.parametrize("case", EDGE, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
+def test_fused_kernels_on_hostile_distributions(lib, case):
+    """1-bit codes, tiles far denser than the stream average (staging buffer flushed in lane groups), 11-bit
+    codes: frame identical to the oracle's, decode through the fused kernel gives the input back."""
+    from test_kernels_simt import _gen2
+    kind, nb, P, rot, bm, chunk, want_fused = case
+    d = _gen2(kind, nb, 13)
+    want = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)
+    assert bytes(lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == want
+    assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
+    assert lib.last_fused_chunks() == want_fused
+
+
 @pytest.mark.parametrize("name", G.names())
 def test_golden_frames_through_zipnn_api(lib, name):
     from zipnn_amd import ZipNN

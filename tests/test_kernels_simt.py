@@ -74,6 +74,7 @@ def test_zipnn_api_reproduces_golden(use_simt, name):
 FUSED = [("bf16", 3 * C, 2, 1, 10, C, 3), ("bf16", 2 * C + 100, 2, 1, 10, C, 2), ("fp16", 2 * C, 2, 0, 10, C, 2),
          ("fp32", 2 * C, 4, 1, 220, C, 2), ("fp8", 2 * C, 1, 1, 10, C, 2), ("const", 2 * C, 2, 1, 10, C, 2),
          ("rand", 2 * C, 2, 1, 10, C, 2), ("u11", 2 * C, 2, 1, 10, C, 2), ("skew", 2 * C, 1, 1, 10, C, 2),
+         ("burst", 2 * C, 1, 1, 10, C, 2), ("burst16", 4 * C, 2, 0, 10, 2 * C, 2),
          ("bf16", 2 * 4096 * 3, 2, 1, 10, 4096, 6), ("bf16", 256 * 1024, 2, 1, 10, 256 * 1024, 1)]
 
 
@@ -84,6 +85,17 @@ def _gen2(kind, nb, seed):
     if kind == "skew":   # one symbol > 50 %: 1-bit codes, smallest sub-blocks
         r = np.random.default_rng(seed)
         return r.choice(np.array([7, 9, 200, 31, 32, 33], dtype=np.uint8), nb, p=[0.6, 0.2, 0.1, 0.05, 0.03, 0.02]).tobytes()
+    if kind == "burst16":  # the same in the even bytes, incompressible odd bytes (one Huffman plane + one raw plane)
+        r = np.random.default_rng(seed)
+        a = np.frombuffer(_gen2("burst", nb, seed), dtype=np.uint8).copy()
+        a[0::2] = a[:nb // 2]; a[1::2] = r.integers(0, 256, nb // 2, dtype=np.uint8)
+        return a.tobytes()
+    if kind == "burst":  # long runs of a 1-bit symbol between incompressible stretches: tiles far denser than
+        r = np.random.default_rng(seed)   # the stream average, so the staging buffer is flushed in lane groups
+        a = r.integers(1, 251, nb, dtype=np.uint8)
+        blk = np.arange(nb) // 4096
+        a[(blk % 5) < 3] = 0
+        return a.tobytes()
     return gen_bytes(kind, nb, seed)
 
 

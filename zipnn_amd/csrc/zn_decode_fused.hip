@@ -7,7 +7,7 @@
 //   1. threads < P parse the chunk's metadata; wave 0 turns the tree description into the
 //      canonical symbol order (zn_huf_wave.hpp: FSE chain on the scalar ALU, everything else
 //      with ballots); all 256 threads fill the single-symbol LUT and from it the MULTI-symbol
-//      LUT: one 64-bit entry per 11-bit window = up to 4 symbols, their start offsets, total.
+//      LUT: one 64-bit entry per 11-bit window = up to 5 symbols, their start offsets, total.
 //   2. each wave decodes its backward bit-stream IN PARALLEL ACROSS ITS 64 LANES.  huff0 has no
 //      gap array, so this uses Huffman self-synchronisation, format-transparently: the stream
 //      is cut into tiles of 64 sub-blocks of D dwords; lane k guesses a start 48 bits
@@ -37,12 +37,24 @@
 #include "zn_decode_common.hpp"
 
 #define ZN_F_THREADS 256
-#define ZN_F_RING_BYTES 7168u            // per wave; multiple of every row size (512 / 1024 symbols)
+#ifndef ZN_F_RING_BYTES
+#define ZN_F_RING_BYTES 4096u            // per wave; multiple of every row size (512 / 1024 symbols)
+#endif
+#ifndef ZN_F_WAVES_PER_SIMD
+#define ZN_F_WAVES_PER_SIMD 4            // workgroups per CU the LDS budget allows (drives the VGPR budget)
+#endif
 #define ZN_F_RING_DW (ZN_F_RING_BYTES / 4u)
-#define ZN_F_DMAX 8
+#ifndef ZN_F_DMAX
+#define ZN_F_DMAX 4                      // largest sub-block (dwords); sizes the stream-tile buffer and its prefetch registers
+#endif
+#ifndef ZN_F_DCONST
+#define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
+#endif
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
-#define ZN_F_DELTA0 48                   // initial sync run-in (bits); doubles after a mismatch
+#ifndef ZN_F_DELTA0
+#define ZN_F_DELTA0 24                   // initial sync run-in (bits); doubles after a mismatch
+#endif
 
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
@@ -59,16 +71,24 @@ struct ZnFusedLds {
   ZnWaveStats st;
 };
 
-// multi-symbol LUT entry: low dword = up to 4 symbols (unused bytes 0); high dword ("meta") =
-//   total length (bits 0-3) | start offset of symbol 1/2/3 (8-11 / 12-15 / 16-19; 15 = absent) | count (29-31)
-#define ZN_E_META(cnt, total, starts) ((total) | (starts) | ((cnt) << 29))
+// multi-symbol LUT entry = up to 5 symbols of one 11-bit window: low dword = symbols 0-3 (unused bytes 0);
+// high dword ("meta") = total length (bits 0-3) | start offset of symbol 4 / 1 / 2 / 3 (4-7 / 8-11 / 12-15 /
+// 16-19; 15 = absent) | symbol 4 (20-27) | count (29-31)
+#define ZN_E_META(cnt, total, starts, sym4) ((total) | (starts) | ((sym4) << 20) | ((cnt) << 29))
 
-// wave-wide exclusive prefix sum (all 64 lanes participate)
+// wave-wide exclusive prefix sum on the DPP network (6 v_add_u32 with a dpp modifier, no LDS traffic):
+// row_shr 1/2/4/8 scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals forward.
 __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
-  uint32_t x = v;
-  for (uint32_t d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= d) x += y; }
-  *total = __shfl(x, 63);
-  return x - v;
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  (void)lane;
+  return (uint32_t)x - v;
 }
 
 // One decode chain = the sub-block of the tile walked by one lane.  All 32-bit arithmetic: the unread
@@ -102,12 +122,12 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
   else { const uint32_t s1 = (meta >> 8) & 15u; nb = (meta >> 29) > 1u ? s1 : (meta & 15u); cnt = 1u; }   // length of the first symbol
   nb = act ? nb : 0u; cnt = act ? cnt : 0u;
   if (MODE == 2) {
-    uint32_t syms = lut32[idx];
+    uint32_t syms = lut32[idx], sym4 = MULTI ? ((meta >> 20) & 0xFFu) : 0u;
     if (!MULTI) syms &= 0xFFu;
-    syms = act ? syms : 0u;
+    syms = act ? syms : 0u; sym4 = act ? sym4 : 0u;
     const uint32_t sh8 = (c.wpos & 3u) << 3; uint32_t* d = stage + (c.wpos >> 2);
     atomicOr(d, syms << sh8);
-    atomicOr(d + 1, (syms >> 1) >> (31u - sh8));                    // bytes that spill into the next dword (0 when none)
+    atomicOr(d + 1, ((syms >> 1) >> (31u - sh8)) | (sym4 << sh8));  // bytes that spill into the next dword (0 when none)
     c.wpos += cnt;
   }
   const uint32_t t = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb);
@@ -115,7 +135,7 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
   if (MODE == 1) c.n += cnt;
 }
 
-// Decode every symbol that starts in (stop, pos]: groups of up to 4 symbols while the whole group provably
+// Decode every symbol that starts in (stop, pos]: groups of up to 5 symbols while the whole group provably
 // starts above `stop`, single symbols for the last < TL bits.  MODE 0: advance only (sync run-in);
 // 1: count symbols; 2: OR the symbols into the staging buffer (ds_or_b32: neighbouring lanes share dwords).
 // base_bit = absolute bit position of bit 0 of in[0].  All 64 lanes call this together.
@@ -140,7 +160,9 @@ __device__ __forceinline__ void zn_fused_run(const uint32_t* lut32, const uint32
 
 // Everything one wave does for its quarter of the chunk, with the Huffman plane index H known at
 // compile time (H = -1: no Huffman plane) so that register arrays are statically indexed.
-template <int P, int H>
+// DC: the sub-block size when it is known at compile time (the common value gets its own instance,
+// which lets the tile loads / staging loops unroll exactly), 0 = run-time Du.
+template <int P, int H, int DC>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
                                               const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
@@ -148,7 +170,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
-  constexpr int RB = (P == 2) ? 14 : 7;       // rows kept in registers at once
+  constexpr int RB = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (int)(ZN_F_RING_BYTES / 1024u);   // rows kept in registers at once
   ZN_PT_DECL;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
@@ -220,7 +242,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t b0 = (int32_t)(8u * (uint32_t)(sa & 3u));
   int32_t carry = b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last);
   int32_t hi_dw = (carry + 31) >> 5;
-  const int32_t Di = (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
+  const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
   int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
 
   // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D
@@ -229,14 +251,23 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t top_dw = hi_dw - 1;
   const bool top_guard = ((const uint8_t*)(gdw + hi_dw) > body_end);
   auto fetch_tile = [&](int32_t lo_dw_, int32_t hi_dw_) {
-    for (int i = 0; i <= ZN_F_DMAX; i++) {
-      const int32_t li = (int32_t)lane + 64 * i, gi = lo_dw_ - 1 + li;
-      uint32_t x = 0;
-      if (li <= TD && gi >= -1 && gi < hi_dw_) {
-        if (top_guard && gi == top_dw) { const uint8_t* pa = (const uint8_t*)(gdw + gi); for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b); }
-        else x = gdw[gi];
+    const uint32_t* p = gdw + (lo_dw_ - 1) + (int32_t)lane;
+    if (lo_dw_ >= 0 && !(top_guard && hi_dw_ - 1 == top_dw)) {
+      // common case: every dword of the tile exists in the buffer; lane 0 also fetches the tile's last dword
+      for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? p[64 * i] : 0u;
+      nx[ZN_F_DMAX] = 0u;
+      const uint32_t last = (lane == 0) ? p[TD] : 0u;
+      for (int i = 0; i <= ZN_F_DMAX; i++) if (i == Di) nx[i] = last;
+    } else {
+      for (int i = 0; i <= ZN_F_DMAX; i++) {
+        const int32_t li = (int32_t)lane + 64 * i, gi = lo_dw_ - 1 + li;
+        uint32_t x = 0;
+        if (li <= TD && gi >= -1 && gi < hi_dw_) {
+          if (top_guard && gi == top_dw) { const uint8_t* pa = (const uint8_t*)(gdw + gi); for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b); }
+          else x = gdw[gi];
+        }
+        nx[i] = x;
       }
-      nx[i] = x;
     }
   };
   fetch_tile(hi_dw - TD, hi_dw);
@@ -284,35 +315,51 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
     const uint32_t nact = (uint32_t)__popcll(__ballot(active));
     const int32_t e_last = __shfl(e, (int)(nact ? nact - 1u : 0u));
-    if (!chained || J + N > seg || J + N - JF > ZN_F_RING_BYTES) { ok = false; break; }
+    if (!chained || J + N > seg) { ok = false; break; }
+    carry = e_last; hi_dw = lo_dw;
 
-    // rows that will be complete after this tile: request their raw bytes now, use them after the write pass
-    int rows = (int)((J + N - JF) / UNIT);
-    const int first = rows < RB ? rows : RB;
-    fetch_rows(JF, first);
-    ZN_PT(8);   // scans / shuffles / issue loads
+    // write: second decode of the same sub-blocks, symbols OR-ed into the staging buffer.  The buffer is
+    // linear: its byte 0 holds symbol JF (the unflushed remainder of the previous tile sits at its start).
+    // The sub-block size is chosen from the stream's average code length, so a tile normally fits in one
+    // go; a tile that is denser than that is written in several lane groups with a flush after each.
+    uint32_t lane_lo = 0, wdone = 0;
+    do {
+      const uint32_t base = J - JF;                            // < UNIT
+      const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - 4u - base);   // monotone in the lane index
+      const uint32_t lane_hi = (uint32_t)__popcll(__ballot(fits));
+      if (lane_hi <= lane_lo) { ok = false; break; }           // cannot happen: one sub-block always fits
+      const uint32_t wend = (lane_hi >= 64u) ? N : (uint32_t)__shfl((int)o_k, (int)(lane_hi & 63u));
+      const uint32_t nsub = wend - wdone;
 
-    // write: second decode of the same sub-block, symbols OR-ed into the staging buffer; the buffer is
-    // linear: its byte 0 holds symbol JF (the unflushed remainder of the previous tile sits at its start)
-    A.pos = active ? s : stop; A.stop = stop; A.wpos = J - JF + o_k;
-    zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
-    __builtin_amdgcn_wave_barrier();
-    ZN_PT(9);   // write pass
-    J += N; carry = e_last; hi_dw = lo_dw;
+      // rows that will be complete after this group: request their raw bytes now, use them after the write pass
+      int rows = (int)((base + nsub) / UNIT);
+      const int first = rows < RB ? rows : RB;
+      fetch_rows(JF, first);
+      ZN_PT(8);   // scans / shuffles / issue loads
 
-    const int total_rows = rows;
-    uint32_t srow = 0;
-    emit_rows(JF, first, srow); JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
-    while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
-    if (total_rows > 0 && J > JF) {
-      // move the incomplete last row (< UNIT symbols) to the start of the staging buffer
-      const uint32_t i = ((uint32_t)total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
-      uint32_t t[EW];
-      for (int k = 0; k < EW; k++) { t[k] = ring[i + k]; ring[i + k] = 0; }
+      const bool mine = active && lane >= lane_lo && lane < lane_hi;
+      A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
+      zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
       __builtin_amdgcn_wave_barrier();
-      for (int k = 0; k < EW; k++) ring[((uint32_t)EPL * lane >> 2) + k] = t[k];
-      __builtin_amdgcn_wave_barrier();
-    }
+      ZN_PT(9);   // write pass
+      J += nsub; wdone = wend; lane_lo = lane_hi;
+
+      const int total_rows = rows;
+      uint32_t srow = 0;
+      emit_rows(JF, first, srow); JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
+      while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
+      if (total_rows > 0 && J > JF) {
+        // move the incomplete last row (< UNIT symbols) to the start of the staging buffer
+        const uint32_t i = ((uint32_t)total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
+        uint32_t t[EW];
+        for (int k = 0; k < EW; k++) { t[k] = ring[i + k]; ring[i + k] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < EW; k++) ring[((uint32_t)EPL * lane >> 2) + k] = t[k];
+        __builtin_amdgcn_wave_barrier();
+      }
+      ZN_PT_COUNT(20, 1);                    // write groups (== tiles when nothing overflowed)
+    } while (lane_lo < 64u);
+    if (!ok) break;
     ZN_PT(3);   // flush rows
   }
   ZN_PT_FLUSH();
@@ -320,7 +367,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 }
 
 template <int P>
-__global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
+__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
                                                                   uint8_t* __restrict__ dst, uint8_t* __restrict__ done,
                                                                   uint32_t* __restrict__ status) {
   constexpr int EPL = (P == 1) ? 16 : 8;
@@ -360,7 +407,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
   if (!elig || nhuf > 1u) { if (tid == 0) done[c] = 0; return; }
 
   const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
-  uint32_t TL = 0, D = 1;
+  uint32_t TL = 0;
   const uint8_t* stream = nullptr; uint32_t slen = 0;
 
   if (h >= 0) {
@@ -384,29 +431,27 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
     {
       // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
       const uint32_t mask = (1u << TL) - 1u;
-      uint32_t pos[8], cnt[8], syms[8], starts[8];
-      for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; starts[k] = 0xFFF00u; }
-      for (int step = 0; step < 4; step++) {
+      uint32_t pos[8], cnt[8], syms[8], starts[8], sym4[8];
+      for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; starts[k] = 0xFFFF0u; sym4[k] = 0; }
+      for (int step = 0; step < 5; step++) {
+        const int fs = (step == 4) ? 4 : 4 + 4 * step;          // bit position of this symbol's start-offset field
         for (int k = 0; k < 8; k++) {
           const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
           if (u <= mask && cnt[k] == (uint32_t)step) {
             const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
             if (pos[k] + len <= TL) {             // the window holds this code completely
-              if (step > 0) starts[k] = (starts[k] & ~(15u << (4 + 4 * step))) | (pos[k] << (4 + 4 * step));
-              syms[k] |= (e & 0xFFu) << (8 * step); pos[k] += len; cnt[k]++;
+              if (step > 0) starts[k] = (starts[k] & ~(15u << fs)) | (pos[k] << fs);
+              if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
+              pos[k] += len; cnt[k]++;
             }
           }
         }
       }
       for (int k = 0; k < 8; k++) {
         const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-        if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k]) << 32);
+        if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k], sym4[k]) << 32);
       }
     }
-    // shortest code length → how many symbols a tile can hold → sub-block size D (dwords)
-    D = ((ZN_F_RING_BYTES - UNIT - 8u) * st.lmin) / 2048u;
-    if (D > ZN_F_DMAX) D = ZN_F_DMAX;
-    if (D < 1u) D = 1u;
     // jump table → this wave's stream
     const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
     const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
@@ -424,14 +469,21 @@ __global__ __launch_bounds__(ZN_F_THREADS, 3) void zn_k_decode_fused(ZnGeom g, c
   for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
   uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
   uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
+  // sub-block size (dwords): a tile of 64 sub-blocks should decode to about one staging buffer minus the
+  // carried remainder, at this stream's average code length (8 slen / seg bits per symbol)
+  uint32_t Du = ((ZN_F_RING_BYTES - UNIT - 128u) * slen) / (256u * seg);
+  Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+  Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
   bool ok;
-#define ZN_WAVE_CASE(H_) ok = zn_fused_wave<P, H_>(g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, D, stream, slen)
+#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, Du, stream, slen
+#define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0>(ZN_WAVE_ARGS)
   if (h < 0) ZN_WAVE_CASE(-1);
   else if (h == 0) ZN_WAVE_CASE(0);
   else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
   else if (P >= 4 && h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
   else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
 #undef ZN_WAVE_CASE
+#undef ZN_WAVE_ARGS
   if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
   if (tid == 0) done[c] = 1;
   ZN_PT_COUNT(19, 1);                        // chunks
