@@ -12,7 +12,7 @@ echo "== smoke =="; timeout 300 python -c "import __graft_entry__ as g; g.smoke(
 echo "== bench =="; timeout 900 python bench.py --steps "$STEPS" --warmup 2 2>&1 | tail -5 | tee "$OUT/bench.log"
 echo "== rocprofv3 kernel stats =="
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/rocprof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$R/bench.py" --steps "$STEPS" --warmup 2 --no-cpu-baseline > "$OUT/rocprof.log" 2>&1
 tail -3 "$OUT/rocprof.log"
 find "$OUT/prof" -name '*kernel_stats*' | head -3 | while read f; do echo "--- $f"; head -12 "$f"; done
 # keep only the small summaries (the merged gpurun_out is capped at 64 MiB)

@@ -113,6 +113,29 @@ def test_fused_decode_path(simt_lib, case):
     assert "zn_k_decode_fused" in simt_lib.last_kernels()
 
 
+@pytest.mark.parametrize("group", [1, 2, 3, 4])
+def test_fused_decode_chunk_groups(simt_lib, group, monkeypatch):
+    """A workgroup decodes `group` consecutive chunks; groups may mix Huffman, raw-only, RLE and
+    two-Huffman-plane (generic path) chunks, and the last group may be short."""
+    monkeypatch.setenv("ZN_DECODE_GROUP", str(group))
+    ch = 16384
+    r = np.random.default_rng(5)
+    parts = []
+    for k in range(11):
+        kind = ["bf16", "rand", "const", "u11", "skewpair", "bf16"][k % 6]
+        if kind == "skewpair":   # both planes compressible → two Huffman planes → not fused
+            parts.append(r.choice(np.array([1, 2, 3, 4], dtype=np.uint8), ch, p=[0.7, 0.1, 0.1, 0.1]).tobytes())
+        else:
+            parts.append(_gen2(kind, ch, 20 + k))
+    d = b"".join(parts) + _gen2("bf16", 1000, 3)           # + a partial tail chunk
+    frame = O.compress_frame(HDR, d, 2, 0, 10, ch)
+    body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8)
+    out = torch.empty(len(d), dtype=torch.uint8)
+    simt_lib.decompress_dev(body.data_ptr(), body.numel(), 2, 0, 10, ch, len(d), out.data_ptr())
+    assert out.numpy().tobytes() == d
+    assert simt_lib.last_fused_chunks() == 9            # 11 full chunks minus the two "skewpair" ones
+
+
 def test_fused_detects_corrupt_stream(simt_lib):
     d = gen_bytes("bf16", 2 * C, 4)
     frame = bytearray(O.compress_frame(HDR, d, 2, 1, 10, C))

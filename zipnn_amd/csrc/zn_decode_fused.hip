@@ -33,6 +33,7 @@
 // HUF_decompress (:807), combine_buffers_dtype16/32 + revert_all_floats_* (data_manipulation_
 // dtype16.c:145-216, data_manipulation_dtype32.c:275-294,391-456).
 #include "zn_internal.hpp"
+#include <cstdlib>
 #include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
 
@@ -65,10 +66,11 @@ struct ZnFusedLds {
   uint64_t lut[1u << ZN_F_TLMAX];          // multi-symbol decode table
   uint32_t ring[4][ZN_F_RING_DW];          // per-wave output ring; ring[0] holds the 16-bit LUT while tables are built
   uint32_t in[4][ZN_F_IN_DW];              // per-wave staged stream tile
-  uint8_t w[256], symlist[256], cell[64];
-  uint32_t rank_start[14], sym_start[14];
-  ZnFusedPlane plane[4];
-  ZnWaveStats st;
+  uint8_t symlist[4][256];                 // per chunk of the group: symbols in canonical order
+  uint32_t rank_start[4][14], sym_start[4][14];
+  ZnFusedPlane plane[4][4];                // [chunk of the group][plane]
+  ZnWaveStats st[4];
+  uint32_t what[4];
 };
 
 // multi-symbol LUT entry = up to 5 symbols of one 11-bit window: low dword = symbols 0-3 (unused bytes 0);
@@ -366,127 +368,152 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   return ok && carry == b0 && J == seg && JF == seg;
 }
 
+// One workgroup decodes a GROUP of up to 4 consecutive chunks.  The tree description of a huff0 block is
+// a serial job for one wave (zn_huf_wave.hpp), so the four waves first parse the descriptions of the
+// group's four chunks side by side; after that the whole workgroup decodes the chunks one after the other
+// (LUT fill by 256 threads, then wave w = stream w).  ncg = chunks per group (1..4, chosen by the host so
+// that small inputs still spread over every CU).
 template <int P>
 __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
                                                                   uint8_t* __restrict__ dst, uint8_t* __restrict__ done,
-                                                                  uint32_t* __restrict__ status) {
+                                                                  uint32_t* __restrict__ status, uint32_t ncg) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c = blockIdx.x;
-  const uint32_t clen = zn_chunk_len(g, c);
+  const uint64_t c0 = (uint64_t)blockIdx.x * ncg;
+  const uint32_t nc = (g.K - c0 < (uint64_t)ncg) ? (uint32_t)(g.K - c0) : ncg;
   const uint32_t plen = (uint32_t)(g.chunk / P);
+  const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
   const uint8_t* body_end = body + body_len;
   ZN_PT_DECL;
 
-  // ---- metadata: one thread per plane ----
-  if (tid < (uint32_t)P) {
-    const ZnPcMeta m = zn_pc_meta(g, body, body_len, tid, c);
+  // ---- metadata: one thread per (chunk, plane) ----
+  if (tid < nc * (uint32_t)P) {
+    const uint32_t j = tid / (uint32_t)P, p = tid % (uint32_t)P;
+    const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c0 + j);
     ZnFusedPlane pl; pl.off = m.off; pl.csize = m.csize; pl.kind = 99u;   // 99 = not for this kernel
-    if (m.ok && m.type <= 1u && clen == g.chunk) {
+    if (m.ok && m.type <= 1u && zn_chunk_len(g, c0 + j) == g.chunk) {
       if (m.type == 0u) { if (m.csize >= plen) pl.kind = ZN_KIND_RAW; }
       else if (m.csize == plen) pl.kind = ZN_KIND_RAW;
       else if (m.csize == 1u) { pl.kind = ZN_KIND_RLE; pl.off = body[m.off]; }
       else if (m.csize > 1u && m.csize < plen) pl.kind = ZN_KIND_HUF;
     }
-    L.plane[tid] = pl;
+    L.plane[j][p] = pl;
   }
   __syncthreads();
   ZN_PT(0);   // metadata
 
-  int h = -1; uint32_t nhuf = 0; uint64_t h_off = 0; uint32_t h_csize = 0;
-  bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
-  ZnFusedPlane pl[P];
-  for (int p = 0; p < P; p++) {
-    pl[p] = L.plane[p];
-    if (pl[p].kind == 99u) elig = false;
-    if (pl[p].kind == ZN_KIND_HUF) { h = p; nhuf++; h_off = pl[p].off; h_csize = pl[p].csize; }
+  // ---- wave j: is chunk j ours, and if it has a Huffman plane, its tree description ----
+  if (wave < nc) {
+    int h = -1; uint32_t nhuf = 0;
+    bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
+    for (int p = 0; p < P; p++) {
+      const uint32_t kind = L.plane[wave][p].kind;
+      if (kind == 99u) elig = false;
+      if (kind == ZN_KIND_HUF) { h = p; nhuf++; }
+    }
+    if (nhuf > 1u) elig = false;
+    ZnWaveStats st; st.hs = 0; st.nsym = 0; st.tl = 0; st.lmin = 1;
+    if (elig && h >= 0) {
+      const uint32_t csize = L.plane[wave][h].csize;
+      uint8_t* scratch = (uint8_t*)&L.ring[wave][0];          // weights + FSE cells; the ring is idle until the decode
+      st = zn_wave_read_stats(body + L.plane[wave][h].off, csize, body_end, lane, scratch, L.symlist[wave], L.rank_start[wave],
+                              L.sym_start[wave], scratch + 512);
+      if (st.hs < 0 || st.tl > ZN_F_TLMAX || (uint32_t)st.hs >= csize || csize - (uint32_t)st.hs < 10u) elig = false;
+    }
+    if (lane == 0) { L.st[wave] = st; L.what[wave] = elig ? (uint32_t)(h + 2) : 0u; }   // 0: not ours, 1: no Huffman plane, 2+h
   }
-  if (!elig || nhuf > 1u) { if (tid == 0) done[c] = 0; return; }
+  __syncthreads();
+  ZN_PT(1);   // tree descriptions (one per wave)
 
-  const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
-  uint32_t TL = 0;
-  const uint8_t* stream = nullptr; uint32_t slen = 0;
+  for (uint32_t j = 0; j < nc; j++) {
+    const uint64_t c = c0 + j;
+    if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
+    const uint32_t what = L.what[j];
+    if (what == 0u) { if (tid == 0) done[c] = 0; continue; }
+    const int h = (int)what - 2;
+    ZnFusedPlane pl[P];
+    for (int p = 0; p < P; p++) pl[p] = L.plane[j][p];
 
-  if (h >= 0) {
-    // ---- decode table ----
-    const uint8_t* src = body + h_off; const uint32_t csize = h_csize;
-    if (wave == 0) {
-      const ZnWaveStats st = zn_wave_read_stats(src, csize, body_end, lane, L.w, L.symlist, L.rank_start, L.sym_start, L.cell);
-      if (lane == 0) L.st = st;
-    }
-    __syncthreads();
-    ZN_PT(1);   // tree description (wave 0)
-    const ZnWaveStats st = L.st;
-    const int hs = st.hs; TL = st.tl;
-    if (hs < 0 || TL > ZN_F_TLMAX || (uint32_t)hs >= csize || csize - (uint32_t)hs < 10u) { if (tid == 0) done[c] = 0; return; }
-    uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
-    {
-      const ZnRankTab rt = zn_load_ranks(L.rank_start, L.sym_start);
-      for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist, rt, L.rank_start, L.sym_start);
-    }
-    __syncthreads();
-    {
-      // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
-      const uint32_t mask = (1u << TL) - 1u;
-      uint32_t pos[8], cnt[8], syms[8], starts[8], sym4[8];
-      for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; starts[k] = 0xFFFF0u; sym4[k] = 0; }
-      for (int step = 0; step < 5; step++) {
-        const int fs = (step == 4) ? 4 : 4 + 4 * step;          // bit position of this symbol's start-offset field
-        for (int k = 0; k < 8; k++) {
-          const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-          if (u <= mask && cnt[k] == (uint32_t)step) {
-            const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
-            if (pos[k] + len <= TL) {             // the window holds this code completely
-              if (step > 0) starts[k] = (starts[k] & ~(15u << fs)) | (pos[k] << fs);
-              if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
-              pos[k] += len; cnt[k]++;
+    uint32_t TL = 0;
+    const uint8_t* stream = nullptr; uint32_t slen = 0;
+    bool bad = false;
+    if (h >= 0) {
+      // ---- decode tables ----
+      uint64_t h_off = 0; uint32_t csize = 0;
+      for (int p = 0; p < P; p++) if (p == h) { h_off = pl[p].off; csize = pl[p].csize; }
+      const uint8_t* src = body + h_off;
+      const ZnWaveStats st = L.st[j];
+      const int hs = st.hs; TL = st.tl;
+      uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
+      {
+        const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
+        for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
+      }
+      __syncthreads();
+      {
+        // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
+        const uint32_t mask = (1u << TL) - 1u;
+        uint32_t pos[8], cnt[8], syms[8], starts[8], sym4[8];
+        for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; starts[k] = 0xFFFF0u; sym4[k] = 0; }
+        for (int step = 0; step < 5; step++) {
+          const int fs = (step == 4) ? 4 : 4 + 4 * step;          // bit position of this symbol's start-offset field
+          for (int k = 0; k < 8; k++) {
+            const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+            if (u <= mask && cnt[k] == (uint32_t)step) {
+              const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
+              if (pos[k] + len <= TL) {             // the window holds this code completely
+                if (step > 0) starts[k] = (starts[k] & ~(15u << fs)) | (pos[k] << fs);
+                if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
+                pos[k] += len; cnt[k]++;
+              }
             }
           }
         }
+        for (int k = 0; k < 8; k++) {
+          const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+          if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k], sym4[k]) << 32);
+        }
       }
-      for (int k = 0; k < 8; k++) {
-        const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-        if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k], sym4[k]) << 32);
-      }
+      // jump table → this wave's stream
+      const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
+      const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+      uint32_t l4 = 0;
+      if (l1 + l2 + l3 + 6u > rem) bad = true; else l4 = rem - 6u - l1 - l2 - l3;
+      if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) bad = true;
+      const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
+      stream = js + so; slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
+      __syncthreads();                         // lut16 (aliasing ring[0]) is dead from here on
+      ZN_PT(2);   // LUT fill
     }
-    // jump table → this wave's stream
-    const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
-    const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
-    if (l1 + l2 + l3 + 6u > rem) { if (tid == 0) done[c] = 0; return; }
-    const uint32_t l4 = rem - 6u - l1 - l2 - l3;
-    if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) { if (tid == 0) done[c] = 0; return; }
-    const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
-    stream = js + so; slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
-    __syncthreads();                         // lut16 (aliasing ring[0]) is dead from here on
-    ZN_PT(2);   // LUT fill
-  }
+    if (bad) { if (tid == 0) done[c] = 0; continue; }   // malformed jump table: the generic path reports it
 
-  // ---- per-wave: decode the stream tile by tile, flush rows ----
-  const uint8_t* rawq[P];
-  for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
-  uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
-  uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
-  // sub-block size (dwords): a tile of 64 sub-blocks should decode to about one staging buffer minus the
-  // carried remainder, at this stream's average code length (8 slen / seg bits per symbol)
-  uint32_t Du = ((ZN_F_RING_BYTES - UNIT - 128u) * slen) / (256u * seg);
-  Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
-  Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
-  bool ok;
+    // ---- per-wave: decode the stream tile by tile, flush rows ----
+    const uint8_t* rawq[P];
+    for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
+    uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
+    uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
+    // sub-block size (dwords): a tile of 64 sub-blocks should decode to about one staging buffer minus the
+    // carried remainder, at this stream's average code length (8 slen / seg bits per symbol)
+    uint32_t Du = ((ZN_F_RING_BYTES - UNIT - 128u) * slen) / (256u * seg);
+    Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+    Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
+    bool ok;
 #define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, Du, stream, slen
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0>(ZN_WAVE_ARGS)
-  if (h < 0) ZN_WAVE_CASE(-1);
-  else if (h == 0) ZN_WAVE_CASE(0);
-  else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
-  else if (P >= 4 && h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
-  else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
+    if (h < 0) ok = zn_fused_wave<P, -1, 0>(ZN_WAVE_ARGS);
+    else if (h == 0) ZN_WAVE_CASE(0);
+    else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
+    else if (P >= 4 && h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
+    else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
 #undef ZN_WAVE_CASE
 #undef ZN_WAVE_ARGS
-  if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
-  if (tid == 0) done[c] = 1;
-  ZN_PT_COUNT(19, 1);                        // chunks
+    if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
+    if (tid == 0) done[c] = 1;
+    ZN_PT_COUNT(19, 1);                        // chunks
+  }
   ZN_PT_FLUSH();
 }
 
@@ -502,8 +529,20 @@ extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
 void zn_launch_decode_fused(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_dst, uint8_t* d_done,
                             uint32_t* d_status, hipStream_t stream) {
   if (g.K == 0) return;
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3((uint32_t)g.K), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3((uint32_t)g.K), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status);
-  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3((uint32_t)g.K), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status);
+  // chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
+  // outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots = cus * ZN_F_WAVES_PER_SIMD;
+  }
+  uint32_t ncg = (uint32_t)(g.K / (uint64_t)slots);
+  ncg = ncg > 4u ? 4u : (ncg < 1u ? 1u : ncg);
+  if (const char* e = getenv("ZN_DECODE_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4) ncg = (uint32_t)v; }   // test / tuning knob
+  const uint32_t grid = (uint32_t)((g.K + ncg - 1u) / ncg);
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(grid), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status, ncg);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(grid), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status, ncg);
+  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(grid), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status, ncg);
   zn_note_kernel("zn_k_decode_fused");
 }
