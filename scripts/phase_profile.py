@@ -57,13 +57,11 @@ def main():
     codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)
     raw.zn_debug_phase_read_enc(acc, 1)
     ch = acc[19] or 1
-    en = {0: "zero + histogram", 1: "reduce + decisions", 2: "parallel sort", 3: "serial rest (barrier wait etc.)", 4: "stream sizes + descriptor",
-          5: "  serial: tree + lengths + values", 6: "  serial: tree description (FSE)"}
-    tot = sum(acc[i] for i in range(7))
-    print(f"encode stats kernel, {ch} chunks")
-    for i in range(7):
-        print(f"  {en[i]:32s} {acc[i] / ch:10.0f} cyc/chunk  {100.0 * acc[i] / max(tot, 1):5.1f} %")
-
+    jobs = acc[18] or 1
+    print(f"encode: stats kernel (per chunk, {ch} chunks) / tables kernel (per table, {jobs} tables)")
+    for i, nm, d in ((0, "stats: zero + 4 quarter histograms", ch), (1, "stats: decisions + counts out", ch), (2, "tables: counts + rank sort", jobs),
+                     (5, "tables: tree + lengths + values", jobs), (6, "tables: tree description (FSE)", jobs), (3, "tables: sizes + descriptor", jobs)):
+        print(f"  {nm:36s} {acc[i] / d:10.0f} cyc")
 
 if __name__ == "__main__":
     main()

@@ -85,11 +85,11 @@ __device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P,
 static __device__ unsigned long long zn_phase_acc[64];   // one copy per translation unit; only the fused decode TU reads it back
 // cycles are accumulated in registers and published once (global atomics inside the phases would
 // be waited on by the kernel's own vmcnt waits and distort what they measure)
-struct ZnPhaseTimer { unsigned long long t0; unsigned int a[20]; };
-#define ZN_PT_DECL ZnPhaseTimer zn_pt_; do { for (int i_ = 0; i_ < 20; i_++) zn_pt_.a[i_] = 0; zn_pt_.t0 = __builtin_readcyclecounter(); } while (0)
+struct ZnPhaseTimer { unsigned long long t0; unsigned int a[24]; };
+#define ZN_PT_DECL ZnPhaseTimer zn_pt_; do { for (int i_ = 0; i_ < 24; i_++) zn_pt_.a[i_] = 0; zn_pt_.t0 = __builtin_readcyclecounter(); } while (0)
 #define ZN_PT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); zn_pt_.a[i] += (unsigned int)(t_ - zn_pt_.t0); zn_pt_.t0 = t_; } while (0)
 #define ZN_PT_COUNT(i, n) do { zn_pt_.a[i] += (unsigned int)(n); } while (0)
-#define ZN_PT_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 20; i_++) if (zn_pt_.a[i_]) atomicAdd(&zn_phase_acc[i_], (unsigned long long)zn_pt_.a[i_]); } while (0)
+#define ZN_PT_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 24; i_++) if (zn_pt_.a[i_]) atomicAdd(&zn_phase_acc[i_], (unsigned long long)zn_pt_.a[i_]); } while (0)
 #else
 #define ZN_PT_DECL do { } while (0)
 #define ZN_PT(i) do { } while (0)

@@ -44,7 +44,7 @@ template <int P> __device__ __forceinline__ uint32_t zn_rot_fwd(uint32_t u, uint
 }
 
 // ---------------------------------------------------------------------------
-// kernel A: statistics → type, stored size, code table
+// kernel A: histograms → RLE / raw decisions, per-quarter symbol counts of the planes that need a table
 // ---------------------------------------------------------------------------
 template <int P>
 struct ZnStatsLds {
@@ -53,13 +53,12 @@ struct ZnStatsLds {
   // (bin >> 1) * COLS + col.  A column sees ≤ 8192 symbols, so the packed halves cannot carry over.
   static constexpr int COLS = (P == 4) ? 16 : 32;
   uint32_t hist16[P][128 * COLS];
-  uint32_t count[P][256];                    // per-plane histograms
-  ZnTabScratch S;
-  ZnHNode nodes[513];
-  uint32_t kind[P], cs[P], largest[P], maxsv[P];
-  uint32_t go, hdr, bits[4];
+  uint32_t red_mx[P][4], red_hi[P][4];
 };
 
+// The chunk is histogrammed quarter by quarter (a quarter = the symbols of one huff0 stream); after each
+// quarter the columns are summed (thread = bin), which yields the per-stream symbol counts that turn code
+// lengths into stream sizes later without a second pass over the data.
 template <int P>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, const uint8_t* __restrict__ src, float threshold,
                                                                   uint32_t* __restrict__ csize_out, uint8_t* __restrict__ type_out,
@@ -74,16 +73,17 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
   for (uint32_t i = tid; i < (uint32_t)P * 128u * COLS; i += ZN_E_THREADS) (&L.hist16[0][0])[i] = 0;
   __syncthreads();
 
-  // ---- histograms: wave w reads quarter w of the chunk, 16 bytes per lane per step ----
-  {
-    const uint8_t* q = src + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
-    const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;
-    uint32_t* hbase = &L.hist16[0][lane & (COLS - 1u)];
-    // 4 independent 16-byte loads in flight per lane per step (nvec is a multiple of 256)
-    for (uint32_t v0 = lane; v0 < nvec; v0 += 256u) {
+  uint32_t tot[P], qc[P][4];                                  // thread = bin: count so far / per quarter
+  for (int p = 0; p < P; p++) tot[p] = 0;
+  const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;       // 16-byte vectors per quarter (a multiple of 256)
+  uint32_t* hbase = &L.hist16[0][lane & (COLS - 1u)];
+  for (int q = 0; q < 4; q++) {
+    const uint8_t* qs = src + c * g.chunk + (uint64_t)q * (g.chunk / 4u);
+    // 4 independent 16-byte loads in flight per thread per step
+    for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
       uint4 xs[4];
-      for (int u = 0; u < 4; u++) xs[u] = *(const uint4*)(q + 16ull * (v0 + 64u * (uint32_t)u));
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? *(const uint4*)(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
+      for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
         const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
         for (int k = 0; k < 4; k++)
           for (int t = 0; t < 4; t++) {
@@ -93,125 +93,137 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
           }
       }
     }
-  }
-  __syncthreads();
-  ZN_PT(0);   // zero + histogram
-  // ---- reduce the columns: per-plane histograms (thread = bin; column order staggered per lane so that
-  //      the 64 lanes of a wave read different banks) ----
-  for (int p = 0; p < P; p++) {
-    uint32_t tot = 0;
-    for (uint32_t r = 0; r < COLS; r++) tot += (L.hist16[p][(tid >> 1) * COLS + ((r + (tid >> 1)) & (COLS - 1u))] >> (16u * (tid & 1u))) & 0xFFFFu;
-    L.count[p][tid] = tot;
-  }
-  __syncthreads();
-  // ---- per plane: largest count, highest symbol, and the cheap exits of HUF_compress ----
-  if (wave < (uint32_t)P) {
-    const int p = (int)wave;
-    uint32_t mx = 0, hi = 0;
-    for (int k = 0; k < 4; k++) { const uint32_t b = lane + 64u * (uint32_t)k, v = L.count[p][b]; if (v > mx) mx = v; if (v && b > hi) hi = b; }
-    for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d), h2 = __shfl_xor(hi, d); if (m2 > mx) mx = m2; if (h2 > hi) hi = h2; }
-    if (lane == 0) {
-      uint32_t kind = 0, cs = 0;                 // kind: 0 = store raw (cs = HUF return value), 1 = RLE, 2 = build a table
-      if (mx == n) { kind = 1; cs = 1; }
-      else if (mx <= (n >> 7) + 4u) cs = 0;      // "probably not compressible"
-      else kind = 2;
-      L.kind[p] = kind; L.cs[p] = cs; L.largest[p] = mx; L.maxsv[p] = hi;
-    }
-  }
-  __syncthreads();
-  ZN_PT(1);   // reduce + plane decisions
-
-  const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
-  for (int p = 0; p < P; p++) {
-    const uint64_t pc = (uint64_t)p * g.K + c;
-    if (L.kind[p] == 2u) {                       // uniform across the workgroup
-      {
-        // HUF_sort, in parallel: a symbol's position is the number of symbols that sort before it
-        // (larger count, or equal count and smaller symbol value)
-        const uint32_t max_sv = L.maxsv[p];
-        for (uint32_t i = tid; i < 513u; i += ZN_E_THREADS) { ZnHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nb = 0; L.nodes[i] = z; }
-        __syncthreads();
-        if (tid <= max_sv) {
-          const uint32_t cme = L.count[p][tid]; uint32_t rank = 0;
-          for (uint32_t u = 0; u <= max_sv; u++) { const uint32_t cu = L.count[p][u]; rank += (cu > cme || (cu == cme && u < tid)) ? 1u : 0u; }
-          ZnHNode z; z.count = cme; z.parent = 0; z.byte = (uint8_t)tid; z.nb = 0;
-          L.nodes[1u + rank] = z;
-        }
-        __syncthreads();
-        ZN_PT(2);   // parallel sort
-      }
-      if (tid == 0) {
-        const uint32_t max_sv = L.maxsv[p];
-        uint32_t huff_log = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
-        huff_log = zn_huf_build_from_sorted(&L.S, L.nodes, max_sv, huff_log);
-        ZN_PT(5);   // (thread 0) tree + code lengths + values
-        const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log);
-        ZN_PT(6);   // (thread 0) tree description
-        uint32_t go = 0, cs = 0;
-        if (h < 0) cs = 0xFFFFFFFFu;             // huff0 error → fails the threshold test → raw
-        else if ((uint32_t)h + 12u >= n) cs = 0;
-        else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u) cs = 0;
-        else go = 1;
-        L.go = go; L.hdr = (uint32_t)(h > 0 ? h : 0); L.cs[p] = cs;
-        for (uint32_t s = max_sv + 1u; s < 256u; s++) { L.S.nbits[s] = 0; L.S.vals[s] = 0; }
-      }
-      __syncthreads();
-      ZN_PT(3);   // serial: tree, lengths, tree description
-      if (L.go) {
-        // stream k's size: wave k re-reads its quarter (cache-resident) and sums the code lengths
-        uint32_t bits = 0;
-        {
-          const uint8_t* q = src + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
-          const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;
-          const uint8_t* nbt = L.S.nbits;
-          for (uint32_t v0 = lane; v0 < nvec; v0 += 256u) {
-            uint4 xs[4];
-            for (int u = 0; u < 4; u++) xs[u] = *(const uint4*)(q + 16ull * (v0 + 64u * (uint32_t)u));
-            for (int u = 0; u < 4; u++) {
-              const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
-              // the bytes of plane p inside a dword: P = 1: all four; P = 2: bytes p, p+2; P = 4: byte p
-              for (int k = 0; k < 4; k++) {
-                if (P == 1) { for (int t = 0; t < 4; t++) bits += nbt[(d[k] >> (8 * t)) & 0xFFu]; }
-                else if (P == 2) { const uint32_t w2 = d[k] >> (8u * (uint32_t)p); bits += nbt[w2 & 0xFFu]; bits += nbt[(w2 >> 16) & 0xFFu]; }
-                else bits += nbt[(d[k] >> (8u * (uint32_t)p)) & 0xFFu];
-              }
-            }
-          }
-        }
-        for (int d = 32; d >= 1; d >>= 1) bits += __shfl_xor(bits, d);
-        if (lane == 0) L.bits[wave] = bits + 1u;
-        __syncthreads();
-        uint32_t sz[4]; uint32_t pos = L.hdr + 6u; bool fail = false;
-        for (int k = 0; k < 4; k++) {            // BIT_closeCStream's capacity rule, stream by stream
-          const uint64_t cap_rem = cap - pos;
-          if (cap_rem <= 8u || (uint64_t)(L.bits[k] >> 3) >= cap_rem - 8u) { fail = true; sz[k] = 0; break; }
-          sz[k] = (L.bits[k] + 7u) >> 3; pos += sz[k];
-        }
-        uint32_t cs = fail ? 0u : pos;
-        if (!fail && pos >= n - 1u) cs = 0;
-        const bool keep = cs != 0 && (double)cs < (double)n * (double)threshold;
-        if (keep) {
-          ZnEncDesc* D = descs + pc;
-          D->code[tid] = (uint32_t)L.S.vals[tid] | ((uint32_t)L.S.nbits[tid] << 16);
-          if (tid < 136u) D->hdr[tid] = (tid < L.hdr) ? L.S.hdr[tid] : 0;
-          if (tid == 0) { D->hdr_len = L.hdr; for (int k = 0; k < 4; k++) D->ssize[k] = sz[k]; }
-        }
-        if (tid == 0) L.cs[p] = cs;
-        __syncthreads();
-        ZN_PT(4);   // stream sizes + descriptor
-      }
-    }
-    if (tid == 0) {
-      // threshold rule of compression_worker (zipnn_core.c:371-385)
-      const uint32_t cs = L.cs[p];
-      const bool huf = cs != 0 && (double)cs < (double)n * (double)threshold;
-      type_out[pc] = huf ? 1 : 0;
-      csize_out[pc] = huf ? cs : n;
-      if (huf && cs == 1u) descs[pc].hdr[0] = (uint8_t)L.maxsv[p];   // RLE: the byte
+    __syncthreads();
+    // sum the columns (column order staggered per thread so that the lanes of a wave read different banks)
+    for (int p = 0; p < P; p++) {
+      uint32_t cum = 0;
+      for (uint32_t r = 0; r < COLS; r++) cum += (L.hist16[p][(tid >> 1) * COLS + ((r + (tid >> 1)) & (COLS - 1u))] >> (16u * (tid & 1u))) & 0xFFFFu;
+      qc[p][q] = cum - tot[p]; tot[p] = cum;
     }
     __syncthreads();
   }
+  ZN_PT(0);   // zero + histograms
+
+  // ---- per plane: largest count, highest symbol, and the cheap exits of HUF_compress ----
+  for (int p = 0; p < P; p++) {
+    uint32_t mx = tot[p], hi = tot[p] ? tid : 0u;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d), h2 = __shfl_xor(hi, d); if (m2 > mx) mx = m2; if (h2 > hi) hi = h2; }
+    if (lane == 0) { L.red_mx[p][wave] = mx; L.red_hi[p][wave] = hi; }
+  }
+  __syncthreads();
+  for (int p = 0; p < P; p++) {
+    uint32_t mx = 0, hi = 0;
+    for (int w = 0; w < 4; w++) { if (L.red_mx[p][w] > mx) mx = L.red_mx[p][w]; if (L.red_hi[p][w] > hi) hi = L.red_hi[p][w]; }
+    const uint64_t pc = (uint64_t)p * g.K + c;
+    if (mx == n) {                               // RLE: HUF_compress returns 1; threshold rule of compression_worker (zipnn_core.c:371-385)
+      const bool keep = 1.0 < (double)n * (double)threshold;
+      if (tid == 0) { type_out[pc] = keep ? 1 : 0; csize_out[pc] = keep ? 1u : n; if (keep) descs[pc].hdr[0] = (uint8_t)hi; }
+    } else if (mx <= (n >> 7) + 4u) {            // "probably not compressible": stored raw
+      if (tid == 0) { type_out[pc] = 0; csize_out[pc] = n; }
+    } else {                                     // needs a code table: zn_k_encode_tables takes over
+      ZnEncDesc* D = descs + pc;
+      for (int q = 0; q < 4; q++) D->qcount[q][tid] = (uint16_t)qc[p][q];
+      if (tid == 0) { type_out[pc] = 2; csize_out[pc] = n; }
+    }
+  }
+  ZN_PT(1);   // decisions + counts out
   ZN_PT_COUNT(19, 1);
+  ZN_PT_FLUSH();
+}
+
+// ---------------------------------------------------------------------------
+// kernel B: code tables.  One wave per (plane, chunk) that kernel A marked: HUF_sort (rank sort over the
+// lanes), then the serial part of HUF_compress on lane 0 — tree, length limiting, canonical values, tree
+// description (zn_huf_tables.hpp) — then stream sizes from the per-quarter counts, the capacity and
+// threshold rules, and the descriptor for the emit kernel.  Serial work per plane, but thousands of
+// planes: every SIMD holds several of these waves.
+// ---------------------------------------------------------------------------
+struct ZnTablesLds {
+  ZnTabScratch S;
+  ZnHNode nodes[513];
+  uint32_t count[256];
+  uint32_t go, hdr, cs;
+};
+
+__global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nfull, float threshold, uint32_t* __restrict__ csize_out,
+                                                         uint8_t* __restrict__ type_out, ZnEncDesc* __restrict__ descs) {
+  __shared__ ZnTablesLds L;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t p = (uint32_t)(blockIdx.x / nfull);
+  const uint64_t c = blockIdx.x % nfull, pc = (uint64_t)p * g.K + c;
+  if (type_out[pc] != 2) return;
+  const uint32_t n = (uint32_t)(g.chunk / g.P);
+  const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
+  ZnEncDesc* D = descs + pc;
+  ZN_PT_DECL;
+
+  // symbol counts (lane handles symbols lane + 64 k), highest symbol
+  uint32_t qv[4][4], cnt[4], max_sv = 0;
+  for (int k = 0; k < 4; k++) {
+    cnt[k] = 0;
+    for (int q = 0; q < 4; q++) { qv[q][k] = D->qcount[q][lane + 64u * (uint32_t)k]; cnt[k] += qv[q][k]; }
+    L.count[lane + 64u * (uint32_t)k] = cnt[k];
+    const uint64_t m = __ballot(cnt[k] != 0);
+    if (m) max_sv = 64u * (uint32_t)k + 63u - (uint32_t)__builtin_clzll(m);
+  }
+  for (uint32_t i = lane; i < 513u; i += 64u) { ZnHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nb = 0; L.nodes[i] = z; }
+  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
+  // HUF_sort: a symbol's position is the number of symbols that sort before it (larger count, or equal
+  // count and smaller symbol value)
+  for (int k = 0; k < 4; k++) {
+    const uint32_t sym = lane + 64u * (uint32_t)k;
+    uint32_t rank = 0;
+    for (uint32_t u = 0; u <= max_sv; u++) { const uint32_t cu = L.count[u]; rank += (cu > cnt[k] || (cu == cnt[k] && u < sym)) ? 1u : 0u; }
+    if (sym <= max_sv) { ZnHNode z; z.count = cnt[k]; z.parent = 0; z.byte = (uint8_t)sym; z.nb = 0; L.nodes[1u + rank] = z; }
+  }
+  __syncthreads();
+  ZN_PT(2);   // counts + sort
+  if (lane == 0) {
+    uint32_t huff_log = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
+    huff_log = zn_huf_build_from_sorted(&L.S, L.nodes, max_sv, huff_log);
+    ZN_PT(5);   // tree + code lengths + values
+    const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log);
+    ZN_PT(6);   // tree description
+    uint32_t go = 0, cs = 0;
+    if (h < 0) cs = 0xFFFFFFFFu;               // huff0 error → fails the threshold test → raw
+    else if ((uint32_t)h + 12u >= n) cs = 0;
+    else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u) cs = 0;
+    else go = 1;
+    L.go = go; L.hdr = (uint32_t)(h > 0 ? h : 0); L.cs = cs;
+    for (uint32_t s = max_sv + 1u; s < 256u; s++) { L.S.nbits[s] = 0; L.S.vals[s] = 0; }
+  }
+  __syncthreads();
+  uint32_t cs = L.cs;
+  uint32_t sz[4] = {0, 0, 0, 0};
+  if (L.go) {
+    // stream q's bit count = Σ_symbols count_q[s] · len[s], + 1 for the end mark
+    uint32_t bits[4];
+    for (int q = 0; q < 4; q++) {
+      uint32_t b = 0;
+      for (int k = 0; k < 4; k++) b += qv[q][k] * (uint32_t)L.S.nbits[lane + 64u * (uint32_t)k];
+      for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d);
+      bits[q] = b + 1u;
+    }
+    uint32_t pos = L.hdr + 6u; bool fail = false;
+    for (int k = 0; k < 4; k++) {              // BIT_closeCStream's capacity rule, stream by stream
+      const uint64_t cap_rem = cap - pos;
+      if (cap_rem <= 8u || (uint64_t)(bits[k] >> 3) >= cap_rem - 8u) { fail = true; sz[k] = 0; break; }
+      sz[k] = (bits[k] + 7u) >> 3; pos += sz[k];
+    }
+    cs = fail ? 0u : pos;
+    if (!fail && pos >= n - 1u) cs = 0;
+  }
+  // threshold rule of compression_worker (zipnn_core.c:371-385)
+  const bool keep = cs != 0 && (double)cs < (double)n * (double)threshold;
+  if (keep) {
+    for (int k = 0; k < 4; k++) { const uint32_t s = lane + 64u * (uint32_t)k; D->code[s] = (uint32_t)L.S.vals[s] | ((uint32_t)L.S.nbits[s] << 16); }
+    for (uint32_t i = lane; i < 136u; i += 64u) D->hdr[i] = (i < L.hdr) ? L.S.hdr[i] : 0;
+    if (lane == 0) { D->hdr_len = L.hdr; for (int k = 0; k < 4; k++) D->ssize[k] = sz[k]; }
+  }
+  if (lane == 0) { type_out[pc] = keep ? 1 : 0; csize_out[pc] = keep ? cs : n; }
+  ZN_PT(3);   // sizes + descriptor
+  ZN_PT_COUNT(18, 1);
   ZN_PT_FLUSH();
 }
 
@@ -383,6 +395,8 @@ void zn_launch_encode_fused_stats(const ZnGeom& g, uint64_t nfull, const uint8_t
   else if (g.P == 2) hipLaunchKernelGGL(zn_k_encode_stats<2>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
   else hipLaunchKernelGGL(zn_k_encode_stats<4>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
   zn_note_kernel("zn_k_encode_stats");
+  hipLaunchKernelGGL(zn_k_encode_tables, dim3((uint32_t)(nfull * g.P)), dim3(64), 0, stream, g, nfull, threshold, d_csize, d_type, d_descs);
+  zn_note_kernel("zn_k_encode_tables");
 }
 
 void zn_launch_encode_fused_emit(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, const uint32_t* d_csize, const uint8_t* d_type,

@@ -42,6 +42,7 @@ struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs f
   uint8_t  hdr[136];         // tree description (RLE: hdr[0] = the byte)
   uint32_t hdr_len;
   uint32_t ssize[4];         // stream sizes in bytes
+  uint16_t qcount[4][256];   // symbol counts of each quarter (stats kernel → tables kernel)
 };
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src);
 void zn_launch_encode_fused_stats(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, float threshold, uint32_t* d_csize,
