@@ -49,10 +49,13 @@ template <int P> __device__ __forceinline__ uint32_t zn_rot_fwd(uint32_t u, uint
 template <int P>
 struct ZnStatsLds {
   // workgroup-shared histograms, one column per lane of a half-wave so that a wave's 32 concurrent LDS
-  // atomics always hit 32 different banks: counter(bin, col) = 16-bit half (bin & 1) of dword
-  // (bin >> 1) * COLS + col.  A column sees ≤ 8192 symbols, so the packed halves cannot carry over.
+  // atomics always hit 32 different banks.  Two planes share a counter dword (plane 2i in the low, plane
+  // 2i+1 in the high 16 bits), so the increment of a byte is a constant (1 or 65536) and its address is
+  // just its value: counter(pair, bin, col) = pair[bin * COLS + col].  A column sees ≤ 8192 symbols of a
+  // plane, so the low half never carries into the high one.  (P = 1: one plane, plain 32-bit counters.)
   static constexpr int COLS = (P == 4) ? 16 : 32;
-  uint32_t hist16[P][128 * COLS];
+  static constexpr int PAIRS = (P + 1) / 2;
+  uint32_t hist[PAIRS][256 * COLS];
   uint32_t red_mx[P][4], red_hi[P][4];
 };
 
@@ -70,13 +73,14 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
   ZN_PT_DECL;
 
   constexpr uint32_t COLS = ZnStatsLds<P>::COLS;
-  for (uint32_t i = tid; i < (uint32_t)P * 128u * COLS; i += ZN_E_THREADS) (&L.hist16[0][0])[i] = 0;
+  constexpr uint32_t PAIRS = ZnStatsLds<P>::PAIRS;
+  for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
   __syncthreads();
 
   uint32_t tot[P], qc[P][4];                                  // thread = bin: count so far / per quarter
   for (int p = 0; p < P; p++) tot[p] = 0;
   const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;       // 16-byte vectors per quarter (a multiple of 256)
-  uint32_t* hbase = &L.hist16[0][lane & (COLS - 1u)];
+  uint32_t* hbase = &L.hist[0][lane & (COLS - 1u)];
   for (int q = 0; q < 4; q++) {
     const uint8_t* qs = src + c * g.chunk + (uint64_t)q * (g.chunk / 4u);
     // 4 independent 16-byte loads in flight per thread per step
@@ -88,8 +92,8 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
         for (int k = 0; k < 4; k++)
           for (int t = 0; t < 4; t++) {
             const uint32_t b = (d[k] >> (8 * t)) & 0xFFu;
-            const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;
-            atomicAdd(hbase + (uint32_t)p * (128u * COLS) + (b >> 1) * COLS, 1u << (16u * (b & 1u)));
+            const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;           // plane of byte t of a dword
+            atomicAdd(hbase + (uint32_t)(p >> 1) * (256u * COLS) + b * COLS, (p & 1) ? 65536u : 1u);
           }
       }
     }
@@ -97,7 +101,10 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
     // sum the columns (column order staggered per thread so that the lanes of a wave read different banks)
     for (int p = 0; p < P; p++) {
       uint32_t cum = 0;
-      for (uint32_t r = 0; r < COLS; r++) cum += (L.hist16[p][(tid >> 1) * COLS + ((r + (tid >> 1)) & (COLS - 1u))] >> (16u * (tid & 1u))) & 0xFFFFu;
+      for (uint32_t r = 0; r < COLS; r++) {
+        const uint32_t x = L.hist[p >> 1][tid * COLS + ((r + tid) & (COLS - 1u))];
+        cum += (P == 1) ? x : ((x >> (16u * (uint32_t)(p & 1))) & 0xFFFFu);
+      }
       qc[p][q] = cum - tot[p]; tot[p] = cum;
     }
     __syncthreads();
@@ -141,7 +148,6 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
 struct ZnTablesLds {
   ZnTabScratch S;
   ZnHNode nodes[513];
-  uint32_t count[256];
   uint32_t go, hdr, cs;
 };
 
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
   for (int k = 0; k < 4; k++) {
     cnt[k] = 0;
     for (int q = 0; q < 4; q++) { qv[q][k] = D->qcount[q][lane + 64u * (uint32_t)k]; cnt[k] += qv[q][k]; }
-    L.count[lane + 64u * (uint32_t)k] = cnt[k];
+    L.S.count[lane + 64u * (uint32_t)k] = cnt[k];   // (the weight coder reuses S.count later, after the sort)
     const uint64_t m = __ballot(cnt[k] != 0);
     if (m) max_sv = 64u * (uint32_t)k + 63u - (uint32_t)__builtin_clzll(m);
   }
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
   for (int k = 0; k < 4; k++) {
     const uint32_t sym = lane + 64u * (uint32_t)k;
     uint32_t rank = 0;
-    for (uint32_t u = 0; u <= max_sv; u++) { const uint32_t cu = L.count[u]; rank += (cu > cnt[k] || (cu == cnt[k] && u < sym)) ? 1u : 0u; }
+    for (uint32_t u = 0; u <= max_sv; u++) { const uint32_t cu = L.S.count[u]; rank += (cu > cnt[k] || (cu == cnt[k] && u < sym)) ? 1u : 0u; }
     if (sym <= max_sv) { ZnHNode z; z.count = cnt[k]; z.parent = 0; z.byte = (uint8_t)sym; z.nb = 0; L.nodes[1u + rank] = z; }
   }
   __syncthreads();
