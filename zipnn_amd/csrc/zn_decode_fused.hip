@@ -51,11 +51,15 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
-#define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
+#define ZN_F_IN_DW (66 * ZN_F_DMAX + 8)   // 64 D + 1 dwords of stream, one pad dword after every 32 (ZN_IN_IDX)
 #define ZN_F_TLMAX 11u
 #ifndef ZN_F_DELTA0
 #define ZN_F_DELTA0 24                   // initial sync run-in (bits); doubles after a mismatch
 #endif
+
+// stream-tile dword i lives at in[ZN_IN_IDX(i)]: lanes walk the tile with a stride of D dwords, and one pad
+// dword per 32 keeps a power-of-two stride from piling onto a few LDS banks
+#define ZN_IN_IDX(i) ((i) + ((i) >> 5))
 
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
@@ -63,7 +67,7 @@ typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 struct ZnFusedPlane { uint64_t off; uint32_t kind; uint32_t csize; };   // off: body offset (RAW/HUF) or byte value (RLE)
 
 struct ZnFusedLds {
-  uint64_t lut[1u << ZN_F_TLMAX];          // multi-symbol decode table
+  uint32_t lut[2u << ZN_F_TLMAX];          // multi-symbol decode table: [0, 2^TL) meta words, [2^TLMAX, …) symbol words
   uint32_t ring[4][ZN_F_RING_DW];          // per-wave output ring; ring[0] holds the 16-bit LUT while tables are built
   uint32_t in[4][ZN_F_IN_DW];              // per-wave staged stream tile
   uint8_t symlist[4][256];                 // per chunk of the group: symbols in canonical order
@@ -108,7 +112,7 @@ __device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, 
   int32_t q = c.pos - 1 - base_bit;
   q = q < 32 ? 32 : q;                                     // (only lanes that are done can be below; keeps in[j-1] in range)
   const int32_t j = q >> 5; const uint32_t sh = 31u - (uint32_t)(q & 31);
-  const uint32_t d1 = in[j], d0 = in[j - 1];
+  const uint32_t d1 = in[ZN_IN_IDX(j)], d0 = in[ZN_IN_IDX(j - 1)];
   const uint32_t t = __builtin_amdgcn_alignbit(d1, d0, 32u - sh);   // (d1:d0) << sh, upper dword — wrong for sh == 0 …
   c.whi = sh ? t : d1;                                              // … where alignbit's shift wraps to 0
   c.wlo = d0 << sh;
@@ -116,15 +120,15 @@ __device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, 
 // one step; `multi`: take the whole group of the LUT entry (else only its first symbol)
 template <int MODE, bool MULTI>
 __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32, uint32_t sh, int32_t bound, uint32_t* stage) {
-  const uint32_t idx = 2u * (c.whi >> sh);
-  const uint32_t meta = lut32[idx + 1u];
+  const uint32_t idx = c.whi >> sh;
+  const uint32_t meta = lut32[idx];
   const bool act = c.pos > bound;                                   // MULTI: bound = stop + TL - 1; single: bound = stop
   uint32_t nb, cnt;
   if (MULTI) { nb = meta & 15u; cnt = meta >> 29; }
   else { const uint32_t s1 = (meta >> 8) & 15u; nb = (meta >> 29) > 1u ? s1 : (meta & 15u); cnt = 1u; }   // length of the first symbol
   nb = act ? nb : 0u; cnt = act ? cnt : 0u;
   if (MODE == 2) {
-    uint32_t syms = lut32[idx], sym4 = MULTI ? ((meta >> 20) & 0xFFu) : 0u;
+    uint32_t syms = lut32[idx + (1u << ZN_F_TLMAX)], sym4 = MULTI ? ((meta >> 20) & 0xFFu) : 0u;
     if (!MULTI) syms &= 0xFFu;
     syms = act ? syms : 0u; sym4 = act ? sym4 : 0u;
     const uint32_t sh8 = (c.wpos & 3u) << 3; uint32_t* d = stage + (c.wpos >> 2);
@@ -279,7 +283,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
     __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i <= ZN_F_DMAX; i++) { const int32_t li = (int32_t)lane + 64 * i; if (li <= TD) in[li] = nx[i]; }
+    for (int i = 0; i <= ZN_F_DMAX; i++) { const int32_t li = (int32_t)lane + 64 * i; if (li <= TD) in[ZN_IN_IDX(li)] = nx[i]; }
     __builtin_amdgcn_wave_barrier();
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
     ZN_PT(4);   // stage tile
@@ -474,7 +478,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
         }
         for (int k = 0; k < 8; k++) {
           const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-          if (u <= mask) L.lut[u] = (uint64_t)syms[k] | ((uint64_t)ZN_E_META(cnt[k], pos[k], starts[k], sym4[k]) << 32);
+          if (u <= mask) { L.lut[u] = ZN_E_META(cnt[k], pos[k], starts[k], sym4[k]); L.lut[u + (1u << ZN_F_TLMAX)] = syms[k]; }
         }
       }
       // jump table → this wave's stream
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
-#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, (const uint32_t*)L.lut, ring, in, lane, seg, TL, Du, stream, slen
+#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0>(ZN_WAVE_ARGS)
     if (h < 0) ok = zn_fused_wave<P, -1, 0>(ZN_WAVE_ARGS);
     else if (h == 0) ZN_WAVE_CASE(0);
