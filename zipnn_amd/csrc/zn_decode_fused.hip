@@ -77,10 +77,10 @@ struct ZnFusedLds {
   uint32_t what[4];
 };
 
-// multi-symbol LUT entry = up to 5 symbols of one 11-bit window: low dword = symbols 0-3 (unused bytes 0);
-// high dword ("meta") = total length (bits 0-3) | start offset of symbol 4 / 1 / 2 / 3 (4-7 / 8-11 / 12-15 /
-// 16-19; 15 = absent) | symbol 4 (20-27) | count (29-31)
-#define ZN_E_META(cnt, total, starts, sym4) ((total) | (starts) | ((sym4) << 20) | ((cnt) << 29))
+// multi-symbol LUT entry = up to 5 symbols of one 11-bit window.  Symbol word: symbols 0-3 (unused bytes 0).
+// Meta word: E1..E5 in bits 0-19 (4 bits each), symbol 4 in 20-27, count in 29-31, where E_j = bits consumed
+// when exactly j symbols are taken = start offset of symbol j (j < count), the total length for j ≥ count.
+#define ZN_E_META(cnt, efields, sym4) ((efields) | ((sym4) << 20) | ((cnt) << 29))
 
 // wave-wide exclusive prefix sum on the DPP network (6 v_add_u32 with a dpp modifier, no LDS traffic):
 // row_shr 1/2/4/8 scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals forward.
@@ -117,33 +117,44 @@ __device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, 
   c.whi = sh ? t : d1;                                              // … where alignbit's shift wraps to 0
   c.wlo = d0 << sh;
 }
-// one step; `multi`: take the whole group of the LUT entry (else only its first symbol)
-template <int MODE, bool MULTI>
+// One step.  FULL: the whole group of the LUT entry, for lanes that are still more than a window above
+// their boundary (pos > bound = stop + TL - 1), nothing for the others.  !FULL: the boundary step — exactly
+// the symbols of the group that START above `stop` (symbol j starts E_j bits below pos).
+// A lane that takes nothing leaves its window undefined; every loop iteration begins with a refill.
+template <int MODE, bool FULL>
 __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32, uint32_t sh, int32_t bound, uint32_t* stage) {
   const uint32_t idx = c.whi >> sh;
-  const uint32_t meta = lut32[idx];
-  const bool act = c.pos > bound;                                   // MULTI: bound = stop + TL - 1; single: bound = stop
-  uint32_t nb, cnt;
-  if (MULTI) { nb = meta & 15u; cnt = meta >> 29; }
-  else { const uint32_t s1 = (meta >> 8) & 15u; nb = (meta >> 29) > 1u ? s1 : (meta & 15u); cnt = 1u; }   // length of the first symbol
-  nb = act ? nb : 0u; cnt = act ? cnt : 0u;
+  uint32_t meta = lut32[idx];
+  uint32_t nb, cnt, keep = 0xFFFFFFFFu;                             // keep: byte mask of the symbols 0-3 taken
+  if (FULL) {
+    const bool act = c.pos > bound;
+    meta = act ? meta : 0u; keep = act ? keep : 0u;
+    nb = (meta >> 16) & 15u; cnt = meta >> 29;
+  } else {
+    const int32_t rem = c.pos - c.stop;                             // ≤ 0: this lane is done
+    const uint32_t k = (uint32_t)(rem > 0) + (uint32_t)((int32_t)(meta & 15u) < rem) + (uint32_t)((int32_t)((meta >> 4) & 15u) < rem) +
+                       (uint32_t)((int32_t)((meta >> 8) & 15u) < rem) + (uint32_t)((int32_t)((meta >> 12) & 15u) < rem);
+    const uint32_t have = meta >> 29;
+    cnt = k < have ? k : have;
+    nb = k ? ((meta >> (4u * k - 4u)) & 15u) : 0u;
+    keep = cnt >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8u * cnt));
+    if (cnt < 5u) meta &= ~(0xFFu << 20);                           // symbol 4 only with all five
+  }
   if (MODE == 2) {
-    uint32_t syms = lut32[idx + (1u << ZN_F_TLMAX)], sym4 = MULTI ? ((meta >> 20) & 0xFFu) : 0u;
-    if (!MULTI) syms &= 0xFFu;
-    syms = act ? syms : 0u; sym4 = act ? sym4 : 0u;
+    const uint32_t syms = lut32[idx + (1u << ZN_F_TLMAX)] & keep, sym4 = (meta >> 20) & 0xFFu;
     const uint32_t sh8 = (c.wpos & 3u) << 3; uint32_t* d = stage + (c.wpos >> 2);
     atomicOr(d, syms << sh8);
     atomicOr(d + 1, ((syms >> 1) >> (31u - sh8)) | (sym4 << sh8));  // bytes that spill into the next dword (0 when none)
     c.wpos += cnt;
   }
-  const uint32_t t = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb);
-  c.whi = nb ? t : c.whi; c.wlo <<= nb; c.pos -= (int32_t)nb;
+  c.whi = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb);        // (nb == 0: garbage, see above)
+  c.wlo <<= nb; c.pos -= (int32_t)nb;
   if (MODE == 1) c.n += cnt;
 }
 
-// Decode every symbol that starts in (stop, pos]: groups of up to 5 symbols while the whole group provably
-// starts above `stop`, single symbols for the last < TL bits.  MODE 0: advance only (sync run-in);
-// 1: count symbols; 2: OR the symbols into the staging buffer (ds_or_b32: neighbouring lanes share dwords).
+// Decode every symbol that starts in (stop, pos]: whole groups of up to 5 symbols while the group provably
+// starts above `stop`, then the boundary step(s).  MODE 0: advance only (sync run-in); 1: count symbols;
+// 2: OR the symbols into the staging buffer (ds_or_b32: neighbouring lanes share dwords).
 // base_bit = absolute bit position of bit 0 of in[0].  All 64 lanes call this together.
 template <int MODE>
 __device__ __forceinline__ void zn_fused_run(const uint32_t* lut32, const uint32_t* in, int32_t base_bit, uint32_t TL,
@@ -156,10 +167,8 @@ __device__ __forceinline__ void zn_fused_run(const uint32_t* lut32, const uint32
     zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
     zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
   }
-  while (__any(c.pos > c.stop)) {
+  while (__any(c.pos > c.stop)) {            // one iteration unless > 5 symbols start in the last TL - 1 bits
     zn_chain_refill(c, in, base_bit);
-    zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
-    zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
     zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
   }
 }
@@ -460,16 +469,15 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
       {
         // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
         const uint32_t mask = (1u << TL) - 1u;
-        uint32_t pos[8], cnt[8], syms[8], starts[8], sym4[8];
-        for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; starts[k] = 0xFFFF0u; sym4[k] = 0; }
+        uint32_t pos[8], cnt[8], syms[8], ef[8], sym4[8];
+        for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; sym4[k] = 0; }
         for (int step = 0; step < 5; step++) {
-          const int fs = (step == 4) ? 4 : 4 + 4 * step;          // bit position of this symbol's start-offset field
           for (int k = 0; k < 8; k++) {
             const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
             if (u <= mask && cnt[k] == (uint32_t)step) {
               const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
               if (pos[k] + len <= TL) {             // the window holds this code completely
-                if (step > 0) starts[k] = (starts[k] & ~(15u << fs)) | (pos[k] << fs);
+                if (step > 0) ef[k] |= pos[k] << (4 * (step - 1));          // E_step = where this symbol starts
                 if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
                 pos[k] += len; cnt[k]++;
               }
@@ -478,7 +486,8 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
         }
         for (int k = 0; k < 8; k++) {
           const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-          if (u <= mask) { L.lut[u] = ZN_E_META(cnt[k], pos[k], starts[k], sym4[k]); L.lut[u + (1u << ZN_F_TLMAX)] = syms[k]; }
+          for (uint32_t j = 1; j <= 5u; j++) if (j >= cnt[k]) ef[k] |= pos[k] << (4u * (j - 1u));   // E_j = total for j ≥ count
+          if (u <= mask) { L.lut[u] = ZN_E_META(cnt[k], ef[k], sym4[k]); L.lut[u + (1u << ZN_F_TLMAX)] = syms[k]; }
         }
       }
       // jump table → this wave's stream
