@@ -10,14 +10,15 @@ from zipnn_amd.build import hipcc_path, sources
 
 VARIANTS = {
     "base": [],
-    "r4k_force4": ["-DZN_F_RING_BYTES=4096u", "-DZN_F_DMAX=4", "-DZN_F_DFORCE=4", "-DZN_F_DELTA0=24"],
-    "r4k_m4": ["-DZN_F_RING_BYTES=4096u", "-DZN_F_DMAX=4"],
-    "r3k_m4": ["-DZN_F_RING_BYTES=3072u", "-DZN_F_DMAX=4"],
-    "r3k5_m4": ["-DZN_F_RING_BYTES=3584u", "-DZN_F_DMAX=4"],
-    "r5k_m6_3wg": ["-DZN_F_RING_BYTES=5120u", "-DZN_F_DMAX=6", "-DZN_F_WAVES_PER_SIMD=3"],
-    "r4k_m4_d24": ["-DZN_F_RING_BYTES=4096u", "-DZN_F_DMAX=4", "-DZN_F_DELTA0=24"],
-    "r4k_m4_d40": ["-DZN_F_RING_BYTES=4096u", "-DZN_F_DMAX=4", "-DZN_F_DELTA0=40"],
+    "rb6": ["-DZN_F_RBMAX=6"],
+    "rb4": ["-DZN_F_RBMAX=4"],
+    "w3": ["-DZN_F_WAVES_PER_SIMD=3"],
+    "d16": ["-DZN_F_DELTA0=16"],
+    "d32": ["-DZN_F_DELTA0=32"],
+    "r3k": ["-DZN_F_RING_BYTES=3072u", "-DZN_F_DCONST=3"],
+    "r5k_w3": ["-DZN_F_RING_BYTES=5120u", "-DZN_F_DMAX=6", "-DZN_F_DCONST=6", "-DZN_F_WAVES_PER_SIMD=3"],
 }
+
 
 
 def main():

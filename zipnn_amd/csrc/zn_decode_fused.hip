@@ -185,7 +185,12 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
+#ifdef ZN_F_RBMAX
+  constexpr int RB0 = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (int)(ZN_F_RING_BYTES / 1024u);
+  constexpr int RB = RB0 > (ZN_F_RBMAX * 2 / P > 0 ? ZN_F_RBMAX * 2 / P : 1) ? (ZN_F_RBMAX * 2 / P > 0 ? ZN_F_RBMAX * 2 / P : 1) : RB0;
+#else
   constexpr int RB = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (int)(ZN_F_RING_BYTES / 1024u);   // rows kept in registers at once
+#endif
   ZN_PT_DECL;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows

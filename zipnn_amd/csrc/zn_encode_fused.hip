@@ -176,12 +176,30 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
   __builtin_amdgcn_wave_barrier();
   __syncthreads();
   // HUF_sort: a symbol's position is the number of symbols that sort before it (larger count, or equal
-  // count and smaller symbol value)
-  for (int k = 0; k < 4; k++) {
-    const uint32_t sym = lane + 64u * (uint32_t)k;
-    uint32_t rank = 0;
-    for (uint32_t u = 0; u <= max_sv; u++) { const uint32_t cu = L.S.count[u]; rank += (cu > cnt[k] || (cu == cnt[k] && u < sym)) ? 1u : 0u; }
-    if (sym <= max_sv) { ZnHNode z; z.count = cnt[k]; z.parent = 0; z.byte = (uint8_t)sym; z.nb = 0; L.nodes[1u + rank] = z; }
+  // count and smaller symbol value).  Only symbols that occur can sort before one that occurs, so the
+  // candidates are walked through the ballot masks (wave-uniform broadcast with v_readlane); symbols that
+  // do not occur follow in symbol order.
+  {
+    uint64_t nzm[4]; uint32_t nz_total = 0;
+    for (int k = 0; k < 4; k++) { nzm[k] = __ballot(cnt[k] != 0); nz_total += (uint32_t)__popcll(nzm[k]); }
+    uint32_t rank[4] = {0, 0, 0, 0};
+    for (int k2 = 0; k2 < 4; k2++) {
+      uint64_t m = nzm[k2];
+      while (m) {
+        const uint32_t j = (uint32_t)__builtin_ctzll(m); m &= m - 1;
+        const uint32_t cu = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k2], (int)j), u = j + 64u * (uint32_t)k2;
+        for (int k = 0; k < 4; k++) { const uint32_t sym = lane + 64u * (uint32_t)k; rank[k] += (cu > cnt[k] || (cu == cnt[k] && u < sym)) ? 1u : 0u; }
+      }
+    }
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+    uint32_t nz_before = 0;                      // symbols < sym that occur
+    for (int k = 0; k < 4; k++) {
+      const uint32_t sym = lane + 64u * (uint32_t)k;
+      const uint32_t nzb = nz_before + (uint32_t)__popcll(nzm[k] & lt);
+      const uint32_t r = cnt[k] ? rank[k] : nz_total + (sym - nzb);
+      if (sym <= max_sv) { ZnHNode z; z.count = cnt[k]; z.parent = 0; z.byte = (uint8_t)sym; z.nb = 0; L.nodes[1u + r] = z; }
+      nz_before += (uint32_t)__popcll(nzm[k]);
+    }
   }
   __syncthreads();
   ZN_PT(2);   // counts + sort
@@ -200,6 +218,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
     for (uint32_t s = max_sv + 1u; s < 256u; s++) { L.S.nbits[s] = 0; L.S.vals[s] = 0; }
   }
   __syncthreads();
+  ZN_PT(7);   // hand-over from the serial lane
   uint32_t cs = L.cs;
   uint32_t sz[4] = {0, 0, 0, 0};
   if (L.go) {
@@ -220,6 +239,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
     cs = fail ? 0u : pos;
     if (!fail && pos >= n - 1u) cs = 0;
   }
+  ZN_PT(8);   // stream sizes
   // threshold rule of compression_worker (zipnn_core.c:371-385)
   const bool keep = cs != 0 && (double)cs < (double)n * (double)threshold;
   if (keep) {

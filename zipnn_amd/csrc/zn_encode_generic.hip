@@ -151,39 +151,68 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t
 // ---------------------------------------------------------------------------
 // kernel 3: sizes -> wire-format metadata + payload offsets
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void zn_k_scan_sizes(ZnGeom g, const uint32_t* __restrict__ csize,
-                                                       const uint8_t* __restrict__ type, uint64_t* __restrict__ offs,
-                                                       uint64_t* __restrict__ total, uint8_t* __restrict__ body) {
-  __shared__ uint64_t part[256];
-  __shared__ uint64_t plane_base;
-  const uint32_t t = threadIdx.x;
+// Plane-major order is index order (i = p·K + c), so ONE exclusive scan over all P·K stored sizes gives
+// every payload offset; the wire format's per-plane inclusive cumSizes are that scan minus its value at
+// the plane's first index.  One workgroup of 1024 threads, each owning a contiguous run of entries
+// (loads issued 8 at a time); 64-bit wave scans + one LDS hop.
+#define ZN_SCAN_THREADS 1024
+__global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnGeom g, const uint32_t* __restrict__ csize,
+                                                                   const uint8_t* __restrict__ type, uint64_t* __restrict__ offs,
+                                                                   uint64_t* __restrict__ total, uint8_t* __restrict__ body) {
+  __shared__ uint64_t wsum[ZN_SCAN_THREADS / 64];
+  __shared__ uint64_t pbase[8];                // exclusive scan at the first index of each plane (P ≤ 4)
+  const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint64_t PK = (uint64_t)g.P * g.K;
+  if (g.K == 0) { if (t == 0) *total = 0; return; }       // empty input: empty body
   uint8_t* cum = body + PK;
-  if (t == 0) plane_base = 9u * PK;
-  __syncthreads();
-  const uint64_t per = (g.K + 255u) / 256u;
-  for (uint32_t p = 0; p < g.P; p++) {
-    const uint64_t lo = (uint64_t)t * per, hi = (lo + per < g.K) ? lo + per : g.K;
-    uint64_t s = 0;
-    for (uint64_t c = lo; c < hi; c++) s += csize[(uint64_t)p * g.K + c];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) { uint64_t run = 0; for (int i = 0; i < 256; i++) { const uint64_t v = part[i]; part[i] = run; run += v; } }
-    __syncthreads();
-    uint64_t run = part[t];
-    const uint64_t base = plane_base;
-    for (uint64_t c = lo; c < hi; c++) {
-      const uint64_t i = (uint64_t)p * g.K + c;
-      offs[i] = base + run;
-      run += csize[i];
-      zn_st64(cum + 8u * i, run);
-      body[i] = type[i];
-    }
-    __syncthreads();
-    if (t == 255) plane_base = base + run;   // thread 255 owns the last range (possibly empty: run = plane total)
-    __syncthreads();
+  const uint64_t per = (PK + ZN_SCAN_THREADS - 1u) / ZN_SCAN_THREADS;
+  const uint64_t lo = ((uint64_t)t * per < PK) ? (uint64_t)t * per : PK, hi = (lo + per < PK) ? lo + per : PK;
+
+  uint64_t s = 0;
+  for (uint64_t i = lo; i < hi; i += 8u) {
+    uint32_t v[8];
+    for (uint32_t u = 0; u < 8u; u++) v[u] = (i + u < hi) ? csize[i + u] : 0u;
+    for (uint32_t u = 0; u < 8u; u++) s += v[u];
   }
-  if (t == 0) *total = plane_base;
+  uint64_t incl = s;
+  for (uint32_t d = 1; d < 64u; d <<= 1) {
+    const uint32_t ylo = __shfl_up((uint32_t)incl, d), yhi = __shfl_up((uint32_t)(incl >> 32), d);
+    if (lane >= d) incl += ((uint64_t)yhi << 32) | ylo;
+  }
+  if (lane == 63u) wsum[wave] = incl;
+  __syncthreads();
+  uint64_t run = incl - s, grand = 0;
+  for (uint32_t w = 0; w < ZN_SCAN_THREADS / 64u; w++) { const uint64_t x = wsum[w]; if (w < wave) run += x; grand += x; }
+
+  // payload offsets; the thread that owns a plane's first index publishes the scan value there
+  const uint64_t base = 9u * PK;
+  {
+    uint64_t x = run, nb = (lo / g.K) * g.K; uint32_t p = (uint32_t)(lo / g.K);
+    if (nb < lo) { nb += g.K; p++; }           // next plane boundary at or after lo
+    for (uint64_t i = lo; i < hi; i += 8u) {
+      uint32_t v[8];
+      for (uint32_t u = 0; u < 8u; u++) v[u] = (i + u < hi) ? csize[i + u] : 0u;
+      for (uint32_t u = 0; u < 8u; u++) if (i + u < hi) {
+        if (i + u == nb) { pbase[p] = x; p++; nb += g.K; }
+        offs[i + u] = base + x; x += v[u];
+      }
+    }
+  }
+  __syncthreads();
+  {
+    uint64_t x = run; uint32_t p = (uint32_t)(lo / g.K); uint64_t nb = ((uint64_t)p + 1u) * g.K, pb = (lo < PK) ? pbase[p] : 0;
+    for (uint64_t i = lo; i < hi; i += 8u) {
+      uint32_t v[8]; uint8_t ty[8];
+      for (uint32_t u = 0; u < 8u; u++) { v[u] = (i + u < hi) ? csize[i + u] : 0u; ty[u] = (i + u < hi) ? type[i + u] : 0; }
+      for (uint32_t u = 0; u < 8u; u++) if (i + u < hi) {
+        if (i + u == nb) { p++; nb += g.K; pb = pbase[p]; }
+        x += v[u];
+        zn_st64(cum + 8u * (i + u), x - pb);
+        body[i + u] = ty[u];
+      }
+    }
+  }
+  if (t == 0) *total = base + grand;
 }
 
 // ---------------------------------------------------------------------------
@@ -216,7 +245,7 @@ void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t*
 
 void zn_launch_scan_sizes(const ZnGeom& g, const uint32_t* d_csize, const uint8_t* d_type, uint64_t* d_offs,
                           uint64_t* d_total, uint8_t* d_body, hipStream_t stream) {
-  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(1), dim3(256), 0, stream, g, d_csize, d_type, d_offs, d_total, d_body);
+  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(1), dim3(ZN_SCAN_THREADS), 0, stream, g, d_csize, d_type, d_offs, d_total, d_body);
   zn_note_kernel("zn_k_scan_sizes");
 }
 
