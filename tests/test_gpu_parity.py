@@ -34,6 +34,8 @@ def _cases():
     for nb in (1, 5, 1000, 128 * KB - 1, 128 * KB, 128 * KB + 1, 300001):
         cs += [("fp8", nb, 1, 1, 10, 128 * KB), ("rand", nb, 1, 1, 10, 128 * KB)]
     cs += [("bf16", 5 * 65536 + 10, 2, 1, 10, 65536), ("bf16", 9 * 16384 + 2, 2, 1, 10, 16384), ("bf16", 0, 2, 1, 10, C)]
+    # thousands of (plane, chunk) entries: multi-workgroup size scan, plane starts inside scan blocks
+    cs += [("bf16", 1024 * 1500 + 10, 2, 1, 10, 1024), ("fp32", 512 * 777 + 4, 4, 1, 220, 512), ("rand", 256 * 2049, 1, 1, 10, 256)]
     return cs
 
 
@@ -63,6 +65,24 @@ def test_fused_kernels_on_hostile_distributions(lib, case):
     assert bytes(lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == want
     assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
     assert lib.last_fused_chunks() == want_fused
+
+
+@pytest.mark.parametrize("group", [1, 2, 3, 4])
+def test_fused_decode_chunk_groups(lib, group, monkeypatch):
+    """Workgroups decode `group` consecutive chunks; mixed Huffman / raw / RLE / two-Huffman-plane chunks, short last group."""
+    from test_kernels_simt import _gen2
+    monkeypatch.setenv("ZN_DECODE_GROUP", str(group))
+    ch = 65536
+    r = np.random.default_rng(5)
+    parts = []
+    for k in range(23):
+        kind = ["bf16", "rand", "const", "u11", "pair", "bf16", "burst16"][k % 7]
+        parts.append(r.choice(np.array([1, 2, 3, 4], dtype=np.uint8), ch, p=[0.7, 0.1, 0.1, 0.1]).tobytes() if kind == "pair" else _gen2(kind, ch, 20 + k))
+    d = b"".join(parts) + _gen2("bf16", 1000, 3)
+    want = O.compress_frame(HDR, d, 2, 0, 10, ch, threads=4)
+    assert bytes(lib.compress(HDR, d, 2, 0, 10, ch, 0.95)) == want
+    assert bytes(lib.decompress(want[32:], 2, 0, 10, ch, len(d))) == d
+    assert lib.last_fused_chunks() == 23 - 3            # the three "pair" chunks have two Huffman planes
 
 
 @pytest.mark.parametrize("name", G.names())

@@ -31,6 +31,19 @@ def test_c_abi_matches_oracle(simt_lib, case):
         assert bytes(simt_lib.decompress(ref[32:], P, rot, bm, chunk, nb)) == d
 
 
+@pytest.mark.parametrize("case", [("bf16", 1024 * 1500 + 10, 2, 1, 10, 1024), ("fp32", 512 * 777 + 4, 4, 1, 220, 512),
+                                  ("rand", 256 * 2049, 1, 1, 10, 256), ("bf16", 512 * 513, 2, 1, 10, 512)],
+                         ids=lambda c: f"{c[0]}-K{c[1] // c[5]}-P{c[2]}")
+def test_many_chunks_multi_block_size_scan(simt_lib, case):
+    """Thousands of (plane, chunk) entries: the size scan runs over several workgroups and plane starts fall
+    inside blocks; the frame must still be the oracle's, byte for byte."""
+    kind, nb, P, rot, bm, chunk = case
+    d = gen_bytes(kind, nb, 9)
+    ref = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    assert bytes(simt_lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == ref
+    assert bytes(simt_lib.decompress(ref[32:], P, rot, bm, chunk, nb)) == d
+
+
 def test_input_buffer_is_not_modified(simt_lib):
     d = bytearray(gen_bytes("bf16", 5000, 1))
     keep = bytes(d)

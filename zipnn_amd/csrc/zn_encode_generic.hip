@@ -153,66 +153,75 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t
 // ---------------------------------------------------------------------------
 // Plane-major order is index order (i = p·K + c), so ONE exclusive scan over all P·K stored sizes gives
 // every payload offset; the wire format's per-plane inclusive cumSizes are that scan minus its value at
-// the plane's first index.  One workgroup of 1024 threads, each owning a contiguous run of entries
-// (loads issued 8 at a time); 64-bit wave scans + one LDS hop.
-#define ZN_SCAN_THREADS 1024
-__global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnGeom g, const uint32_t* __restrict__ csize,
+// the plane's first index.  Every workgroup owns a contiguous block of T entries (T a multiple of 256):
+// it first sums everything in front of its block by plane (coalesced reads of an L2-resident array — no
+// inter-workgroup dependency), then scans its block in tiles of 256 with coalesced loads and stores.
+#define ZN_SCAN_THREADS 256
+__device__ __forceinline__ uint64_t zn_wave_sum64(uint64_t v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+__global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnGeom g, uint64_t T, const uint32_t* __restrict__ csize,
                                                                    const uint8_t* __restrict__ type, uint64_t* __restrict__ offs,
                                                                    uint64_t* __restrict__ total, uint8_t* __restrict__ body) {
-  __shared__ uint64_t wsum[ZN_SCAN_THREADS / 64];
-  __shared__ uint64_t pbase[8];                // exclusive scan at the first index of each plane (P ≤ 4)
+  __shared__ uint64_t red[ZN_SCAN_THREADS / 64][4];
+  __shared__ uint32_t wtot[ZN_SCAN_THREADS / 64];
+  __shared__ uint64_t pb_s[4];                 // scan value at a plane start that lies inside this block
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-  const uint64_t PK = (uint64_t)g.P * g.K;
-  if (g.K == 0) { if (t == 0) *total = 0; return; }       // empty input: empty body
+  const uint64_t PK = (uint64_t)g.P * g.K, K = g.K;
+  if (K == 0) { if (t == 0 && blockIdx.x == 0) *total = 0; return; }       // empty input: empty body
   uint8_t* cum = body + PK;
-  const uint64_t per = (PK + ZN_SCAN_THREADS - 1u) / ZN_SCAN_THREADS;
-  const uint64_t lo = ((uint64_t)t * per < PK) ? (uint64_t)t * per : PK, hi = (lo + per < PK) ? lo + per : PK;
+  const uint64_t i0 = (uint64_t)blockIdx.x * T, i1 = (i0 + T < PK) ? i0 + T : PK;
+  if (i0 >= PK) return;
 
-  uint64_t s = 0;
-  for (uint64_t i = lo; i < hi; i += 8u) {
+  // everything in front of the block, by plane
+  uint64_t sp[4] = {0, 0, 0, 0};
+  for (uint64_t j = t; j < i0; j += 8u * ZN_SCAN_THREADS) {      // i0 is a multiple of 256; 8 loads in flight
     uint32_t v[8];
-    for (uint32_t u = 0; u < 8u; u++) v[u] = (i + u < hi) ? csize[i + u] : 0u;
-    for (uint32_t u = 0; u < 8u; u++) s += v[u];
+    for (uint32_t u = 0; u < 8u; u++) { const uint64_t i = j + (uint64_t)u * ZN_SCAN_THREADS; v[u] = (i < i0) ? csize[i] : 0u; }
+    for (uint32_t u = 0; u < 8u; u++) {
+      const uint64_t i = j + (uint64_t)u * ZN_SCAN_THREADS;
+      const uint32_t p = (uint32_t)(i >= K) + (uint32_t)(i >= 2u * K) + (uint32_t)(i >= 3u * K);
+      for (uint32_t q = 0; q < 4u; q++) sp[q] += (p == q) ? (uint64_t)v[u] : 0u;
+    }
   }
-  uint64_t incl = s;
-  for (uint32_t d = 1; d < 64u; d <<= 1) {
-    const uint32_t ylo = __shfl_up((uint32_t)incl, d), yhi = __shfl_up((uint32_t)(incl >> 32), d);
-    if (lane >= d) incl += ((uint64_t)yhi << 32) | ylo;
-  }
-  if (lane == 63u) wsum[wave] = incl;
+  for (uint32_t q = 0; q < 4u; q++) { const uint64_t r = zn_wave_sum64(sp[q]); if (lane == 0) red[wave][q] = r; }
   __syncthreads();
-  uint64_t run = incl - s, grand = 0;
-  for (uint32_t w = 0; w < ZN_SCAN_THREADS / 64u; w++) { const uint64_t x = wsum[w]; if (w < wave) run += x; grand += x; }
+  uint64_t known[4], run = 0;                  // known[p]: scan value at p·K when that lies at or before i0
+  for (uint32_t q = 0; q < 4u; q++) { known[q] = run; for (uint32_t w = 0; w < ZN_SCAN_THREADS / 64u; w++) run += red[w][q]; }
 
-  // payload offsets; the thread that owns a plane's first index publishes the scan value there
   const uint64_t base = 9u * PK;
-  {
-    uint64_t x = run, nb = (lo / g.K) * g.K; uint32_t p = (uint32_t)(lo / g.K);
-    if (nb < lo) { nb += g.K; p++; }           // next plane boundary at or after lo
-    for (uint64_t i = lo; i < hi; i += 8u) {
-      uint32_t v[8];
-      for (uint32_t u = 0; u < 8u; u++) v[u] = (i + u < hi) ? csize[i + u] : 0u;
-      for (uint32_t u = 0; u < 8u; u++) if (i + u < hi) {
-        if (i + u == nb) { pbase[p] = x; p++; nb += g.K; }
-        offs[i + u] = base + x; x += v[u];
-      }
+  const bool aligned = ((((uint64_t)cum) & 7u) == 0);
+  for (uint64_t b0 = i0; b0 < i1; b0 += ZN_SCAN_THREADS) {
+    const uint64_t i = b0 + t;
+    const bool in = i < i1;
+    const uint32_t v = in ? csize[i] : 0u;
+    const uint8_t ty = in ? type[i] : 0;
+    uint32_t incl = v;                          // a tile sums to < 2^32 (256 sizes ≤ 128 KiB)
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= d) incl += y; }
+    if (lane == 63u) wtot[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, ttot = 0;
+    for (uint32_t w = 0; w < ZN_SCAN_THREADS / 64u; w++) { const uint32_t x = wtot[w]; if (w < wave) woff += x; ttot += x; }
+    const uint64_t x = run + woff + (incl - v);  // exclusive scan at i
+    const uint32_t p = (uint32_t)(i >= K) + (uint32_t)(i >= 2u * K) + (uint32_t)(i >= 3u * K);
+    if (in && i == (uint64_t)p * K) pb_s[p] = x;
+    __syncthreads();
+    if (in) {
+      uint64_t pb = 0;
+      for (uint32_t q = 0; q < 4u; q++) if (q == p) pb = known[q];
+      if ((uint64_t)p * K >= i0) pb = pb_s[p];
+      offs[i] = base + x;
+      const uint64_t c = x + v - pb;
+      if (aligned) *(uint64_t*)(cum + 8u * i) = c; else zn_st64(cum + 8u * i, c);
+      body[i] = ty;
     }
+    run += ttot;
   }
-  __syncthreads();
-  {
-    uint64_t x = run; uint32_t p = (uint32_t)(lo / g.K); uint64_t nb = ((uint64_t)p + 1u) * g.K, pb = (lo < PK) ? pbase[p] : 0;
-    for (uint64_t i = lo; i < hi; i += 8u) {
-      uint32_t v[8]; uint8_t ty[8];
-      for (uint32_t u = 0; u < 8u; u++) { v[u] = (i + u < hi) ? csize[i + u] : 0u; ty[u] = (i + u < hi) ? type[i + u] : 0; }
-      for (uint32_t u = 0; u < 8u; u++) if (i + u < hi) {
-        if (i + u == nb) { p++; nb += g.K; pb = pbase[p]; }
-        x += v[u];
-        zn_st64(cum + 8u * (i + u), x - pb);
-        body[i + u] = ty[u];
-      }
-    }
-  }
-  if (t == 0) *total = base + grand;
+  if (i1 == PK && t == 0) *total = base + run;
 }
 
 // ---------------------------------------------------------------------------
@@ -245,7 +254,12 @@ void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t*
 
 void zn_launch_scan_sizes(const ZnGeom& g, const uint32_t* d_csize, const uint8_t* d_type, uint64_t* d_offs,
                           uint64_t* d_total, uint8_t* d_body, hipStream_t stream) {
-  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(1), dim3(ZN_SCAN_THREADS), 0, stream, g, d_csize, d_type, d_offs, d_total, d_body);
+  // ≤ 256 blocks of T entries each, T a multiple of the tile size
+  const uint64_t PK = (uint64_t)g.P * g.K;
+  uint64_t nb = (PK + 511u) / 512u; if (nb > 256u) nb = 256u; if (nb < 1u) nb = 1u;
+  uint64_t T = (PK + nb - 1u) / nb; T = (T + ZN_SCAN_THREADS - 1u) / ZN_SCAN_THREADS * ZN_SCAN_THREADS; if (T == 0) T = ZN_SCAN_THREADS;
+  const uint32_t grid = PK ? (uint32_t)((PK + T - 1u) / T) : 1u;
+  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(grid), dim3(ZN_SCAN_THREADS), 0, stream, g, T, d_csize, d_type, d_offs, d_total, d_body);
   zn_note_kernel("zn_k_scan_sizes");
 }
 
