@@ -10,6 +10,8 @@ from zipnn_amd.build import hipcc_path, sources
 
 VARIANTS = {
     "base": [],
+    "d20": ["-DZN_F_DELTA0=20"],
+    "d24": ["-DZN_F_DELTA0=24"],
     "rb6": ["-DZN_F_RBMAX=6"],
     "rb4": ["-DZN_F_RBMAX=4"],
     "w3": ["-DZN_F_WAVES_PER_SIMD=3"],

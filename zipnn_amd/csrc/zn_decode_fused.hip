@@ -51,15 +51,15 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
-#define ZN_F_IN_DW (66 * ZN_F_DMAX + 8)   // 64 D + 1 dwords of stream, one pad dword after every 32 (ZN_IN_IDX)
+#define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
 #ifndef ZN_F_DELTA0
-#define ZN_F_DELTA0 24                   // initial sync run-in (bits); doubles after a mismatch
+#define ZN_F_DELTA0 16                   // initial sync run-in (bits); doubles after a mismatch
 #endif
 
-// stream-tile dword i lives at in[ZN_IN_IDX(i)]: lanes walk the tile with a stride of D dwords, and one pad
-// dword per 32 keeps a power-of-two stride from piling onto a few LDS banks
-#define ZN_IN_IDX(i) ((i) + ((i) >> 5))
+// stream-tile dword i lives at in[ZN_IN_IDX(i)] (a padded layout against bank conflicts of the strided walk
+// was measured: no gain, the kernel is issue-bound — identity)
+#define ZN_IN_IDX(i) (i)
 
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
@@ -97,8 +97,8 @@ __device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane,
   return (uint32_t)x - v;
 }
 
-// One decode chain = the sub-block of the tile walked by one lane.  All 32-bit arithmetic: the unread
-// bits sit MSB-aligned in (whi:wlo) and are consumed with v_alignbit_b32.  The loops are BRANCH-FREE per
+// One decode chain = the sub-block of the tile walked by one lane.  The unread bits sit MSB-aligned in
+// (whi:wlo) and are consumed with one 64-bit shift per step.  The loops are BRANCH-FREE per
 // step (lanes that are done keep executing with a zero-length step) and unrolled as "refill + 3 steps":
 // a refill leaves ≥ 33 valid bits and a step consumes ≤ TL ≤ 11, so no per-step refill test is needed.
 struct ZnChain {
@@ -113,9 +113,8 @@ __device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, 
   q = q < 32 ? 32 : q;                                     // (only lanes that are done can be below; keeps in[j-1] in range)
   const int32_t j = q >> 5; const uint32_t sh = 31u - (uint32_t)(q & 31);
   const uint32_t d1 = in[ZN_IN_IDX(j)], d0 = in[ZN_IN_IDX(j - 1)];
-  const uint32_t t = __builtin_amdgcn_alignbit(d1, d0, 32u - sh);   // (d1:d0) << sh, upper dword — wrong for sh == 0 …
-  c.whi = sh ? t : d1;                                              // … where alignbit's shift wraps to 0
-  c.wlo = d0 << sh;
+  const uint64_t w = (((uint64_t)d1 << 32) | d0) << sh;    // one v_lshlrev_b64
+  c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w;
 }
 // One step.  FULL: the whole group of the LUT entry, for lanes that are still more than a window above
 // their boundary (pos > bound = stop + TL - 1), nothing for the others.  !FULL: the boundary step — exactly
@@ -147,8 +146,8 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
     atomicOr(d + 1, ((syms >> 1) >> (31u - sh8)) | (sym4 << sh8));  // bytes that spill into the next dword (0 when none)
     c.wpos += cnt;
   }
-  c.whi = __builtin_amdgcn_alignbit(c.whi, c.wlo, 32u - nb);        // (nb == 0: garbage, see above)
-  c.wlo <<= nb; c.pos -= (int32_t)nb;
+  { const uint64_t w = (((uint64_t)c.whi << 32) | c.wlo) << nb; c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w; }   // v_lshlrev_b64
+  c.pos -= (int32_t)nb;
   if (MODE == 1) c.n += cnt;
 }
 
@@ -309,7 +308,15 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it
     ZnChain A;
     A.pos = (lane > 0 && active) ? hi_k + delta : hi_k; A.stop = hi_k; A.n = 0; A.wpos = 0; A.whi = 0; A.wlo = 0;
-    zn_fused_run<0>(lut32, in, base_bit, TL, A, nullptr);
+    if (delta <= 21) {
+      // short run-in: one refill feeds one whole group (≤ TL bits) and the boundary step (≤ TL bits)
+      zn_chain_refill(A, in, base_bit);
+      zn_chain_step<0, true>(A, lut32, 32u - TL, A.stop + (int32_t)TL - 1, nullptr);
+      zn_chain_step<0, false>(A, lut32, 32u - TL, A.stop, nullptr);
+      while (__any(A.pos > A.stop)) { zn_chain_refill(A, in, base_bit); zn_chain_step<0, false>(A, lut32, 32u - TL, A.stop, nullptr); }
+    } else {
+      zn_fused_run<0>(lut32, in, base_bit, TL, A, nullptr);
+    }
     int32_t s = (lane > 0) ? A.pos : carry;
     ZN_PT(5);   // sync run-in
 
