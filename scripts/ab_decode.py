@@ -10,6 +10,9 @@ from zipnn_amd.build import hipcc_path, sources
 
 VARIANTS = {
     "base": [],
+    "ent_stats": ["-DZN_E_NTLOAD_STATS"],
+    "ent_emit": ["-DZN_E_NTLOAD_EMIT"],
+    "ent_both": ["-DZN_E_NTLOAD_STATS", "-DZN_E_NTLOAD_EMIT"],
     "d20": ["-DZN_F_DELTA0=20"],
     "d24": ["-DZN_F_DELTA0=24"],
     "rb6": ["-DZN_F_RBMAX=6"],
@@ -50,7 +53,16 @@ def main():
             for _ in range(10):
                 codec.decompress_device(lib, body, 2, 1, 10, 256 * 1024, n, out=out, check=False)
             torch.cuda.synchronize(); best = min(best, (time.perf_counter() - t0) / 10)
-        print(f"{name:14s} ok={ok} fused={lib.last_fused_chunks()} decode {best * 1e3:.3f} ms  {n / best / 1e9:.0f} GB/s", flush=True)
+        fused = lib.last_fused_chunks()
+        cb = codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)
+        ok = ok and torch.equal(cb, body)
+        bestc = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(5):
+                codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)
+            torch.cuda.synchronize(); bestc = min(bestc, (time.perf_counter() - t0) / 5)
+        print(f"{name:14s} ok={ok} fused={fused} decode {best * 1e3:.3f} ms  {n / best / 1e9:.0f} GB/s   compress {bestc * 1e3:.3f} ms  {n / bestc / 1e9:.0f} GB/s", flush=True)
         lib.release_workspace()
         os.remove(so)
 

@@ -13,6 +13,7 @@
 // every live lane of the wave (the kernels are written that way); a lane that never
 // arrives is reported as a deadlock instead of hanging.
 #pragma once
+#define ZN_SIMT_EMULATOR 1
 
 #include <stdint.h>
 #include <stddef.h>

@@ -90,7 +90,14 @@ struct ZnPhaseTimer { unsigned long long t0; unsigned int a[24]; };
 #define ZN_PT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); zn_pt_.a[i] += (unsigned int)(t_ - zn_pt_.t0); zn_pt_.t0 = t_; } while (0)
 #define ZN_PT_COUNT(i, n) do { zn_pt_.a[i] += (unsigned int)(n); } while (0)
 #define ZN_PT_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 24; i_++) if (zn_pt_.a[i_]) atomicAdd(&zn_phase_acc[i_], (unsigned long long)zn_pt_.a[i_]); } while (0)
+// a callee that shares its caller's timer: extra parameter / argument / local reference
+#define ZN_PT_PARAM , ZnPhaseTimer* zn_ptp_
+#define ZN_PT_PASS , &zn_pt_
+#define ZN_PT_SHARED ZnPhaseTimer& zn_pt_ = *zn_ptp_
 #else
+#define ZN_PT_PARAM
+#define ZN_PT_PASS
+#define ZN_PT_SHARED do { } while (0)
 #define ZN_PT_DECL do { } while (0)
 #define ZN_PT(i) do { } while (0)
 #define ZN_PT_COUNT(i, n) do { } while (0)

@@ -61,6 +61,14 @@
 // was measured: no gain, the kernel is issue-bound — identity)
 #define ZN_IN_IDX(i) (i)
 
+// 16-byte output store, non-temporal: the output is written once and never read back by this kernel
+#if !defined(ZN_SIMT_EMULATOR)
+typedef uint32_t zn_v4u __attribute__((ext_vector_type(4)));
+#define ZN_ST128(p, a, b, c, d) __builtin_nontemporal_store((zn_v4u){(a), (b), (c), (d)}, (zn_v4u*)(p))
+#else
+#define ZN_ST128(p, a, b, c, d) (*(uint4*)(p) = make_uint4((a), (b), (c), (d)))
+#endif
+
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 
@@ -180,7 +188,7 @@ template <int P, int H, int DC>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
                                               const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
-                                              uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen) {
+                                              uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen ZN_PT_PARAM) {
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
@@ -190,7 +198,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #else
   constexpr int RB = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (int)(ZN_F_RING_BYTES / 1024u);   // rows kept in registers at once
 #endif
-  ZN_PT_DECL;
+  ZN_PT_SHARED;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
   uint32_t pre[RB][P][EW];
@@ -216,13 +224,13 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
       uint8_t* o = outq + (uint64_t)si * P;
       if (P == 1) {
-        *(uint4*)o = make_uint4(pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
+        ZN_ST128(o, pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
       } else if (P == 2) {
         uint32_t x[4];
         x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
         x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
         if (g.rot) for (int k = 0; k < 4; k++) x[k] = zn_rot_inv16(x[k]);
-        *(uint4*)o = make_uint4(x[0], x[1], x[2], x[3]);
+        ZN_ST128(o, x[0], x[1], x[2], x[3]);
       } else {
         for (int half = 0; half < 2; half++) {
           const int k = half % EW;
@@ -232,7 +240,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
           x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
           if (g.rot) for (int q = 0; q < 4; q++) x[q] = zn_rot_inv32(x[q]);
-          *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);
+          ZN_ST128(o + 16 * half, x[0], x[1], x[2], x[3]);
         }
       }
     }
@@ -246,7 +254,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       fetch_rows(JF, nr); emit_rows(JF, nr, 0); JF += (uint32_t)nr * UNIT;
     }
     ZN_PT(3);
-    ZN_PT_FLUSH();
     return true;
   }
 
@@ -256,9 +263,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   uint32_t J = 0;                             // symbols decoded into the ring so far
   const uint8_t last = stream[slen - 1];
   if (last == 0) return false;
-  const uint64_t sa = (uint64_t)stream;
-  const uint32_t* gdw = (const uint32_t*)(sa & ~(uint64_t)3);
-  const int32_t b0 = (int32_t)(8u * (uint32_t)(sa & 3u));
+  // (pointer arithmetic, not an integer round trip: keeps the loads in the global address space — flat loads
+  //  would tie every later LDS wait to the HBM latency of the tile prefetch)
+  const uint32_t mis = (uint32_t)((uint64_t)stream & 3u);
+  const uint32_t* gdw = (const uint32_t*)(stream - mis);
+  const int32_t b0 = (int32_t)(8u * mis);
   int32_t carry = b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last);
   int32_t hi_dw = (carry + 31) >> 5;
   const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
@@ -389,7 +398,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     if (!ok) break;
     ZN_PT(3);   // flush rows
   }
-  ZN_PT_FLUSH();
   return ok && carry == b0 && J == seg && JF == seg;
 }
 
@@ -456,6 +464,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   for (uint32_t j = 0; j < nc; j++) {
     const uint64_t c = c0 + j;
     if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
+    ZN_PT(21);  // wait for the slowest wave of the previous chunk
     const uint32_t what = L.what[j];
     if (what == 0u) { if (tid == 0) done[c] = 0; continue; }
     const int h = (int)what - 2;
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
-#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen
+#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen ZN_PT_PASS
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0>(ZN_WAVE_ARGS)
     if (h < 0) ok = zn_fused_wave<P, -1, 0>(ZN_WAVE_ARGS);
     else if (h == 0) ZN_WAVE_CASE(0);

@@ -33,6 +33,17 @@
 #define ZN_E_TILE (64 * ZN_E_SPL)          // symbols per tile
 #define ZN_E_BUF_DW 768                    // tile bit buffer: 2048 symbols × ≤12 bits = 768 dwords, + carry
 
+// 16-byte input loads.  Measured (4 GiB bf16): non-temporal loads help the histogram pass (one pure streaming
+// read, -3 % on compress) and hurt the emit pass (its four strided loads per tile share cache lines).
+#if !defined(ZN_SIMT_EMULATOR)
+typedef uint32_t zn_ev4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 zn_ldnt128(const void* p) { const zn_ev4u v = __builtin_nontemporal_load((const zn_ev4u*)p); return make_uint4(v.x, v.y, v.z, v.w); }
+#else
+__device__ __forceinline__ uint4 zn_ldnt128(const void* p) { return *(const uint4*)p; }
+#endif
+#define ZN_LD_STATS(p) zn_ldnt128(p)
+#define ZN_LD_EMIT(p) (*(const uint4*)(p))
+
 typedef uint64_t __attribute__((aligned(1))) zn_eu64u;
 typedef uint32_t __attribute__((aligned(1))) zn_eu32u;
 struct __attribute__((aligned(1))) zn_eu128u { uint32_t x, y, z, w; };
@@ -86,7 +97,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
     // 4 independent 16-byte loads in flight per thread per step
     for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
       uint4 xs[4];
-      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? *(const uint4*)(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ZN_LD_STATS(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
       for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
         const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
         for (int k = 0; k < 4; k++)
@@ -287,7 +298,7 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
     // this lane's 32 consecutive elements = 32·P source bytes
     uint32_t d[8 * P];
     const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + ZN_E_SPL * lane);
-    for (int k = 0; k < 2 * P; k++) { const uint4 x = *(const uint4*)(a + 16 * k); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w; }
+    for (int k = 0; k < 2 * P; k++) { const uint4 x = ZN_LD_EMIT(a + 16 * k); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w; }
     for (int k = 0; k < 8 * P; k++) d[k] = zn_rot_fwd<P>(d[k], g.rot);
     // raw planes: 32 bytes per lane, contiguous across the wave
     if (do_raw) {

@@ -16,7 +16,7 @@
 
 typedef uint32_t __attribute__((aligned(1))) zn_u32u_w;
 
-#ifdef ZN_PHASE_TIMERS
+#ifdef ZN_PHASE_TIMERS_SUB      // (global atomics per sub-phase: distorts the enclosing phase, so separate switch)
 #define ZN_WT_DECL unsigned long long zn_wt0_ = __builtin_readcyclecounter()
 #define ZN_WT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) atomicAdd(&zn_phase_acc[i], t_ - zn_wt0_); zn_wt0_ = t_; } while (0)
 #else
