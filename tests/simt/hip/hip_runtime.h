@@ -259,6 +259,12 @@ template <typename T> static inline T zn_simt_update_dpp(T old, T src, int ctrl,
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) zn_simt_update_dpp((old), (src), (ctrl), (rm), (bm), (bc))
 
 // ---- host API subset ----
+enum { hipEventDisableTiming = 2 };
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = (hipEvent_t)(uintptr_t)1; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };

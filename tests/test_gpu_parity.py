@@ -67,6 +67,27 @@ def test_fused_kernels_on_hostile_distributions(lib, case):
     assert lib.last_fused_chunks() == want_fused
 
 
+def test_two_streams_share_the_device_workspace_safely(lib):
+    """Un-checked (asynchronous) decompress calls on two streams interleave; the library orders their use of
+    its per-device workspace with an event, so both results are right."""
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    da = torch.frombuffer(bytearray(gen_bytes("bf16", 24 * C + 1000, 1)), dtype=torch.uint8).to(dev)
+    db = torch.frombuffer(bytearray(gen_bytes("fp32", 16 * C + 4, 2)), dtype=torch.uint8).to(dev)
+    ba = codec.compress_device(lib, da, 2, 1, 10, C, 0.95).clone()
+    bb = codec.compress_device(lib, db, 4, 1, 220, C, 0.95).clone()
+    oa = torch.zeros_like(da); ob = torch.zeros_like(db)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for _ in range(20):
+        with torch.cuda.stream(s1):
+            codec.decompress_device(lib, ba, 2, 1, 10, C, da.numel(), out=oa, check=False)
+        with torch.cuda.stream(s2):
+            codec.decompress_device(lib, bb, 4, 1, 220, C, db.numel(), out=ob, check=False)
+    torch.cuda.synchronize()
+    assert torch.equal(oa, da) and torch.equal(ob, db)
+
+
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
 def test_fused_decode_chunk_groups(lib, group, monkeypatch):
     """Workgroups decode `group` consecutive chunks; mixed Huffman / raw / RLE / two-Huffman-plane chunks, short last group."""

@@ -31,6 +31,7 @@ struct Workspace {
   size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
+  hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC };
 
@@ -50,6 +51,18 @@ int ws_reserve(Workspace& w, int slot, size_t bytes) {
 int ws_host_words(Workspace& w) {
   if (!w.h_total) ZN_HIP(hipHostMalloc((void**)&w.h_total, 64, hipHostMallocDefault));
   w.h_status = (uint32_t*)(w.h_total + 4);
+  return ZN_OK;
+}
+
+// The workspace is shared by every call on the device.  Host-side the mutex serialises them; device-side a
+// call on another stream must not start before the previous call's kernels are done with the buffers.
+int ws_acquire(Workspace& w, hipStream_t stream) {
+  if (!w.busy) { ZN_HIP(hipEventCreateWithFlags(&w.busy, hipEventDisableTiming)); return ZN_OK; }
+  ZN_HIP(hipStreamWaitEvent(stream, w.busy, 0));
+  return ZN_OK;
+}
+int ws_release(Workspace& w, hipStream_t stream) {
+  ZN_HIP(hipEventRecord(w.busy, stream));
   return ZN_OK;
 }
 
@@ -128,6 +141,7 @@ int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int
   if ((rc = ws_reserve(w, WS_DESC, (nfull ? PK : 0) * sizeof(ZnEncDesc)))) return rc;   // indexed like csize/type (plane-major over all K)
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
+  if ((rc = ws_acquire(w, stream))) return rc;
   uint64_t* d_total = (uint64_t*)w.buf[WS_WORDS];
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
@@ -139,6 +153,7 @@ int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int
   zn_launch_encode_generic_gather(g, nfull, (const uint8_t*)w.buf[WS_PLANES], (const uint8_t*)w.buf[WS_ENC], d_csize, d_type, d_offs, (uint8_t*)d_body, stream);
   ZN_HIP(hipGetLastError());
   ZN_HIP(hipMemcpyAsync(w.h_total, d_total, 40, hipMemcpyDeviceToHost, stream));   // total length (bytes 0-7) and the status word (bytes 32-35)
+  if ((rc = ws_release(w, stream))) return rc;
   ZN_HIP(hipStreamSynchronize(stream));
   *body_len = (size_t)*w.h_total;
   if (*w.h_status) return ZN_E_CORRUPT;   // internal consistency check of the encoder failed
@@ -167,6 +182,7 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
   if ((rc = ws_reserve(w, WS_META_B, g.K))) return rc;                      // per-chunk "done by the fused kernel" flags
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
+  if ((rc = ws_acquire(w, stream))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   uint8_t* d_done = (uint8_t*)w.buf[WS_META_B];
   w.last_K = g.K;
@@ -175,8 +191,9 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
   zn_launch_decode_generic(g, (const uint8_t*)d_body, body_len, (uint8_t*)w.buf[WS_PLANES], (ZnPlaneDesc*)w.buf[WS_META_C],
                            d_status, (uint8_t*)d_dst, d_done, stream);
   ZN_HIP(hipGetLastError());
+  if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  if ((rc = ws_release(w, stream))) return rc;
   if (check) {
-    ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ZN_HIP(hipStreamSynchronize(stream));
     const uint32_t st = *w.h_status;
     if (st & ZN_DEV_BAD_TYPE) return ZN_E_TYPE;
@@ -247,12 +264,13 @@ int zn_release_workspace(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 64; d++) {
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr;
     for (int i = 0; i < 7; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
     for (int i = 0; i < 7; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
+    if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
   }
   return ZN_OK;
 }
