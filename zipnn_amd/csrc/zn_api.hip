@@ -175,9 +175,7 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
   t_kernels.clear();
   std::lock_guard<std::mutex> lk(g_mu);
   Workspace& w = g_ws[dev];
-  const size_t slot = zn_plane_slot(chunk, num_buf);
   const size_t PK = (size_t)g.P * g.K;
-  if ((rc = ws_reserve(w, WS_PLANES, PK * slot))) return rc;
   if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(ZnPlaneDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_META_B, g.K))) return rc;                      // per-chunk "done by the fused kernel" flags
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
@@ -188,8 +186,7 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
   w.last_K = g.K;
   ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
   zn_launch_decode_fused(g, (const uint8_t*)d_body, body_len, (uint8_t*)d_dst, d_done, d_status, stream);
-  zn_launch_decode_generic(g, (const uint8_t*)d_body, body_len, (uint8_t*)w.buf[WS_PLANES], (ZnPlaneDesc*)w.buf[WS_META_C],
-                           d_status, (uint8_t*)d_dst, d_done, stream);
+  zn_launch_decode_generic(g, (const uint8_t*)d_body, body_len, (ZnPlaneDesc*)w.buf[WS_META_C], d_status, (uint8_t*)d_dst, d_done, stream);
   ZN_HIP(hipGetLastError());
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if ((rc = ws_release(w, stream))) return rc;

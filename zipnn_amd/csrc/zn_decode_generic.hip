@@ -3,10 +3,10 @@
 //
 //   zn_k_decode_planes   one wave per (plane, chunk): parse its metadata, classify it
 //                        (raw / RLE / huff0) and, for huff0 blocks, build the decode LUT in
-//                        LDS and decode the four backward streams into a scratch plane.
-//   zn_k_merge_planes    one workgroup per chunk: interleave the planes (from the body for
-//                        raw planes, from scratch for decoded ones), undo the sign-bit
-//                        rotate, write the chunk with 16-byte coalesced stores.
+//                        LDS and decode the four backward streams straight into the plane's
+//                        (strided) byte positions of the output — no scratch memory.
+//   zn_k_merge_planes    one workgroup per chunk: fill in the raw / RLE planes from the body,
+//                        undo the sign-bit rotate (in place, word by word).
 //
 // Replaces: decompression_chunk_worker (reference csrc/zipnn_core.c:768-861), the metadata
 // parse of py_combine_dtype (:929-1028), HUF_decompress (call site :807) and
@@ -35,7 +35,8 @@ __device__ inline uint64_t zn_window(const uint8_t* base, int32_t bitpos) {
 }
 
 // returns 0 when the stream decodes to exactly `nout` symbols and is fully consumed
-__device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, uint8_t* out, uint32_t nout,
+// (symbol i goes to out[i * stride])
+__device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, uint8_t* out, uint32_t stride, uint32_t nout,
                                               const uint16_t* lut, uint32_t tl) {
   if (len == 0 || src[len - 1] == 0) return 1;
   int32_t bitpos = (int32_t)(len - 1u) * 8 + (int32_t)zn_hb32(src[len - 1]);
@@ -47,7 +48,7 @@ __device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, 
     while (produced < nout && avail >= (int32_t)tl) {
       const uint32_t e = lut[(uint32_t)(cont >> (64 - tl))];
       const uint32_t nb = e >> 8;
-      out[produced++] = (uint8_t)e;
+      out[(uint64_t)produced * stride] = (uint8_t)e; produced++;
       cont <<= nb; bitpos -= (int32_t)nb; avail -= (int32_t)nb;
     }
   }
@@ -58,7 +59,7 @@ __device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, 
 // kernel 1: classify + decode huff0 planes into scratch
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
-                                                              uint8_t* __restrict__ scratch, uint64_t slot,
+                                                              uint8_t* __restrict__ dst,
                                                               ZnPlaneDesc* __restrict__ descs, uint32_t* __restrict__ status,
                                                               const uint8_t* __restrict__ done) {
   __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const ui
     if (m.plen == 0 || m.csize > m.plen || m.csize == 0) bad = ZN_DEV_CORRUPT;
     else if (m.csize == m.plen) { d.off = m.off; }
     else if (m.csize == 1u) { d.kind = ZN_KIND_RLE; d.off = body[m.off]; }
-    else { d.kind = ZN_KIND_HUF; d.off = pc * slot; }
+    else { d.kind = ZN_KIND_HUF; d.off = 0; }
   }
   if (bad) { d.kind = ZN_KIND_RLE; d.off = 0; }   // keep the merge kernel in bounds; output is discarded by the caller
 
@@ -105,7 +106,9 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const ui
           const uint32_t lens[4] = {l1, l2, l3, rem - 6u - l1 - l2 - l3};
           uint32_t so = 6; for (uint32_t k = 0; k < lane; k++) so += lens[k];
           const uint32_t nout = (lane < 3) ? seg : m.plen - 3u * seg;
-          if (zn_decode_stream_serial(js + so, lens[lane], scratch + d.off + (uint64_t)lane * seg, nout, lut, tl))
+          // plane byte i of this chunk is output byte i * P + p
+          uint8_t* o = dst + c * g.chunk + ((uint64_t)lane * seg) * g.P + p;
+          if (zn_decode_stream_serial(js + so, lens[lane], o, g.P, nout, lut, tl))
             bad = ZN_DEV_CORRUPT;
         }
       }
@@ -118,16 +121,16 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const ui
 // ---------------------------------------------------------------------------
 // kernel 2: merge planes of one chunk into the output
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const uint8_t* body, const uint8_t* scratch, uint32_t i) {
+// byte j of the chunk = byte j / P of plane j % P; a Huffman-decoded plane already sits in `out`
+__device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const uint8_t* body, const uint8_t* out, uint32_t j, uint32_t i) {
   if (d.kind == ZN_KIND_RLE) return (uint32_t)d.off & 0xFFu;
-  const uint8_t* b = (d.kind == ZN_KIND_HUF) ? scratch : body;
-  return b[d.off + i];
+  if (d.kind == ZN_KIND_HUF) return out[j];
+  return body[d.off + i];
 }
 
 template <int P>
 __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t* __restrict__ body,
-                                                         const uint8_t* __restrict__ scratch,
-                                                         const ZnPlaneDesc* __restrict__ descs, uint8_t* __restrict__ dst,
+                                                         const ZnPlaneDesc* __restrict__ descs, uint8_t* dst,
                                                          const uint8_t* __restrict__ done) {
   const uint64_t c = blockIdx.x;
   if (done && done[c]) return;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t
     uint32_t w = 0;
     for (uint32_t t = 0; t < 4; t++) {
       const uint32_t j = 4u * wi + t;
-      w |= zn_plane_byte(d[j % P], body, scratch, j / P) << (8 * t);
+      w |= zn_plane_byte(d[j % P], body, out, j, j / P) << (8 * t);
     }
     if (g.rot) w = (P == 2) ? zn_rot_inv16(w) : zn_rot_inv32(w);
     const uint64_t a = (uint64_t)(out + 4ull * wi);
@@ -151,20 +154,19 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t
   // trailing clen % 4 bytes are never rotated (reference rotates len/4 words only)
   if (threadIdx.x < (clen & 3u)) {
     const uint32_t j = 4u * nwords + threadIdx.x;
-    out[j] = (uint8_t)zn_plane_byte(d[j % P], body, scratch, j / P);
+    out[j] = (uint8_t)zn_plane_byte(d[j % P], body, out, j, j / P);
   }
 }
 
-void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_scratch,
+void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len,
                               ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, const uint8_t* d_done,
                               hipStream_t stream) {
   if (g.K == 0) return;
-  const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
   hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)(g.P * g.K)), dim3(ZN_WAVE), 0, stream, g, d_body, body_len,
-                     d_scratch, slot, d_descs, d_status, d_done);
+                     d_dst, d_descs, d_status, d_done);
   zn_note_kernel("zn_k_decode_planes");
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst, d_done);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst, d_done);
-  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_scratch, d_descs, d_dst, d_done);
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_descs, d_dst, d_done);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_descs, d_dst, d_done);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_descs, d_dst, d_done);
   zn_note_kernel("zn_k_merge_planes");
 }

@@ -48,6 +48,20 @@ typedef uint64_t __attribute__((aligned(1))) zn_eu64u;
 typedef uint32_t __attribute__((aligned(1))) zn_eu32u;
 struct __attribute__((aligned(1))) zn_eu128u { uint32_t x, y, z, w; };
 
+// wave-wide exclusive prefix sum on the DPP network (row_shr 1/2/4/8 inside rows of 16 lanes, row_bcast15 /
+// row_bcast31 across rows); *total = sum over the wave
+__device__ __forceinline__ uint32_t zn_wave_excl_scan_u32(uint32_t v, uint32_t* total) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  return (uint32_t)x - v;
+}
+
 // rotated dword → the reference's forward bit reorder for this plane count
 template <int P> __device__ __forceinline__ uint32_t zn_rot_fwd(uint32_t u, uint32_t rot) {
   if (!rot) return u;
@@ -315,27 +329,40 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
       }
     }
     if (H < 0) continue;
-    // codes of this lane's 32 symbols (val | len << 16) and their total length
-    uint32_t cw[ZN_E_SPL]; uint32_t T = 0;
-    for (int e = 0; e < ZN_E_SPL; e++) {
-      uint32_t sym = 0;
-      for (int p = 0; p < P; p++) if (p == H) { const int k = P * e + p; sym = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu; }
-      cw[e] = code[sym]; T += cw[e] >> 16;
-    }
-    // bit offset of this lane in the tile: lanes are packed from lane 63 down to lane 0
-    uint32_t incl = T;
-    for (uint32_t dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(incl, dd); if (lane >= dd) incl += y; }
-    const uint32_t total = __shfl(incl, 63);
-    uint32_t b = carry + (total - incl);
-    {
-      uint32_t idx = b >> 5, sh = b & 31u, acc = 0;
-      for (int e = ZN_E_SPL - 1; e >= 0; e--) {
-        const uint32_t v = cw[e] & 0xFFFFu, nb = cw[e] >> 16;
-        acc |= v << sh;
-        if (sh + nb >= 32u) { atomicOr(&buf[idx], acc); idx++; acc = v >> (32u - sh); sh = sh + nb - 32u; }   // sh ≥ 20 here
-        else sh += nb;
+    // Codes of this lane's 32 symbols (val | len << 16), merged branch-free: pairs (≤ 22 bits), then quads
+    // (≤ 44 bits, 64-bit).  The stream is written backwards, so inside a group the LATER symbol takes the
+    // lower bits.
+    uint64_t qv[8]; uint32_t qn[8];
+    for (int i = 0; i < 8; i++) {
+      uint32_t pv[2], pn[2];
+      for (int h = 0; h < 2; h++) {
+        uint32_t cw[2];
+        for (int t = 0; t < 2; t++) {
+          const int e = 4 * i + 2 * h + t;
+          uint32_t sym = 0;
+          for (int p = 0; p < P; p++) if (p == H) { const int k = P * e + p; sym = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu; }
+          cw[t] = code[sym];
+        }
+        pv[h] = ((cw[0] & 0xFFFFu) << (cw[1] >> 16)) | (cw[1] & 0xFFFFu);
+        pn[h] = (cw[0] >> 16) + (cw[1] >> 16);
       }
-      if (sh > 0u) atomicOr(&buf[idx], acc);
+      qv[i] = ((uint64_t)pv[0] << pn[1]) | pv[1];
+      qn[i] = pn[0] + pn[1];
+    }
+    // bit offset of every quad inside the lane (quad 7 lowest), and the lane's total
+    uint32_t qo[8]; uint32_t T = 0;
+    for (int i = 7; i >= 0; i--) { qo[i] = T; T += qn[i]; }
+    // bit offset of this lane in the tile: lanes are packed from lane 63 down to lane 0
+    uint32_t total = 0;
+    const uint32_t excl = zn_wave_excl_scan_u32(T, &total);
+    const uint32_t b = carry + (total - excl - T);
+    for (int i = 0; i < 8; i++) {
+      const uint32_t bp = b + qo[i], idx = bp >> 5, sh = bp & 31u;
+      const uint64_t lo = qv[i] << sh;                                  // bits 0-63 of the shifted quad
+      const uint32_t w2 = (uint32_t)(((qv[i] >> 32) << sh) >> 32);      // bits 64-75 (quad < 2^44)
+      atomicOr(&buf[idx], (uint32_t)lo);
+      atomicOr(&buf[idx + 1u], (uint32_t)(lo >> 32));
+      atomicOr(&buf[idx + 2u], w2);
     }
     __builtin_amdgcn_wave_barrier();
     // flush whole dwords, keep the remainder (< 32 bits) at buf[0]

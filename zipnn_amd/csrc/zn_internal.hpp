@@ -17,7 +17,7 @@ static inline size_t zn_plane_slot(size_t chunk, int P) { return ((chunk + (size
 // ---- generic decode path (any dtype, any tail) : zn_decode_generic.hip ----
 // descs: [P*K]; scratch: P*K slots of zn_plane_slot bytes; status: one device word.
 // d_done: [K] flags written by the fused kernel (1 = chunk already decoded), or nullptr.
-void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_scratch,
+void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len,
                               ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, const uint8_t* d_done,
                               hipStream_t stream);
 
