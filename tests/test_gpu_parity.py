@@ -196,3 +196,34 @@ def test_full_size_roundtrip_properties(lib, dtype):
             mine = body[base + lo: base + int(cum[p, c])].cpu().numpy().tobytes()
             assert mine == opay[off_o: off_o + int(osz[p])]
             off_o += int(osz[p]); base += int(cum[p, -1])
+
+
+def test_beyond_4GiB_offsets_roundtrip(lib):
+    """5 GiB + a ragged tail: every byte offset in the path is 64-bit (input offsets > 2^32, payload offsets
+    > 2^32 in the second plane).  Round trip exact; the last full chunk and the tail equal the oracle's bytes."""
+    from zipnn_amd import codec
+    n_bytes = 5 * (1 << 30) + 3 * C + 1234
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x = torch.empty(n_bytes // 2, dtype=torch.bfloat16, device="cuda")
+    for off in range(0, x.numel(), 1 << 27):
+        m = min(1 << 27, x.numel() - off)
+        x[off:off + m] = (torch.randn(m, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    flat = codec.flat_bytes(x)
+    body = codec.compress_device(lib, flat, 2, 1, 10, C, 0.95)
+    K = (n_bytes + C - 1) // C
+    cum = body[2 * K: 2 * K + 16 * K].cpu().numpy().view(np.uint64).reshape(2, K)
+    assert int(cum[0, -1]) > (1 << 31) and 18 * K + int(cum[:, -1].sum()) == body.numel()
+    out = codec.decompress_device(lib, body, 2, 1, 10, C, n_bytes)
+    assert lib.last_fused_chunks() == K - 1
+    assert torch.equal(out, flat)
+    # the bytes of the last full chunk and of the tail chunk, against the oracle
+    for c in (K - 2, K - 1):
+        raw = flat[c * C: min((c + 1) * C, n_bytes)].cpu().numpy().tobytes()
+        ofr = O.compress_frame(b"", raw, 2, 1, 10, C)
+        osz = np.frombuffer(ofr[2:2 + 16], dtype=np.uint64); opay = ofr[18:]
+        base = 18 * K; off_o = 0
+        for p in range(2):
+            lo = int(cum[p, c - 1])
+            mine = body[base + lo: base + int(cum[p, c])].cpu().numpy().tobytes()
+            assert mine == opay[off_o: off_o + int(osz[p])]
+            off_o += int(osz[p]); base += int(cum[p, -1])
