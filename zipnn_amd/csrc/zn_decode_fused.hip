@@ -148,10 +148,13 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
     if (cnt < 5u) meta &= ~(0xFFu << 20);                           // symbol 4 only with all five
   }
   if (MODE == 2) {
-    const uint32_t syms = lut32[idx + (1u << ZN_F_TLMAX)] & keep, sym4 = (meta >> 20) & 0xFFu;
-    const uint32_t sh8 = (c.wpos & 3u) << 3; uint32_t* d = stage + (c.wpos >> 2);
-    atomicOr(d, syms << sh8);
-    atomicOr(d + 1, ((syms >> 1) >> (31u - sh8)) | (sym4 << sh8));  // bytes that spill into the next dword (0 when none)
+    // the ≤ 5 symbol bytes as one 40-bit value, moved to the byte position inside the dword with one 64-bit
+    // shift: low dword → d[0], high dword = the bytes that spill into d[1] (0 when none)
+    const uint64_t pack = ((uint64_t)((meta >> 20) & 0xFFu) << 32) | (lut32[idx + (1u << ZN_F_TLMAX)] & keep);
+    const uint64_t sp = pack << ((c.wpos & 3u) << 3);
+    uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & ~3u));
+    atomicOr(d, (uint32_t)sp);
+    atomicOr(d + 1, (uint32_t)(sp >> 32));
     c.wpos += cnt;
   }
   { const uint64_t w = (((uint64_t)c.whi << 32) | c.wlo) << nb; c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w; }   // v_lshlrev_b64
@@ -220,6 +223,16 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) pre[r][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
       }
     }
+    // undo the sign-bit rotate on the two top planes BEFORE the interleave (4 elements per dword):
+    // top byte = (low.7) | (top >> 1), low byte = (top.0 << 7) | (low & 0x7F) — two v_bfi per dword pair
+    if (P >= 2 && g.rot) {
+      for (int r = 0; r < RB; r++) if (r < nrows)
+        for (int k = 0; k < EW; k++) {
+          const uint32_t hi = pre[r][P - 1][k], lo = pre[r][(P >= 2) ? P - 2 : 0][k];
+          pre[r][P - 1][k] = (lo & 0x80808080u) | ((hi >> 1) & ~0x80808080u);
+          pre[r][(P >= 2) ? P - 2 : 0][k] = (lo & 0x7F7F7F7Fu) | ((hi << 7) & ~0x7F7F7F7Fu);
+        }
+    }
     for (int r = 0; r < RB; r++) if (r < nrows) {
       const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
       uint8_t* o = outq + (uint64_t)si * P;
@@ -229,7 +242,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         uint32_t x[4];
         x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
         x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
-        if (g.rot) for (int k = 0; k < 4; k++) x[k] = zn_rot_inv16(x[k]);
         ZN_ST128(o, x[0], x[1], x[2], x[3]);
       } else {
         for (int half = 0; half < 2; half++) {
@@ -239,7 +251,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           uint32_t x[4];
           x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
           x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-          if (g.rot) for (int q = 0; q < 4; q++) x[q] = zn_rot_inv32(x[q]);
           ZN_ST128(o + 16 * half, x[0], x[1], x[2], x[3]);
         }
       }
