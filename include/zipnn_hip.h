@@ -96,6 +96,19 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
                       int bytes_mode, size_t chunk, size_t orig_size, void* d_dst, void* stream,
                       int check);
 
+/* Batched decompress: `count` tensors (any mix of dtypes) decoded by one set of kernel launches, so that
+ * many small tensors fill the device as one large one does.  What a safetensors loader does per file:
+ * replaces the per-tensor loop around decompress_safetensors_tensor (reference zipnn/zipnn.py:1584-1596,
+ * scripts/zipnn_decompress_safetensors.py:75-120).  Same semantics per item as zn_decompress_dev; an error
+ * in any item fails the call. */
+typedef struct zn_batch_item {
+  const void* d_body; size_t body_len;   /* frame body (after the header), on the current device */
+  void* d_dst; size_t orig_size;         /* receives orig_size bytes */
+  int num_buf, bits_mode, bytes_mode;
+  size_t chunk;
+} zn_batch_item;
+int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stream, int check);
+
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);
 

@@ -227,3 +227,24 @@ def test_beyond_4GiB_offsets_roundtrip(lib):
             mine = body[base + lo: base + int(cum[p, c])].cpu().numpy().tobytes()
             assert mine == opay[off_o: off_o + int(osz[p])]
             off_o += int(osz[p]); base += int(cum[p, -1])
+
+
+def test_batched_decode_many_tensors(lib):
+    """zn_decompress_batch_dev on the GPU: every plane count, tails, tiny and empty tensors in one call; the
+    results equal the inputs and the per-tensor decode."""
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    specs = [("bf16", 40 * C + 10, 2, 1, 10, C), ("fp32", 9 * C + 4, 4, 1, 220, C), ("fp8", 5 * 128 * KB + 1, 1, 1, 10, 128 * KB),
+             ("bf16", 7, 2, 1, 10, C), ("bf16", 0, 2, 1, 10, C), ("fp16", 33 * C, 2, 0, 10, C), ("rand", 4 * C, 2, 1, 10, C),
+             ("const", 2 * C, 2, 1, 10, C), ("fp32", 1000, 4, 1, 220, C)] + [("bf16", 3 * C + 2 * i, 2, 1, 10, C) for i in range(40)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = gen_bytes(kind, nb, 50 + i)
+        frame = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)
+        body = frame[32:]
+        datas.append(d)
+        items.append(((torch.frombuffer(bytearray(body), dtype=torch.uint8) if body else torch.empty(0, dtype=torch.uint8)).to(dev), P, rot, bm, chunk, nb))
+    outs = codec.decompress_device_batch(lib, items)
+    for d, o in zip(datas, outs):
+        assert o.cpu().numpy().tobytes() == d
+    assert "zn_k_decode_fused" in lib.last_kernels()

@@ -190,3 +190,22 @@ def test_fused_encode_path_bit_exact(simt_lib, case):
     assert body[:used].numpy().tobytes() == want[32:]
     if chunk % 16384 == 0 and chunk % (8192 * P) == 0 and chunk // P <= 128 * 1024:
         assert "zn_k_encode_stats" in simt_lib.last_kernels() and "zn_k_encode_emit" in simt_lib.last_kernels()
+
+
+def test_batched_decode_matches_per_tensor_decode(simt_lib):
+    """zn_decompress_batch_dev: tensors of all plane counts, with tails, tiny and empty ones, in one call."""
+    from zipnn_amd import codec
+    specs = [("bf16", 3 * C + 10, 2, 1, 10, C), ("fp32", 2 * C + 4, 4, 1, 220, C), ("fp8", C + 1, 1, 1, 10, C),
+             ("bf16", 7, 2, 1, 10, C), ("bf16", 0, 2, 1, 10, C), ("fp16", 5 * 16384, 2, 0, 10, 16384),
+             ("rand", 4 * C, 2, 1, 10, C), ("const", 2 * C, 2, 1, 10, C), ("fp32", 1000, 4, 1, 220, C)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = gen_bytes(kind, nb, 30 + i)
+        frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
+        datas.append(d)
+        body = frame[32:]
+        items.append((torch.frombuffer(bytearray(body), dtype=torch.uint8) if body else torch.empty(0, dtype=torch.uint8), P, rot, bm, chunk, nb))
+    outs = codec.decompress_device_batch(simt_lib, items)
+    for d, o in zip(datas, outs):
+        assert o.numpy().tobytes() == d
+    assert simt_lib.last_fused_chunks() == 3 + 2 + 1 + 5 + 4 + 2      # full chunks of the fused-eligible tensors

@@ -43,6 +43,12 @@ def test_safetensors_file_roundtrip_and_plugin(use_simt, tmp_path):
             got = f.get_tensor(k)
             assert got.dtype == v.dtype and got.shape == v.shape
             assert got.view(torch.uint8).numpy().tobytes() == v.contiguous().view(torch.uint8).numpy().tobytes()
+    # whole file in one batched decode (device = cpu memory under the emulator)
+    loaded = safetensors_io.load_file(znn_path, device="cpu")
+    assert set(loaded) == set(tensors)
+    for k, v in tensors.items():
+        assert loaded[k].dtype == v.dtype and loaded[k].shape == v.shape
+        assert loaded[k].contiguous().view(torch.uint8).numpy().tobytes() == v.contiguous().view(torch.uint8).numpy().tobytes(), k
     # plugin: patched safe_open decompresses on access
     orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
     try:

@@ -26,6 +26,13 @@ class ZnError(RuntimeError):
         self.status = status
 
 
+class ZnBatchItem(ctypes.Structure):
+    """struct zn_batch_item of include/zipnn_hip.h"""
+    _fields_ = [("d_body", ctypes.c_void_p), ("body_len", ctypes.c_size_t), ("d_dst", ctypes.c_void_p),
+                ("orig_size", ctypes.c_size_t), ("num_buf", ctypes.c_int), ("bits_mode", ctypes.c_int),
+                ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t)]
+
+
 class ZnLib:
     """A loaded libzipnn_hip.so."""
 
@@ -51,6 +58,8 @@ class ZnLib:
         L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
         L.zn_decompress_dev.restype = ci
         L.zn_decompress_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, vp, vp, ci]
+        L.zn_decompress_batch_dev.restype = ci
+        L.zn_decompress_batch_dev.argtypes = [ctypes.POINTER(ZnBatchItem), sz, vp, ci]
         L.zn_release_workspace.restype = ci
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
         self._L = L
@@ -124,6 +133,15 @@ class ZnLib:
         rc = self._L.zn_decompress_dev(body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr,
                                        stream, 1 if check else 0)
         self._check(rc)
+
+    def decompress_batch_dev(self, items, stream=0, check=True):
+        """items: iterable of (body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr)."""
+        items = list(items)
+        arr = (ZnBatchItem * max(len(items), 1))()
+        for i, (bp, bl, nb, bi, by, ch, n, dp) in enumerate(items):
+            arr[i].d_body = bp; arr[i].body_len = bl; arr[i].d_dst = dp; arr[i].orig_size = n
+            arr[i].num_buf = nb; arr[i].bits_mode = bi; arr[i].bytes_mode = by; arr[i].chunk = ch
+        self._check(self._L.zn_decompress_batch_dev(arr, len(items), stream, 1 if check else 0))
 
     def last_fused_chunks(self):
         """Chunks of the last decompress_dev call that took the fused single-pass kernel."""

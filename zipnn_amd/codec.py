@@ -66,3 +66,18 @@ class _nullctx:
 
     def __exit__(self, *a):
         return False
+
+
+def decompress_device_batch(lib, items, check=True):
+    """Many tensors, one set of kernel launches (zn_decompress_batch_dev): small tensors fill the device together.
+    items: iterable of (body, num_buf, bits_mode, bytes_mode, chunk, orig_size) with `body` a uint8 tensor on
+    the device (frame minus header).  Returns the list of decoded uint8 tensors (same device)."""
+    items = [(b.contiguous(), nb, bi, by, ch, n) for (b, nb, bi, by, ch, n) in items]
+    if not items:
+        return []
+    dev = items[0][0].device
+    outs = [torch.empty(n, dtype=torch.uint8, device=dev) for (_, _, _, _, _, n) in items]
+    with torch.cuda.device(dev) if dev.type == "cuda" else _nullctx():
+        lib.decompress_batch_dev(((b.data_ptr(), b.numel(), nb, bi, by, ch, n, o.data_ptr() if n else 0)
+                                  for (b, nb, bi, by, ch, n), o in zip(items, outs)), _stream_handle(items[0][0]), check)
+    return outs

@@ -7,6 +7,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 #include <string.h>
 
 namespace {
@@ -27,13 +28,14 @@ thread_local std::string t_kernels;
 // device serialise on their workspace — independent GPUs run in independent processes).
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
-  void* buf[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[7] = {0, 0, 0, 0, 0, 0, 0};
+  void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched decode
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
 };
-enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC };
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_COUNT };
 
 std::mutex g_mu;
 Workspace g_ws[64];
@@ -160,33 +162,76 @@ int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int
   return ZN_OK;
 }
 
-int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                      size_t orig_size, void* d_dst, void* stream_, int check) {
-  ZnGeom g;
-  int rc = check_geom(orig_size, num_buf, bytes_mode, chunk, &g, bits_mode);
-  if (rc) return rc;
-  if (body_len < 9u * (size_t)g.P * g.K) return ZN_E_CORRUPT;
-  if (orig_size == 0) return ZN_OK;
-  if (!d_body || !d_dst) return ZN_E_ARG;
-  hipStream_t stream = (hipStream_t)stream_;
+// Decode `count` tensors in one set of launches per plane count.  A single tensor travels to the kernels as an
+// argument; a batch as a segment table in device memory.
+static int decompress_items(const zn_batch_item* items, size_t count, hipStream_t stream, int check) {
+  if (count && !items) return ZN_E_ARG;
+  std::vector<ZnSeg> segs[3];                    // by plane count: 1, 2, 4
+  uint64_t pk_of[3] = {0, 0, 0}, k_of[3] = {0, 0, 0}; uint64_t wg_of[3] = {0, 0, 0};
+  uint64_t total_chunks = 0;
+  for (size_t i = 0; i < count; i++) total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk);
+  const uint32_t ncg = zn_decode_fused_group(total_chunks);
+  for (size_t i = 0; i < count; i++) {
+    const zn_batch_item& it = items[i];
+    ZnSeg sg;
+    int rc = check_geom(it.orig_size, it.num_buf, it.bytes_mode, it.chunk, &sg.g, it.bits_mode);
+    if (rc) return rc;
+    if (it.body_len < 9u * (size_t)sg.g.P * sg.g.K) return ZN_E_CORRUPT;
+    if (it.orig_size == 0) continue;
+    if (!it.d_body || !it.d_dst) return ZN_E_ARG;
+    const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
+    sg.body = (const uint8_t*)it.d_body; sg.body_len = it.body_len; sg.dst = (uint8_t*)it.d_dst;
+    sg.chunk0 = k_of[q]; sg.desc0 = pk_of[q]; sg.wg0 = (uint32_t)wg_of[q]; sg.ncg = ncg;
+    k_of[q] += sg.g.K; pk_of[q] += (uint64_t)sg.g.P * sg.g.K; wg_of[q] += (sg.g.K + ncg - 1u) / ncg;
+    if (pk_of[q] > 0x7FFFFFFFull || wg_of[q] > 0x7FFFFFFFull) return ZN_E_ARG;
+    segs[q].push_back(sg);
+  }
+  const uint64_t all_k = k_of[0] + k_of[1] + k_of[2], all_pk = pk_of[0] + pk_of[1] + pk_of[2];
+  if (all_k == 0) return ZN_OK;
   int dev = 0;
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   t_kernels.clear();
   std::lock_guard<std::mutex> lk(g_mu);
   Workspace& w = g_ws[dev];
-  const size_t PK = (size_t)g.P * g.K;
-  if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(ZnPlaneDesc)))) return rc;
-  if ((rc = ws_reserve(w, WS_META_B, g.K))) return rc;                      // per-chunk "done by the fused kernel" flags
+  int rc;
+  const size_t nseg_all = segs[0].size() + segs[1].size() + segs[2].size();
+  const bool table = nseg_all > 1;
+  if ((rc = ws_reserve(w, WS_META_C, all_pk * sizeof(ZnPlaneDesc)))) return rc;
+  if ((rc = ws_reserve(w, WS_META_B, all_k))) return rc;                     // per-chunk "done by the fused kernel" flags
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
+  if (table) {
+    if ((rc = ws_reserve(w, WS_SEGS, nseg_all * sizeof(ZnSeg)))) return rc;
+    if (w.h_segs_cap < nseg_all) {
+      if (w.h_segs) { ZN_HIP(hipHostFree(w.h_segs)); w.h_segs = nullptr; w.h_segs_cap = 0; }
+      ZN_HIP(hipHostMalloc((void**)&w.h_segs, nseg_all * sizeof(ZnSeg), hipHostMallocDefault));
+      w.h_segs_cap = nseg_all;
+    }
+  }
   if ((rc = ws_acquire(w, stream))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
-  uint8_t* d_done = (uint8_t*)w.buf[WS_META_B];
-  w.last_K = g.K;
+  w.last_K = all_k;
   ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
-  zn_launch_decode_fused(g, (const uint8_t*)d_body, body_len, (uint8_t*)d_dst, d_done, d_status, stream);
-  zn_launch_decode_generic(g, (const uint8_t*)d_body, body_len, (ZnPlaneDesc*)w.buf[WS_META_C], d_status, (uint8_t*)d_dst, d_done, stream);
+  if (table) {
+    // the previous batched call may still be reading the pinned staging: wait for it on the host
+    ZN_HIP(hipEventSynchronize(w.busy));
+    size_t o = 0;
+    for (int q = 0; q < 3; q++) for (const ZnSeg& sg : segs[q]) w.h_segs[o++] = sg;
+    ZN_HIP(hipMemcpyAsync(w.buf[WS_SEGS], w.h_segs, nseg_all * sizeof(ZnSeg), hipMemcpyHostToDevice, stream));
+  }
+  size_t seg_base = 0; uint64_t k_base = 0, pk_base = 0;
+  for (int q = 0; q < 3; q++) {
+    if (segs[q].empty()) continue;
+    const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
+    const ZnSeg* d_segs = table ? (const ZnSeg*)w.buf[WS_SEGS] + seg_base : nullptr;
+    const uint32_t nseg = (uint32_t)segs[q].size();
+    uint8_t* d_done = (uint8_t*)w.buf[WS_META_B] + k_base;
+    ZnPlaneDesc* d_descs = (ZnPlaneDesc*)w.buf[WS_META_C] + pk_base;
+    zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_status, stream);
+    zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, stream);
+    seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q];
+  }
   ZN_HIP(hipGetLastError());
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if ((rc = ws_release(w, stream))) return rc;
@@ -197,6 +242,18 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
     if (st & ZN_DEV_CORRUPT) return ZN_E_CORRUPT;
   }
   return ZN_OK;
+}
+
+int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                      size_t orig_size, void* d_dst, void* stream_, int check) {
+  zn_batch_item it;
+  it.d_body = d_body; it.body_len = body_len; it.d_dst = d_dst; it.orig_size = orig_size;
+  it.num_buf = num_buf; it.bits_mode = bits_mode; it.bytes_mode = bytes_mode; it.chunk = chunk;
+  return decompress_items(&it, 1, (hipStream_t)stream_, check);
+}
+
+int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stream_, int check) {
+  return decompress_items(items, count, (hipStream_t)stream_, check);
 }
 
 int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
@@ -261,11 +318,12 @@ int zn_release_workspace(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 64; d++) {
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr;
-    for (int i = 0; i < 7; i++) any = any || w.buf[i];
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr;
+    for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
-    for (int i = 0; i < 7; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
+    for (int i = 0; i < WS_COUNT; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
+    if (w.h_segs) { (void)hipHostFree(w.h_segs); w.h_segs = nullptr; w.h_segs_cap = 0; }
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
   }

@@ -4,6 +4,21 @@
 #pragma once
 
 #include "zn_common.hpp"
+#include "zn_internal.hpp"
+
+// ---------------------------------------------------------------------------
+// which tensor of a batched launch does grid index `b` belong to?  KEY: 0 = fused workgroup, 1 = (plane,
+// chunk) index, 2 = chunk index.  Wave-uniform (scalar loads); the last segment with key ≤ b.
+// ---------------------------------------------------------------------------
+template <int KEY>
+__device__ __forceinline__ uint64_t zn_seg_key(const ZnSeg& s) { return KEY == 0 ? (uint64_t)s.wg0 : KEY == 1 ? s.desc0 : s.chunk0; }
+template <int KEY>
+__device__ __forceinline__ ZnSeg zn_find_seg(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b) {
+  if (segs == nullptr) return one;
+  uint32_t lo = 0, hi = nseg;                 // invariant: key(lo) ≤ b, key(hi) > b (hi == nseg: past the end)
+  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (zn_seg_key<KEY>(segs[mid]) <= b) lo = mid; else hi = mid; }
+  return segs[lo];
+}
 
 // ---------------------------------------------------------------------------
 // metadata of one (plane, chunk), computed identically by every lane

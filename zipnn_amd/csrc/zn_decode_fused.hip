@@ -418,15 +418,20 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 // (LUT fill by 256 threads, then wave w = stream w).  ncg = chunks per group (1..4, chosen by the host so
 // that small inputs still spread over every CU).
 template <int P>
-__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
-                                                                  uint8_t* __restrict__ dst, uint8_t* __restrict__ done,
-                                                                  uint32_t* __restrict__ status, uint32_t ncg) {
+__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+                                                                  uint8_t* __restrict__ done_all, uint32_t* __restrict__ status) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
+  const ZnSeg S = zn_find_seg<0>(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
+  uint8_t* __restrict__ dst = S.dst; uint8_t* __restrict__ done = done_all + S.chunk0;
+  const uint32_t ncg = S.ncg;
+
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c0 = (uint64_t)blockIdx.x * ncg;
+  const uint64_t c0 = (uint64_t)(blockIdx.x - S.wg0) * ncg;
   const uint32_t nc = (g.K - c0 < (uint64_t)ncg) ? (uint32_t)(g.K - c0) : ncg;
   const uint32_t plen = (uint32_t)(g.chunk / P);
   const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
@@ -571,23 +576,26 @@ extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
 }
 #endif
 
-void zn_launch_decode_fused(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_dst, uint8_t* d_done,
-                            uint32_t* d_status, hipStream_t stream) {
-  if (g.K == 0) return;
-  // chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
-  // outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
+// chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
+// outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
+uint32_t zn_decode_fused_group(uint64_t K) {
   static int slots = 0;
   if (slots == 0) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     slots = cus * ZN_F_WAVES_PER_SIMD;
   }
-  uint32_t ncg = (uint32_t)(g.K / (uint64_t)slots);
+  uint32_t ncg = (uint32_t)(K / (uint64_t)slots);
   ncg = ncg > 4u ? 4u : (ncg < 1u ? 1u : ncg);
   if (const char* e = getenv("ZN_DECODE_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4) ncg = (uint32_t)v; }   // test / tuning knob
-  const uint32_t grid = (uint32_t)((g.K + ncg - 1u) / ncg);
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(grid), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status, ncg);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(grid), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status, ncg);
-  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(grid), dim3(ZN_F_THREADS), 0, stream, g, d_body, body_len, d_dst, d_done, d_status, ncg);
+  return ncg;
+}
+
+void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
+                            uint8_t* d_done, uint32_t* d_status, hipStream_t stream) {
+  if (total_wg == 0) return;
+  if (P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_status);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_status);
+  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_status);
   zn_note_kernel("zn_k_decode_fused");
 }

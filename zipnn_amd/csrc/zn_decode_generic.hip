@@ -58,16 +58,22 @@ __device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, 
 // ---------------------------------------------------------------------------
 // kernel 1: classify + decode huff0 planes into scratch
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnGeom g, const uint8_t* __restrict__ body, uint64_t body_len,
-                                                              uint8_t* __restrict__ dst,
-                                                              ZnPlaneDesc* __restrict__ descs, uint32_t* __restrict__ status,
-                                                              const uint8_t* __restrict__ done) {
+__global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+                                                              ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
+                                                              const uint8_t* __restrict__ done_all) {
   __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
   __shared__ uint8_t sh_w[256], sh_symlist[256], sh_cell[64];
   __shared__ uint32_t sh_rank_start[14], sh_sym_start[14];
 
+  const ZnSeg S = zn_find_seg<1>(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
+  uint8_t* __restrict__ dst = S.dst;
+  ZnPlaneDesc* __restrict__ descs = descs_all + S.desc0;
+  const uint8_t* __restrict__ done = done_all ? done_all + S.chunk0 : nullptr;
+
   const uint32_t lane = threadIdx.x;
-  const uint64_t pc = blockIdx.x;
+  const uint64_t pc = blockIdx.x - S.desc0;
   const uint32_t p = (uint32_t)(pc / g.K);
   const uint64_t c = pc % g.K;
   if (done && done[c]) return;                 // chunk already written by the fused kernel
@@ -129,10 +135,15 @@ __device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const ui
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t* __restrict__ body,
-                                                         const ZnPlaneDesc* __restrict__ descs, uint8_t* dst,
-                                                         const uint8_t* __restrict__ done) {
-  const uint64_t c = blockIdx.x;
+__global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+                                                         const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all) {
+  const ZnSeg S = zn_find_seg<2>(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ body = S.body;
+  uint8_t* dst = S.dst;
+  const ZnPlaneDesc* __restrict__ descs = descs_all + S.desc0;
+  const uint8_t* __restrict__ done = done_all ? done_all + S.chunk0 : nullptr;
+  const uint64_t c = blockIdx.x - S.chunk0;
   if (done && done[c]) return;
   const uint32_t clen = zn_chunk_len(g, c);
   uint8_t* out = dst + c * g.chunk;
@@ -158,15 +169,13 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnGeom g, const uint8_t
   }
 }
 
-void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, const uint8_t* d_done,
-                              hipStream_t stream) {
-  if (g.K == 0) return;
-  hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)(g.P * g.K)), dim3(ZN_WAVE), 0, stream, g, d_body, body_len,
-                     d_dst, d_descs, d_status, d_done);
+void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint64_t total_pk, uint64_t total_k,
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, hipStream_t stream) {
+  if (total_k == 0) return;
+  hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)total_pk), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, d_descs, d_status, d_done);
   zn_note_kernel("zn_k_decode_planes");
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_descs, d_dst, d_done);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_descs, d_dst, d_done);
-  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)g.K), dim3(256), 0, stream, g, d_body, d_descs, d_dst, d_done);
+  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done);
   zn_note_kernel("zn_k_merge_planes");
 }

@@ -14,16 +14,28 @@ struct ZnPlaneDesc {
 // Slot stride (bytes) of one plane of one chunk in the scratch-plane buffers.
 static inline size_t zn_plane_slot(size_t chunk, int P) { return ((chunk + (size_t)P - 1) / (size_t)P + 15) & ~(size_t)15; }
 
+// One tensor ("segment") of a decode launch.  A launch decodes one tensor (the segment travels as a kernel
+// argument) or a batch of tensors with the same plane count (a table in device memory; workgroups find their
+// tensor by binary search over the three running indices).
+struct ZnSeg {
+  ZnGeom g;
+  const uint8_t* body; uint64_t body_len; uint8_t* dst;
+  uint64_t chunk0;   // index of the tensor's first chunk in the launch-wide done[] flags  (merge kernel grid)
+  uint64_t desc0;    // index of its first (plane, chunk) in descs[]                          (planes kernel grid)
+  uint32_t wg0;      // its first workgroup of the fused kernel
+  uint32_t ncg;      // chunks per fused workgroup
+};
+
 // ---- generic decode path (any dtype, any tail) : zn_decode_generic.hip ----
-// descs: [P*K]; scratch: P*K slots of zn_plane_slot bytes; status: one device word.
-// d_done: [K] flags written by the fused kernel (1 = chunk already decoded), or nullptr.
-void zn_launch_decode_generic(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, uint8_t* d_dst, const uint8_t* d_done,
-                              hipStream_t stream);
+// descs: Σ P·K entries; status: one device word; d_done: Σ K flags written by the fused kernel.
+// segs == nullptr: the single tensor `one`.  total_pk / total_k: grid sizes (Σ P·K, Σ K).
+void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint64_t total_pk, uint64_t total_k,
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, hipStream_t stream);
 
 // ---- fused decode path (full chunks, ≤1 Huffman plane) : zn_decode_fused.hip ----
-void zn_launch_decode_fused(const ZnGeom& g, const uint8_t* d_body, uint64_t body_len, uint8_t* d_dst, uint8_t* d_done,
-                            uint32_t* d_status, hipStream_t stream);
+uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a tensor of K chunks
+void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
+                            uint8_t* d_done, uint32_t* d_status, hipStream_t stream);
 
 // ---- generic encode path : zn_encode_generic.hip ----
 // Handles chunks [c0, K).  planes/enc: P*(K-c0) slots each; csize/type/offs: [P*K] (global indexing).

@@ -62,3 +62,30 @@ def decompress_safetensors_file(filename, out_path=None, device="cpu"):
     metadata.pop(METADATA_KEY, None)
     save_file(tensors, out_path, metadata or None)
     return out_path
+
+
+def load_file(filename, device="cuda:0"):
+    """Load a (possibly ZipNN-compressed) safetensors file straight onto `device`: compressed tensors cross
+    PCIe compressed and are decoded by ONE batched launch (zn_decompress_batch_dev), so a file of many small
+    tensors decodes at the rate of one large tensor.  -> {name: tensor}.  The batched counterpart of looping
+    SafeOpen.get_tensor (reference zipnn.py:1592-1626, scripts/zipnn_decompress_safetensors.py:75-120)."""
+    from safetensors import safe_open
+    from . import _capi, codec
+    dev = torch.device(device)
+    out, items, meta = {}, [], []
+    with safe_open(filename, "pt", "cpu") as f:
+        infos = get_compressed_tensors_metadata(dict(f.metadata() or {}))
+        for name in f.keys():
+            t = f.get_tensor(name)
+            if name not in infos:
+                out[name] = t.to(dev, non_blocking=True)
+                continue
+            znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
+            fp = znn.frame_params(t)
+            body = t.reshape(-1).view(torch.uint8)[fp["body_off"]:].to(dev, non_blocking=True)
+            items.append((body, fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"]))
+            meta.append((name, fp["torch_dtype"], fp["shape"]))
+    flats = codec.decompress_device_batch(_capi.lib(), items)
+    for (name, dtype, shape), flat in zip(meta, flats):
+        out[name] = flat.view(dtype).reshape(shape) if flat.numel() else torch.empty(shape, dtype=dtype, device=dev)
+    return out

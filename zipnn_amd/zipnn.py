@@ -305,6 +305,16 @@ class ZipNN:
             return _xor(plain, delta_second_data)
         return self.decompress_bin(data if mv is None else mv, target)
 
+    def frame_params(self, frame):
+        """Parse one frame's header -> what the C ABI needs to decode its body (no data work):
+        dict(body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape)."""
+        head = bytes(frame[:HEADER_LEN + 80].cpu().numpy()) if isinstance(frame, torch.Tensor) else bytes(memoryview(frame)[:HEADER_LEN + 80])
+        body_off = self._retrieve_header(head)
+        dt = dtype_from_code(self.dtype)
+        chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
+        return dict(body_off=body_off, num_buf=dt.planes, bits_mode=self._bit_reorder, bytes_mode=self._byte_reorder,
+                    chunk=chunk, orig_size=self.original_len, torch_dtype=dt.torch, shape=self.shape_bytes)
+
     def decompress_bin(self, frame, target=None):
         """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198)."""
         on_device = isinstance(frame, torch.Tensor) and frame.is_cuda
