@@ -120,6 +120,10 @@ const char* zn_last_kernels(void);
  * Synchronises the device.  Returns a count >= 0 or a negative zn_status. */
 long long zn_last_fused_chunks(void);
 
+/* Diagnostic: how many Huffman planes of partial last chunks the parallel tail kernel decoded in the last
+ * zn_decompress(_batch)_dev call (the rest of a partial chunk goes through the serial generic kernel). */
+long long zn_last_tail_planes(void);
+
 #ifdef __cplusplus
 }
 #endif

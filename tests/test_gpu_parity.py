@@ -248,3 +248,19 @@ def test_batched_decode_many_tensors(lib):
     for d, o in zip(datas, outs):
         assert o.cpu().numpy().tobytes() == d
     assert "zn_k_decode_fused" in lib.last_kernels()
+
+
+@pytest.mark.parametrize("case", [("bf16", 5 * C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 10, C, 1),
+                                  ("fp32", 2 * C + C // 2 + 4, 4, 1, 220, C, 1), ("fp8", 128 * KB + 70001, 1, 1, 10, 128 * KB, 1),
+                                  ("fp16", 3 * C - 2, 2, 0, 10, C, 1), ("skew", C + 130000, 2, 0, 10, C, 2),
+                                  ("burst", 100001, 1, 1, 10, 128 * KB, 1), ("rand", C + 30000, 2, 1, 10, C, 0)],
+                         ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
+def test_partial_last_chunk_through_the_parallel_tail_kernel(lib, case):
+    """Big partial last chunks: Huffman planes by zn_k_decode_tail (ragged streams, padded scratch), exact output."""
+    from test_kernels_simt import _gen2
+    kind, nb, P, rot, bm, chunk, want_tail_planes = case
+    d = _gen2(kind, nb, 17)
+    want = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)
+    assert bytes(lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == want
+    assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
+    assert lib.last_tail_planes() == want_tail_planes

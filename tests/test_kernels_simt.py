@@ -209,3 +209,23 @@ def test_batched_decode_matches_per_tensor_decode(simt_lib):
     for d, o in zip(datas, outs):
         assert o.numpy().tobytes() == d
     assert simt_lib.last_fused_chunks() == 3 + 2 + 1 + 5 + 4 + 2      # full chunks of the fused-eligible tensors
+
+
+TAILS = [("bf16", C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 10, C, 1), ("fp32", 2 * C + C // 2 + 4, 4, 1, 220, C, 1),
+         ("fp8", C + 20001, 1, 1, 10, C, 1), ("fp16", 3 * C - 2, 2, 0, 10, C, 1), ("skew", C + 30000, 2, 0, 10, C, 2),
+         ("burst", 40001, 1, 1, 10, C, 1), ("rand", C + 30000, 2, 1, 10, C, 0), ("bf16", C + 4000, 2, 1, 10, C, 0)]
+
+
+@pytest.mark.parametrize("case", TAILS, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
+def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
+    """A big partial last chunk: its Huffman planes are decoded by zn_k_decode_tail (4 ragged streams into padded
+    scratch), the merge kernel interleaves; tiny / raw tails stay on the serial path.  Output == input."""
+    kind, nb, P, rot, bm, chunk, want_tail_planes = case
+    d = _gen2(kind, nb, 17)
+    frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8)
+    out = torch.empty(nb, dtype=torch.uint8)
+    simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
+    assert out.numpy().tobytes() == d
+    assert "zn_k_decode_tail" in simt_lib.last_kernels()
+    assert simt_lib.last_tail_planes() == want_tail_planes

@@ -62,6 +62,7 @@ class ZnLib:
         L.zn_decompress_batch_dev.argtypes = [ctypes.POINTER(ZnBatchItem), sz, vp, ci]
         L.zn_release_workspace.restype = ci
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
+        L.zn_last_tail_planes.restype = ctypes.c_longlong
         self._L = L
         if L.zn_abi_version() != 1:
             raise ImportError(f"{path}: unexpected ABI version {L.zn_abi_version()}")
@@ -146,6 +147,13 @@ class ZnLib:
     def last_fused_chunks(self):
         """Chunks of the last decompress_dev call that took the fused single-pass kernel."""
         n = self._L.zn_last_fused_chunks()
+        if n < 0:
+            self._check(int(n))
+        return int(n)
+
+    def last_tail_planes(self):
+        """Huffman planes of partial last chunks that the parallel tail kernel decoded in the last decompress call."""
+        n = self._L.zn_last_tail_planes()
         if n < 0:
             self._check(int(n))
         return int(n)

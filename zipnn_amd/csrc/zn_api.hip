@@ -28,6 +28,7 @@ thread_local std::string t_kernels;
 // device serialise on their workspace — independent GPUs run in independent processes).
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
+  size_t last_tails = 0;         // tail planes of the last decompress call (for zn_last_tail_planes)
   void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched decode
@@ -167,7 +168,7 @@ int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int
 static int decompress_items(const zn_batch_item* items, size_t count, hipStream_t stream, int check) {
   if (count && !items) return ZN_E_ARG;
   std::vector<ZnSeg> segs[3];                    // by plane count: 1, 2, 4
-  uint64_t pk_of[3] = {0, 0, 0}, k_of[3] = {0, 0, 0}; uint64_t wg_of[3] = {0, 0, 0};
+  uint64_t pk_of[3] = {0, 0, 0}, k_of[3] = {0, 0, 0}; uint64_t wg_of[3] = {0, 0, 0}, tail_of[3] = {0, 0, 0};
   uint64_t total_chunks = 0;
   for (size_t i = 0; i < count; i++) total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk);
   const uint32_t ncg = zn_decode_fused_group(total_chunks);
@@ -182,6 +183,8 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
     sg.body = (const uint8_t*)it.d_body; sg.body_len = it.body_len; sg.dst = (uint8_t*)it.d_dst;
     sg.chunk0 = k_of[q]; sg.desc0 = pk_of[q]; sg.wg0 = (uint32_t)wg_of[q]; sg.ncg = ncg;
+    sg.tail0 = (uint32_t)tail_of[q]; sg.has_tail = (it.orig_size % it.chunk) != 0 ? 1u : 0u;   // partial last chunk
+    if (sg.has_tail) tail_of[q] += sg.g.P;
     k_of[q] += sg.g.K; pk_of[q] += (uint64_t)sg.g.P * sg.g.K; wg_of[q] += (sg.g.K + ncg - 1u) / ncg;
     if (pk_of[q] > 0x7FFFFFFFull || wg_of[q] > 0x7FFFFFFFull) return ZN_E_ARG;
     segs[q].push_back(sg);
@@ -199,6 +202,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   const bool table = nseg_all > 1;
   if ((rc = ws_reserve(w, WS_META_C, all_pk * sizeof(ZnPlaneDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_META_B, all_k))) return rc;                     // per-chunk "done by the fused kernel" flags
+  const uint64_t all_tail = tail_of[0] + tail_of[1] + tail_of[2];
+  if ((rc = ws_reserve(w, WS_PLANES, all_tail * ZN_TAIL_SLOT))) return rc;   // decoded Huffman planes of partial last chunks
+  if ((rc = ws_reserve(w, WS_META_A, all_tail))) return rc;                  // … and whether the tail kernel produced them
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
   if (table) {
@@ -211,8 +217,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   }
   if ((rc = ws_acquire(w, stream))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
-  w.last_K = all_k;
+  w.last_K = all_k; w.last_tails = all_tail;
   ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+  if (all_tail) ZN_HIP(hipMemsetAsync(w.buf[WS_META_A], 0, all_tail, stream));
   if (table) {
     // the previous batched call may still be reading the pinned staging: wait for it on the host
     ZN_HIP(hipEventSynchronize(w.busy));
@@ -220,7 +227,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     for (int q = 0; q < 3; q++) for (const ZnSeg& sg : segs[q]) w.h_segs[o++] = sg;
     ZN_HIP(hipMemcpyAsync(w.buf[WS_SEGS], w.h_segs, nseg_all * sizeof(ZnSeg), hipMemcpyHostToDevice, stream));
   }
-  size_t seg_base = 0; uint64_t k_base = 0, pk_base = 0;
+  size_t seg_base = 0; uint64_t k_base = 0, pk_base = 0, tail_base = 0;
   for (int q = 0; q < 3; q++) {
     if (segs[q].empty()) continue;
     const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
@@ -228,9 +235,12 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     const uint32_t nseg = (uint32_t)segs[q].size();
     uint8_t* d_done = (uint8_t*)w.buf[WS_META_B] + k_base;
     ZnPlaneDesc* d_descs = (ZnPlaneDesc*)w.buf[WS_META_C] + pk_base;
+    uint8_t* d_tails = (uint8_t*)w.buf[WS_PLANES] + tail_base * ZN_TAIL_SLOT;
+    uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
     zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_status, stream);
-    zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, stream);
-    seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q];
+    zn_launch_decode_tail(segs[q][0], d_segs, nseg, (uint32_t)tail_of[q], d_tails, d_tail_done, d_status, stream);
+    zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_tails, d_tail_done, stream);
+    seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
   }
   ZN_HIP(hipGetLastError());
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -309,6 +319,21 @@ long long zn_last_fused_chunks(void) {
   std::string flags(w.last_K, '\0');
   ZN_HIP(hipDeviceSynchronize());
   ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_B], w.last_K, hipMemcpyDeviceToHost));
+  long long n = 0;
+  for (char f : flags) n += (f != 0);
+  return n;
+}
+
+long long zn_last_tail_planes(void) {
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> lk(g_mu);
+  Workspace& w = g_ws[dev];
+  if (!w.last_tails || !w.buf[WS_META_A]) return 0;
+  std::string flags(w.last_tails, '\0');
+  ZN_HIP(hipDeviceSynchronize());
+  ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_A], w.last_tails, hipMemcpyDeviceToHost));
   long long n = 0;
   for (char f : flags) n += (f != 0);
   return n;

@@ -27,6 +27,9 @@
 #define ZN_KIND_RAW 0u   // type 0, or type 1 with csize == plane_len (HUF_decompress memcpy rule)
 #define ZN_KIND_RLE 1u   // type 1, csize == 1
 #define ZN_KIND_HUF 2u   // type 1, real huff0 block
+#define ZN_KIND_HUFS 3u  // huff0 block of a partial last chunk, already decoded into the tail scratch (4 padded streams)
+#define ZN_TAIL_SEGPAD 32768u            // stride of a stream inside a tail-scratch slot (a huff0 block is ≤ 128 KiB)
+#define ZN_TAIL_SLOT (4u * ZN_TAIL_SEGPAD)
 
 __device__ __forceinline__ uint32_t zn_hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 

@@ -11,7 +11,7 @@
 // chunk) index, 2 = chunk index.  Wave-uniform (scalar loads); the last segment with key ≤ b.
 // ---------------------------------------------------------------------------
 template <int KEY>
-__device__ __forceinline__ uint64_t zn_seg_key(const ZnSeg& s) { return KEY == 0 ? (uint64_t)s.wg0 : KEY == 1 ? s.desc0 : s.chunk0; }
+__device__ __forceinline__ uint64_t zn_seg_key(const ZnSeg& s) { return KEY == 0 ? (uint64_t)s.wg0 : KEY == 1 ? s.desc0 : KEY == 2 ? s.chunk0 : (uint64_t)s.tail0; }
 template <int KEY>
 __device__ __forceinline__ ZnSeg zn_find_seg(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b) {
   if (segs == nullptr) return one;

@@ -183,6 +183,42 @@ __device__ __forceinline__ void zn_fused_run(const uint32_t* lut32, const uint32
   }
 }
 
+// Decode tables of one huff0 block, by the whole workgroup: the canonical single-symbol LUT (u16, aliased into
+// staging buffer 0, idle at this point), then the multi-symbol LUT.  j = which of the group's symbol orders.
+// Contains one __syncthreads(); the caller syncs again before the staging buffers are used.
+__device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, uint32_t TL, uint32_t j) {
+  uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
+  {
+    const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
+    for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
+  }
+  __syncthreads();
+  {
+    // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
+    const uint32_t mask = (1u << TL) - 1u;
+    uint32_t pos[8], cnt[8], syms[8], ef[8], sym4[8];
+    for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; sym4[k] = 0; }
+    for (int step = 0; step < 5; step++) {
+      for (int k = 0; k < 8; k++) {
+        const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+        if (u <= mask && cnt[k] == (uint32_t)step) {
+          const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
+          if (pos[k] + len <= TL) {             // the window holds this code completely
+            if (step > 0) ef[k] |= pos[k] << (4 * (step - 1));          // E_step = where this symbol starts
+            if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
+            pos[k] += len; cnt[k]++;
+          }
+        }
+      }
+    }
+    for (int k = 0; k < 8; k++) {
+      const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+      for (uint32_t j = 1; j <= 5u; j++) if (j >= cnt[k]) ef[k] |= pos[k] << (4u * (j - 1u));   // E_j = total for j ≥ count
+      if (u <= mask) { L.lut[u] = ZN_E_META(cnt[k], ef[k], sym4[k]); L.lut[u + (1u << ZN_F_TLMAX)] = syms[k]; }
+    }
+  }
+}
+
 // Everything one wave does for its quarter of the chunk, with the Huffman plane index H known at
 // compile time (H = -1: no Huffman plane) so that register arrays are statically indexed.
 // DC: the sub-block size when it is known at compile time (the common value gets its own instance,
@@ -191,7 +227,7 @@ template <int P, int H, int DC>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
                                               const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
-                                              uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen ZN_PT_PARAM) {
+                                              uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen, bool ragged ZN_PT_PARAM) {
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
@@ -409,7 +445,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     if (!ok) break;
     ZN_PT(3);   // flush rows
   }
-  return ok && carry == b0 && J == seg && JF == seg;
+  if (ragged && ok && carry == b0 && J == seg && JF < seg) {
+    // a stream of a partial chunk: the last row is incomplete — store it whole (the destination is padded)
+    emit_rows(JF, 1, 0); JF += UNIT;
+  }
+  return ok && carry == b0 && J == seg && JF >= seg;
 }
 
 // One workgroup decodes a GROUP of up to 4 consecutive chunks.  The tree description of a huff0 block is
@@ -497,36 +537,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
       const uint8_t* src = body + h_off;
       const ZnWaveStats st = L.st[j];
       const int hs = st.hs; TL = st.tl;
-      uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
-      {
-        const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
-        for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
-      }
-      __syncthreads();
-      {
-        // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
-        const uint32_t mask = (1u << TL) - 1u;
-        uint32_t pos[8], cnt[8], syms[8], ef[8], sym4[8];
-        for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; sym4[k] = 0; }
-        for (int step = 0; step < 5; step++) {
-          for (int k = 0; k < 8; k++) {
-            const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-            if (u <= mask && cnt[k] == (uint32_t)step) {
-              const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
-              if (pos[k] + len <= TL) {             // the window holds this code completely
-                if (step > 0) ef[k] |= pos[k] << (4 * (step - 1));          // E_step = where this symbol starts
-                if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
-                pos[k] += len; cnt[k]++;
-              }
-            }
-          }
-        }
-        for (int k = 0; k < 8; k++) {
-          const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-          for (uint32_t j = 1; j <= 5u; j++) if (j >= cnt[k]) ef[k] |= pos[k] << (4u * (j - 1u));   // E_j = total for j ≥ count
-          if (u <= mask) { L.lut[u] = ZN_E_META(cnt[k], ef[k], sym4[k]); L.lut[u + (1u << ZN_F_TLMAX)] = syms[k]; }
-        }
-      }
+      zn_fused_fill_luts(L, tid, TL, j);
       // jump table → this wave's stream
       const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
       const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
@@ -551,7 +562,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
-#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen ZN_PT_PASS
+#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0>(ZN_WAVE_ARGS)
     if (h < 0) ok = zn_fused_wave<P, -1, 0>(ZN_WAVE_ARGS);
     else if (h == 0) ZN_WAVE_CASE(0);
@@ -565,6 +576,74 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     ZN_PT_COUNT(19, 1);                        // chunks
   }
   ZN_PT_FLUSH();
+}
+
+// The Huffman-coded planes of a PARTIAL last chunk: one workgroup per plane, wave w = stream w, with the same
+// parallel stream decoder (its single-plane instance), into a padded scratch slot: stream w's symbols start at
+// slot + w * ZN_TAIL_SEGPAD.  The generic merge kernel interleaves from there.  Anything unusual (raw / RLE /
+// tiny planes, tableLog 12, malformed blocks) is left to the serial generic kernel: tail_done stays 0.
+__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_tail(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+                                                                 uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done,
+                                                                 uint32_t* __restrict__ status) {
+  __shared__ ZnFusedLds L;
+  const ZnSeg S = zn_find_seg<3>(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
+  const uint8_t* body_end = body + body_len;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t p = blockIdx.x - S.tail0;
+  const uint64_t c = g.K - 1u;
+  ZN_PT_DECL;
+  const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
+  if (!(m.ok && m.type == 1u && m.csize > 1u && m.csize < m.plen && m.plen >= 4096u && m.plen <= 4u * ZN_TAIL_SEGPAD)) return;
+  const uint8_t* src = body + m.off;
+  if (wave == 0) {
+    uint8_t* tmp = (uint8_t*)&L.ring[0][0];
+    const ZnWaveStats st = zn_wave_read_stats(src, m.csize, body_end, lane, tmp, L.symlist[0], L.rank_start[0], L.sym_start[0], tmp + 512);
+    if (lane == 0) L.st[0] = st;
+  }
+  __syncthreads();
+  const ZnWaveStats st = L.st[0];
+  const int hs = st.hs; const uint32_t TL = st.tl;
+  if (hs < 0 || TL > ZN_F_TLMAX || (uint32_t)hs >= m.csize || m.csize - (uint32_t)hs < 10u) return;
+  __syncthreads();                             // (ring[0] held the parser's scratch)
+  zn_fused_fill_luts(L, tid, TL, 0);
+  const uint8_t* js = src + hs; const uint32_t rem = m.csize - (uint32_t)hs;
+  const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+  if (l1 + l2 + l3 + 6u > rem) return;
+  const uint32_t l4 = rem - 6u - l1 - l2 - l3;
+  if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) return;
+  const uint32_t seg3 = (m.plen + 3u) / 4u;
+  if (3u * seg3 >= m.plen) return;
+  const uint32_t segw = (wave < 3u) ? seg3 : m.plen - 3u * seg3;
+  const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
+  const uint8_t* stream = js + so; const uint32_t slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
+  __syncthreads();                             // lut16 (aliasing ring[0]) is dead from here on
+
+  constexpr uint32_t UNIT1 = 64u * 16u;        // row of the single-plane instance
+  ZnFusedPlane pl[1]; pl[0].off = m.off; pl[0].kind = ZN_KIND_HUF; pl[0].csize = m.csize;
+  const uint8_t* rawq[1] = {nullptr};
+  uint8_t* outq = scratch + (uint64_t)blockIdx.x * ZN_TAIL_SLOT + (uint64_t)wave * ZN_TAIL_SEGPAD;
+  uint32_t Du = ((ZN_F_RING_BYTES - UNIT1 - 128u) * slen) / (256u * segw);
+  Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+  Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
+  const bool ok = (Du == ZN_F_DCONST)
+    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
+    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
+  if (lane == 0) L.what[wave] = ok ? 1u : 0u;
+  __syncthreads();
+  if (tid == 0) {
+    if (L.what[0] & L.what[1] & L.what[2] & L.what[3]) tail_done[blockIdx.x] = 1;
+    else atomicOr(status, ZN_DEV_CORRUPT);
+  }
+  ZN_PT_FLUSH();
+}
+
+void zn_launch_decode_tail(const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_tail_wg, uint8_t* d_tail_scratch,
+                           uint8_t* d_tail_done, uint32_t* d_status, hipStream_t stream) {
+  if (total_tail_wg == 0) return;
+  hipLaunchKernelGGL(zn_k_decode_tail, dim3(total_tail_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_tail_scratch, d_tail_done, d_status);
+  zn_note_kernel("zn_k_decode_tail");
 }
 
 #ifdef ZN_PHASE_TIMERS

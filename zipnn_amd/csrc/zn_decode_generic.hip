@@ -60,7 +60,7 @@ __device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                               ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
-                                                              const uint8_t* __restrict__ done_all) {
+                                                              const uint8_t* __restrict__ done_all, const uint8_t* __restrict__ tail_done) {
   __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
   __shared__ uint8_t sh_w[256], sh_symlist[256], sh_cell[64];
   __shared__ uint32_t sh_rank_start[14], sh_sym_start[14];
@@ -91,6 +91,9 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const Z
     else { d.kind = ZN_KIND_HUF; d.off = 0; }
   }
   if (bad) { d.kind = ZN_KIND_RLE; d.off = 0; }   // keep the merge kernel in bounds; output is discarded by the caller
+  if (!bad && d.kind == ZN_KIND_HUF && S.has_tail && c == g.K - 1u && tail_done && tail_done[S.tail0 + p]) {
+    d.kind = ZN_KIND_HUFS; d.off = (uint64_t)(S.tail0 + p) * ZN_TAIL_SLOT;       // already decoded by zn_k_decode_tail
+  }
 
   if (!bad && d.kind == ZN_KIND_HUF) {
     const uint8_t* src = body + m.off;
@@ -128,15 +131,18 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const Z
 // kernel 2: merge planes of one chunk into the output
 // ---------------------------------------------------------------------------
 // byte j of the chunk = byte j / P of plane j % P; a Huffman-decoded plane already sits in `out`
-__device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const uint8_t* body, const uint8_t* out, uint32_t j, uint32_t i) {
+__device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const uint8_t* body, const uint8_t* out, const uint8_t* tails,
+                                                  uint32_t j, uint32_t i) {
   if (d.kind == ZN_KIND_RLE) return (uint32_t)d.off & 0xFFu;
   if (d.kind == ZN_KIND_HUF) return out[j];
+  if (d.kind == ZN_KIND_HUFS) { const uint32_t seg3 = (d.len + 3u) / 4u, w = i / seg3; return tails[d.off + (uint64_t)w * ZN_TAIL_SEGPAD + (i - w * seg3)]; }
   return body[d.off + i];
 }
 
 template <int P>
 __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
-                                                         const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all) {
+                                                         const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all,
+                                                         const uint8_t* __restrict__ tails) {
   const ZnSeg S = zn_find_seg<2>(one, segs, nseg, blockIdx.x);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = S.body;
@@ -155,7 +161,7 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg*
     uint32_t w = 0;
     for (uint32_t t = 0; t < 4; t++) {
       const uint32_t j = 4u * wi + t;
-      w |= zn_plane_byte(d[j % P], body, out, j, j / P) << (8 * t);
+      w |= zn_plane_byte(d[j % P], body, out, tails, j, j / P) << (8 * t);
     }
     if (g.rot) w = (P == 2) ? zn_rot_inv16(w) : zn_rot_inv32(w);
     const uint64_t a = (uint64_t)(out + 4ull * wi);
@@ -165,17 +171,18 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg*
   // trailing clen % 4 bytes are never rotated (reference rotates len/4 words only)
   if (threadIdx.x < (clen & 3u)) {
     const uint32_t j = 4u * nwords + threadIdx.x;
-    out[j] = (uint8_t)zn_plane_byte(d[j % P], body, out, j, j / P);
+    out[j] = (uint8_t)zn_plane_byte(d[j % P], body, out, tails, j, j / P);
   }
 }
 
 void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint64_t total_pk, uint64_t total_k,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, hipStream_t stream) {
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_tail_scratch,
+                              const uint8_t* d_tail_done, hipStream_t stream) {
   if (total_k == 0) return;
-  hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)total_pk), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, d_descs, d_status, d_done);
+  hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)total_pk), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, d_descs, d_status, d_done, d_tail_done);
   zn_note_kernel("zn_k_decode_planes");
-  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done);
-  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done);
+  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done, d_tail_scratch);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done, d_tail_scratch);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done, d_tail_scratch);
   zn_note_kernel("zn_k_merge_planes");
 }

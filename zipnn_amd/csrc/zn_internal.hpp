@@ -24,18 +24,25 @@ struct ZnSeg {
   uint64_t desc0;    // index of its first (plane, chunk) in descs[]                          (planes kernel grid)
   uint32_t wg0;      // its first workgroup of the fused kernel
   uint32_t ncg;      // chunks per fused workgroup
+  uint32_t tail0;    // a partial last chunk gets P workgroups of the tail kernel / P tail-scratch slots from here …
+  uint32_t has_tail; // … if this is non-zero
 };
 
 // ---- generic decode path (any dtype, any tail) : zn_decode_generic.hip ----
 // descs: Σ P·K entries; status: one device word; d_done: Σ K flags written by the fused kernel.
 // segs == nullptr: the single tensor `one`.  total_pk / total_k: grid sizes (Σ P·K, Σ K).
 void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint64_t total_pk, uint64_t total_k,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, hipStream_t stream);
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_tail_scratch,
+                              const uint8_t* d_tail_done, hipStream_t stream);
 
 // ---- fused decode path (full chunks, ≤1 Huffman plane) : zn_decode_fused.hip ----
 uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a tensor of K chunks
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint32_t* d_status, hipStream_t stream);
+// Huffman planes of partial last chunks, decoded with the parallel stream decoder into padded scratch slots
+// (ZN_TAIL_SLOT bytes per plane); tail_done[i] = 1 where that worked — the generic kernels take it from there.
+void zn_launch_decode_tail(const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_tail_wg, uint8_t* d_tail_scratch,
+                           uint8_t* d_tail_done, uint32_t* d_status, hipStream_t stream);
 
 // ---- generic encode path : zn_encode_generic.hip ----
 // Handles chunks [c0, K).  planes/enc: P*(K-c0) slots each; csize/type/offs: [P*K] (global indexing).
