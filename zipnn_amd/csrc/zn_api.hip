@@ -202,6 +202,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   const bool table = nseg_all > 1;
   if ((rc = ws_reserve(w, WS_META_C, all_pk * sizeof(ZnPlaneDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_META_B, all_k))) return rc;                     // per-chunk "done by the fused kernel" flags
+  if ((rc = ws_reserve(w, WS_ENC, all_pk))) return rc;                       // … and the same per (plane, chunk)
   const uint64_t all_tail = tail_of[0] + tail_of[1] + tail_of[2];
   if ((rc = ws_reserve(w, WS_PLANES, all_tail * ZN_TAIL_SLOT))) return rc;   // decoded Huffman planes of partial last chunks
   if ((rc = ws_reserve(w, WS_META_A, all_tail))) return rc;                  // … and whether the tail kernel produced them
@@ -237,9 +238,10 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     ZnPlaneDesc* d_descs = (ZnPlaneDesc*)w.buf[WS_META_C] + pk_base;
     uint8_t* d_tails = (uint8_t*)w.buf[WS_PLANES] + tail_base * ZN_TAIL_SLOT;
     uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
-    zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_status, stream);
+    uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
+    zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, stream);
     zn_launch_decode_tail(segs[q][0], d_segs, nseg, (uint32_t)tail_of[q], d_tails, d_tail_done, d_status, stream);
-    zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_tails, d_tail_done, stream);
+    zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
   }
   ZN_HIP(hipGetLastError());

@@ -459,7 +459,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 // that small inputs still spread over every CU).
 template <int P>
 __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
-                                                                  uint8_t* __restrict__ done_all, uint32_t* __restrict__ status) {
+                                                                  uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
+                                                                  uint32_t* __restrict__ status) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
@@ -468,6 +469,8 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
   uint8_t* __restrict__ dst = S.dst; uint8_t* __restrict__ done = done_all + S.chunk0;
+  uint8_t* __restrict__ pdone = pdone_all + S.desc0;   // the same flag per (plane, chunk)
+#define ZN_SET_DONE(c_, v_) do { if (tid == 0) done[c_] = (v_); if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -522,7 +525,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
     ZN_PT(21);  // wait for the slowest wave of the previous chunk
     const uint32_t what = L.what[j];
-    if (what == 0u) { if (tid == 0) done[c] = 0; continue; }
+    if (what == 0u) { ZN_SET_DONE(c, 0); continue; }
     const int h = (int)what - 2;
     ZnFusedPlane pl[P];
     for (int p = 0; p < P; p++) pl[p] = L.plane[j][p];
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
       __syncthreads();                         // lut16 (aliasing ring[0]) is dead from here on
       ZN_PT(2);   // LUT fill
     }
-    if (bad) { if (tid == 0) done[c] = 0; continue; }   // malformed jump table: the generic path reports it
+    if (bad) { ZN_SET_DONE(c, 0); continue; }   // malformed jump table: the generic path reports it
 
     // ---- per-wave: decode the stream tile by tile, flush rows ----
     const uint8_t* rawq[P];
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
 #undef ZN_WAVE_CASE
 #undef ZN_WAVE_ARGS
     if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
-    if (tid == 0) done[c] = 1;
+    ZN_SET_DONE(c, 1);
     ZN_PT_COUNT(19, 1);                        // chunks
   }
   ZN_PT_FLUSH();
@@ -671,10 +674,10 @@ uint32_t zn_decode_fused_group(uint64_t K) {
 }
 
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
-                            uint8_t* d_done, uint32_t* d_status, hipStream_t stream) {
+                            uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, hipStream_t stream) {
   if (total_wg == 0) return;
-  if (P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_status);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_status);
-  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_status);
+  if (P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status);
+  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status);
   zn_note_kernel("zn_k_decode_fused");
 }

@@ -58,25 +58,28 @@ __device__ inline int zn_decode_stream_serial(const uint8_t* src, uint32_t len, 
 // ---------------------------------------------------------------------------
 // kernel 1: classify + decode huff0 planes into scratch
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
-                                                              ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
-                                                              const uint8_t* __restrict__ done_all, const uint8_t* __restrict__ tail_done) {
-  __shared__ uint16_t lut[1u << ZN_HUF_LOG_MAX];
-  __shared__ uint8_t sh_w[256], sh_symlist[256], sh_cell[64];
-  __shared__ uint32_t sh_rank_start[14], sh_sym_start[14];
+struct ZnPlanesLds {
+  uint16_t lut[1u << ZN_HUF_LOG_MAX];
+  uint8_t sh_w[256], sh_symlist[256], sh_cell[64];
+  uint32_t sh_rank_start[14], sh_sym_start[14];
+};
 
-  const ZnSeg S = zn_find_seg<1>(one, segs, nseg, blockIdx.x);
+// one (plane, chunk) = launch-wide desc index b, by one wave
+__device__ void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b,
+                                     ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
+                                     const uint8_t* __restrict__ tail_done) {
+  uint16_t* lut = L.lut; uint8_t* sh_w = L.sh_w; uint8_t* sh_symlist = L.sh_symlist; uint8_t* sh_cell = L.sh_cell;
+  uint32_t* sh_rank_start = L.sh_rank_start; uint32_t* sh_sym_start = L.sh_sym_start;
+  const ZnSeg S = zn_find_seg<1>(one, segs, nseg, b);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
   uint8_t* __restrict__ dst = S.dst;
   ZnPlaneDesc* __restrict__ descs = descs_all + S.desc0;
-  const uint8_t* __restrict__ done = done_all ? done_all + S.chunk0 : nullptr;
 
   const uint32_t lane = threadIdx.x;
-  const uint64_t pc = blockIdx.x - S.desc0;
+  const uint64_t pc = b - S.desc0;
   const uint32_t p = (uint32_t)(pc / g.K);
   const uint64_t c = pc % g.K;
-  if (done && done[c]) return;                 // chunk already written by the fused kernel
   const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
   ZnPlaneDesc d; d.off = 0; d.kind = ZN_KIND_RAW; d.len = m.plen;
 
@@ -127,6 +130,31 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const Z
   if (lane == 0) descs[pc] = d;
 }
 
+// Grid-stride over the launch's (plane, chunk) entries; pdone[b] != 0: the fused kernel already wrote that chunk
+// (checked before anything else, so a launch where everything is done costs a few microseconds).
+__global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t total,
+                                                              ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
+                                                              const uint8_t* __restrict__ pdone, const uint8_t* __restrict__ tail_done) {
+  __shared__ ZnPlanesLds L;
+  __shared__ uint32_t n_todo; __shared__ uint16_t todo[ZN_WAVE];
+  // this wave's items are b = blockIdx.x + i * gridDim.x; their flags are read 64 at a time (one latency)
+  const uint64_t nit = (total > blockIdx.x) ? (total - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0;
+  for (uint64_t base = 0; base < nit; base += ZN_WAVE) {
+    if (threadIdx.x == 0) n_todo = 0;
+    __syncthreads();
+    const uint64_t i = base + threadIdx.x, b = blockIdx.x + i * gridDim.x;
+    if (i < nit && !(pdone && pdone[b])) todo[atomicAdd(&n_todo, 1u)] = (uint16_t)threadIdx.x;
+    __syncthreads();
+    const uint32_t n = n_todo;
+    for (uint32_t k = 0; k < n; k++) {
+      const uint64_t bb = blockIdx.x + (base + todo[k]) * gridDim.x;
+      __syncthreads();                         // the tables of the previous item are no longer in use
+      zn_decode_plane_item(L, one, segs, nseg, bb, descs_all, status, tail_done);
+    }
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // kernel 2: merge planes of one chunk into the output
 // ---------------------------------------------------------------------------
@@ -140,17 +168,14 @@ __device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const ui
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
-                                                         const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all,
-                                                         const uint8_t* __restrict__ tails) {
-  const ZnSeg S = zn_find_seg<2>(one, segs, nseg, blockIdx.x);
+__device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b,
+                                                    const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ tails) {
+  const ZnSeg S = zn_find_seg<2>(one, segs, nseg, b);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = S.body;
   uint8_t* dst = S.dst;
   const ZnPlaneDesc* __restrict__ descs = descs_all + S.desc0;
-  const uint8_t* __restrict__ done = done_all ? done_all + S.chunk0 : nullptr;
-  const uint64_t c = blockIdx.x - S.chunk0;
-  if (done && done[c]) return;
+  const uint64_t c = b - S.chunk0;
   const uint32_t clen = zn_chunk_len(g, c);
   uint8_t* out = dst + c * g.chunk;
   ZnPlaneDesc d[P];
@@ -175,14 +200,34 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg*
   }
 }
 
+template <int P>
+__global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t total,
+                                                         const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all,
+                                                         const uint8_t* __restrict__ tails) {
+  __shared__ uint32_t n_todo; __shared__ uint16_t todo[256];
+  // this workgroup's chunks are b = blockIdx.x + i * gridDim.x; their flags are read 256 at a time (one latency)
+  const uint64_t nit = (total > blockIdx.x) ? (total - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0;
+  for (uint64_t base = 0; base < nit; base += 256u) {
+    if (threadIdx.x == 0) n_todo = 0;
+    __syncthreads();
+    const uint64_t i = base + threadIdx.x, b = blockIdx.x + i * gridDim.x;
+    if (i < nit && !(done_all && done_all[b])) todo[atomicAdd(&n_todo, 1u)] = (uint16_t)threadIdx.x;   // not written by the fused kernel
+    __syncthreads();
+    const uint32_t n = n_todo;
+    for (uint32_t k = 0; k < n; k++) zn_merge_chunk_item<P>(one, segs, nseg, blockIdx.x + (base + todo[k]) * gridDim.x, descs_all, tails);
+    __syncthreads();
+  }
+}
+
 void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint64_t total_pk, uint64_t total_k,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_tail_scratch,
-                              const uint8_t* d_tail_done, hipStream_t stream) {
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_pdone,
+                              const uint8_t* d_tail_scratch, const uint8_t* d_tail_done, hipStream_t stream) {
   if (total_k == 0) return;
-  hipLaunchKernelGGL(zn_k_decode_planes, dim3((uint32_t)total_pk), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, d_descs, d_status, d_done, d_tail_done);
+  const uint32_t gp = (uint32_t)(total_pk < 2048u ? total_pk : 2048u), gm = (uint32_t)(total_k < 512u ? total_k : 512u);
+  hipLaunchKernelGGL(zn_k_decode_planes, dim3(gp), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, total_pk, d_descs, d_status, d_pdone, d_tail_done);
   zn_note_kernel("zn_k_decode_planes");
-  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done, d_tail_scratch);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done, d_tail_scratch);
-  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3((uint32_t)total_k), dim3(256), 0, stream, one, d_segs, nseg, d_descs, d_done, d_tail_scratch);
+  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);
   zn_note_kernel("zn_k_merge_planes");
 }

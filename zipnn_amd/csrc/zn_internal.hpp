@@ -32,13 +32,14 @@ struct ZnSeg {
 // descs: Σ P·K entries; status: one device word; d_done: Σ K flags written by the fused kernel.
 // segs == nullptr: the single tensor `one`.  total_pk / total_k: grid sizes (Σ P·K, Σ K).
 void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint64_t total_pk, uint64_t total_k,
-                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_tail_scratch,
-                              const uint8_t* d_tail_done, hipStream_t stream);
+                              ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_pdone,
+                              const uint8_t* d_tail_scratch, const uint8_t* d_tail_done, hipStream_t stream);
 
 // ---- fused decode path (full chunks, ≤1 Huffman plane) : zn_decode_fused.hip ----
 uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a tensor of K chunks
+// d_done: Σ K chunk flags; d_pdone: the same per (plane, chunk) entry (Σ P·K), for the planes kernel
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
-                            uint8_t* d_done, uint32_t* d_status, hipStream_t stream);
+                            uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, hipStream_t stream);
 // Huffman planes of partial last chunks, decoded with the parallel stream decoder into padded scratch slots
 // (ZN_TAIL_SLOT bytes per plane); tail_done[i] = 1 where that worked — the generic kernels take it from there.
 void zn_launch_decode_tail(const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_tail_wg, uint8_t* d_tail_scratch,
