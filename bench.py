@@ -138,6 +138,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    step_ms_min, step_ms_median = min(kernel_ms), sorted(kernel_ms)[len(kernel_ms) // 2]
 
     # ---- compress: same tensor, K timed steps ------------------------------------------
     for _ in range(min(args.warmup, 2)):
@@ -182,6 +183,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": decode_kernels, "avg_launch_ms": round(avg_kernel_ms, 4),
+                         "min_launch_ms": round(step_ms_min, 4), "median_launch_ms": round(step_ms_median, 4),
                          "algorithmic_bytes": n_bytes + c_payload},
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},
         }

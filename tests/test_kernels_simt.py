@@ -229,3 +229,35 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
     assert out.numpy().tobytes() == d
     assert "zn_k_decode_tail" in simt_lib.last_kernels()
     assert simt_lib.last_tail_planes() == want_tail_planes
+
+
+def test_corrupted_bodies_never_crash(simt_lib):
+    """Random damage anywhere in the body (types, cumSizes, tree descriptions, jump tables, streams), truncation
+    and over-long claims: decode either reports an error or returns (possibly different) bytes — it never crashes,
+    hangs or raises anything but the documented exceptions."""
+    r = np.random.default_rng(99)
+    cases = [("bf16", 3 * C + 5000, 2, 1, 10, C), ("fp32", 2 * C + 4, 4, 1, 220, C), ("fp8", C + 20001, 1, 1, 10, C),
+             ("skew", C + 30000, 2, 0, 10, C)]
+    for kind, nb, P, rot, bm, chunk in cases:
+        d = _gen2(kind, nb, 23)
+        body = bytearray(O.compress_frame(HDR, d, P, rot, bm, chunk)[32:])
+        K = (nb + chunk - 1) // chunk
+        meta = 9 * P * K
+        for trial in range(24):
+            b = bytearray(body)
+            mode = trial % 4
+            if mode == 0:                                   # metadata byte
+                b[int(r.integers(0, meta))] ^= int(r.integers(1, 256))
+            elif mode == 1:                                 # start of a payload block (tree description / jump table)
+                b[meta + int(r.integers(0, min(200, len(b) - meta)))] ^= int(r.integers(1, 256))
+            elif mode == 2:                                 # anywhere
+                for _ in range(8):
+                    b[int(r.integers(0, len(b)))] ^= int(r.integers(1, 256))
+            else:                                           # truncate
+                b = b[: int(r.integers(1, len(b)))]
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+            out = torch.empty(nb, dtype=torch.uint8)
+            try:
+                simt_lib.decompress_dev(t.data_ptr(), t.numel(), P, rot, bm, chunk, nb, out.data_ptr())
+            except (RuntimeError, MemoryError, ValueError):
+                pass

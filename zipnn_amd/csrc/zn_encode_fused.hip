@@ -173,7 +173,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, cons
 struct ZnTablesLds {
   ZnTabScratch S;
   ZnHNode nodes[513];
-  uint32_t go, hdr, cs;
+  uint32_t go, hdr, cs, hl;
 };
 
 __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nfull, float threshold, uint32_t* __restrict__ csize_out,
@@ -204,8 +204,9 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
   // count and smaller symbol value).  Only symbols that occur can sort before one that occurs, so the
   // candidates are walked through the ballot masks (wave-uniform broadcast with v_readlane); symbols that
   // do not occur follow in symbol order.
+  uint32_t nz_total = 0;                         // symbols that occur
   {
-    uint64_t nzm[4]; uint32_t nz_total = 0;
+    uint64_t nzm[4];
     for (int k = 0; k < 4; k++) { nzm[k] = __ballot(cnt[k] != 0); nz_total += (uint32_t)__popcll(nzm[k]); }
     uint32_t rank[4] = {0, 0, 0, 0};
     for (int k2 = 0; k2 < 4; k2++) {
@@ -228,11 +229,46 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
   }
   __syncthreads();
   ZN_PT(2);   // counts + sort
+  // serial: the tree over the sorted leaves, code lengths, first code value of every length
   if (lane == 0) {
-    uint32_t huff_log = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
-    huff_log = zn_huf_build_from_sorted(&L.S, L.nodes, max_sv, huff_log);
-    ZN_PT(5);   // tree + code lengths + values
-    const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log);
+    const uint32_t hl0 = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
+    L.hl = zn_huf_tree_from_sorted(&L.S, L.nodes, (int)nz_total - 1, hl0);
+  }
+  __syncthreads();
+  ZN_PT(5);   // tree + code lengths
+  const uint32_t huff_log = L.hl;
+  // parallel: code length of every symbol (sorted position → symbol), zero beyond the highest symbol
+  for (int k = 0; k < 4; k++) {
+    const uint32_t i = lane + 64u * (uint32_t)k;
+    if (i <= max_sv) L.S.nbits[L.nodes[1u + i].byte] = L.nodes[1u + i].nb;
+    else { L.S.nbits[i] = 0; L.S.vals[i] = 0; }
+  }
+  __syncthreads();
+  // parallel: canonical values (symbols of one length in symbol order), huff0 weights and their histogram
+  {
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+    uint32_t run[13], wc[13];
+    for (int v = 0; v < 13; v++) { run[v] = 0; wc[v] = 0; }
+    for (int k = 0; k < 4; k++) {
+      const uint32_t sym = lane + 64u * (uint32_t)k;
+      const uint32_t nb = (sym <= max_sv) ? (uint32_t)L.S.nbits[sym] : 0xFFu;
+      const uint32_t w = (sym < max_sv) ? (nb ? huff_log + 1u - nb : 0u) : 0xFFu;     // the last symbol's weight is implied
+      if (sym < max_sv) L.S.weights[sym] = (uint8_t)w;
+      for (uint32_t v = 0; v < 13u; v++) {
+        const uint64_t m = __ballot(nb == v);
+        if (nb == v) L.S.vals[sym] = (uint16_t)((uint32_t)L.S.val_rank[v] + run[v] + (uint32_t)__popcll(m & lt));
+        run[v] += (uint32_t)__popcll(m);
+        wc[v] += (uint32_t)__popcll(__ballot(w == v));
+      }
+    }
+    for (uint32_t v = 0; v < 13u; v++) if (lane == v) L.S.wcount[v] = wc[v];
+    if (lane == 13u) L.S.wcount[13] = 0;
+  }
+  __syncthreads();
+  ZN_PT(9);   // values + weights
+  // serial: the tree description
+  if (lane == 0) {
+    const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log, true);
     ZN_PT(6);   // tree description
     uint32_t go = 0, cs = 0;
     if (h < 0) cs = 0xFFFFFFFFu;               // huff0 error → fails the threshold test → raw
@@ -240,7 +276,6 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nful
     else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u) cs = 0;
     else go = 1;
     L.go = go; L.hdr = (uint32_t)(h > 0 ? h : 0); L.cs = cs;
-    for (uint32_t s = max_sv + 1u; s < 256u; s++) { L.S.nbits[s] = 0; L.S.vals[s] = 0; }
   }
   __syncthreads();
   ZN_PT(7);   // hand-over from the serial lane

@@ -118,11 +118,11 @@ __device__ inline uint32_t zn_huf_build_ctable(ZnTabScratch* S, ZnHNode* tab0, u
   return zn_huf_build_from_sorted(S, tab0, max_sv, max_nb_bits);
 }
 
-__device__ inline uint32_t zn_huf_build_from_sorted(ZnTabScratch* S, ZnHNode* tab0, uint32_t max_sv, uint32_t max_nb_bits) {
+// The serial core: tree over the leaves tab0[1 .. 1 + non_null] (sorted, counts > 0), code lengths (height-
+// limited), and the first code value of every length in S->val_rank.  Returns the maximum code length.
+__device__ inline uint32_t zn_huf_tree_from_sorted(ZnTabScratch* S, ZnHNode* tab0, int non_null, uint32_t max_nb_bits) {
   const int START = 256;
   ZnHNode* node = tab0 + 1;
-  int non_null = (int)max_sv;
-  while (node[non_null].count == 0) non_null--;
   int low_s = non_null, node_nb = START, low_n = START;
   const int root = node_nb + low_s - 1;
   node[node_nb].count = node[low_s].count + node[low_s - 1].count;
@@ -145,7 +145,16 @@ __device__ inline uint32_t zn_huf_build_from_sorted(ZnTabScratch* S, ZnHNode* ta
   for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) { per_rank[i] = 0; val_rank[i] = 0; }
   for (int n = 0; n <= non_null; n++) per_rank[node[n].nb]++;
   { uint16_t mn = 0; for (int n = (int)max_nb_bits; n > 0; n--) { val_rank[n] = mn; mn = (uint16_t)(mn + per_rank[n]); mn >>= 1; } }
-  for (int n = 0; n <= (int)max_sv; n++) S->nbits[node[n].byte] = node[n].nb;
+  return max_nb_bits;
+}
+
+__device__ inline uint32_t zn_huf_build_from_sorted(ZnTabScratch* S, ZnHNode* tab0, uint32_t max_sv, uint32_t max_nb_bits) {
+  ZnHNode* node = tab0 + 1;
+  int non_null = (int)max_sv;
+  while (node[non_null].count == 0) non_null--;
+  max_nb_bits = zn_huf_tree_from_sorted(S, tab0, non_null, max_nb_bits);
+  uint16_t* val_rank = S->val_rank;
+  for (int n = 0; n <= (int)max_sv; n++) S->nbits[node[n].byte] = node[n].nb;      // (symbols that do not occur: nb 0)
   for (int n = 0; n <= (int)max_sv; n++) S->vals[n] = val_rank[S->nbits[n]]++;
   return max_nb_bits;
 }
@@ -221,12 +230,15 @@ __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_
 
 // HUF_compressWeights: weights w[0..nw) -> dst.  0 = not compressible, 1 = single value,
 // >1 = size (1000 = "too long to be kept"), -1 = error.
-__device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint8_t* w, uint32_t nw) {
+// pre: S->wcount already holds the histogram of w[0..nw) (filled in parallel by the caller).
+__device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint8_t* w, uint32_t nw, bool pre = false) {
   uint32_t* count = S->wcount;
   uint32_t max_sv = ZN_HUF_LOG_MAX, max_c = 0;
   if (nw <= 1) return 0;
-  for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) count[i] = 0;
-  for (uint32_t i = 0; i < nw; i++) count[w[i]]++;
+  if (!pre) {
+    for (uint32_t i = 0; i <= ZN_HUF_LOG_MAX; i++) count[i] = 0;
+    for (uint32_t i = 0; i < nw; i++) count[w[i]]++;
+  }
   while (count[max_sv] == 0) max_sv--;
   for (uint32_t i = 0; i <= max_sv; i++) if (count[i] > max_c) max_c = count[i];
   if (max_c == nw) return 1;
@@ -319,12 +331,13 @@ __device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uin
 }
 
 // HUF_writeCTable: S->nbits -> S->hdr.  Returns header size, or -1 (caller stores the plane raw).
-__device__ inline int zn_huf_write_ctable(ZnTabScratch* S, uint32_t max_sv, uint32_t huff_log) {
+// pre: S->weights[0..max_sv) and their histogram S->wcount are already filled (in parallel, by the caller).
+__device__ inline int zn_huf_write_ctable(ZnTabScratch* S, uint32_t max_sv, uint32_t huff_log, bool pre = false) {
   uint8_t* w = S->weights; uint8_t* op = S->hdr;
-  for (uint32_t n = 0; n < max_sv; n++) w[n] = S->nbits[n] ? (uint8_t)(huff_log + 1u - S->nbits[n]) : 0;
+  if (!pre) for (uint32_t n = 0; n < max_sv; n++) w[n] = S->nbits[n] ? (uint8_t)(huff_log + 1u - S->nbits[n]) : 0;
   {
     // an FSE description is only kept when shorter than maxSV/2 ≤ 127 bytes
-    const int h = zn_huf_compress_weights(S, op + 1, 140, w, max_sv);
+    const int h = zn_huf_compress_weights(S, op + 1, 140, w, max_sv, pre);
     if (h < 0) return -1;
     if (h > 1 && (uint32_t)h < max_sv / 2u) { op[0] = (uint8_t)h; return h + 1; }
   }
