@@ -168,7 +168,8 @@ __device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const ui
 }
 
 template <int P>
-__device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b,
+#define ZN_MERGE_SUB 16u      // a chunk is merged by 16 workgroup-items (one not-done chunk = a partial tail should not take 250 µs)
+__device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b, uint32_t sub,
                                                     const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ tails) {
   const ZnSeg S = zn_find_seg<2>(one, segs, nseg, b);
   const ZnGeom g = S.g;
@@ -182,7 +183,8 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
   for (int p = 0; p < P; p++) d[p] = descs[(uint64_t)p * g.K + c];
   const uint32_t nwords = clen / 4u;
   // whole 32-bit words: gather P-way, undo the rotate (applies to clen/4 words — all of them)
-  for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
+  const uint32_t w_lo = (uint32_t)(((uint64_t)nwords * sub) / ZN_MERGE_SUB), w_hi = (uint32_t)(((uint64_t)nwords * (sub + 1u)) / ZN_MERGE_SUB);
+  for (uint32_t wi = w_lo + threadIdx.x; wi < w_hi; wi += blockDim.x) {
     uint32_t w = 0;
     for (uint32_t t = 0; t < 4; t++) {
       const uint32_t j = 4u * wi + t;
@@ -194,7 +196,7 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
     else for (uint32_t t = 0; t < 4; t++) out[4ull * wi + t] = (uint8_t)(w >> (8 * t));
   }
   // trailing clen % 4 bytes are never rotated (reference rotates len/4 words only)
-  if (threadIdx.x < (clen & 3u)) {
+  if (sub == ZN_MERGE_SUB - 1u && threadIdx.x < (clen & 3u)) {
     const uint32_t j = 4u * nwords + threadIdx.x;
     out[j] = (uint8_t)zn_plane_byte(d[j % P], body, out, tails, j, j / P);
   }
@@ -205,16 +207,21 @@ __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg*
                                                          const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all,
                                                          const uint8_t* __restrict__ tails) {
   __shared__ uint32_t n_todo; __shared__ uint16_t todo[256];
-  // this workgroup's chunks are b = blockIdx.x + i * gridDim.x; their flags are read 256 at a time (one latency)
-  const uint64_t nit = (total > blockIdx.x) ? (total - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0;
+  // items = (chunk, sixteenth); this workgroup's items are it = blockIdx.x + i * gridDim.x; the chunks' flags are
+  // read 256 at a time (one latency)
+  const uint64_t items = total * ZN_MERGE_SUB;
+  const uint64_t nit = (items > blockIdx.x) ? (items - blockIdx.x + gridDim.x - 1u) / gridDim.x : 0;
   for (uint64_t base = 0; base < nit; base += 256u) {
     if (threadIdx.x == 0) n_todo = 0;
     __syncthreads();
-    const uint64_t i = base + threadIdx.x, b = blockIdx.x + i * gridDim.x;
-    if (i < nit && !(done_all && done_all[b])) todo[atomicAdd(&n_todo, 1u)] = (uint16_t)threadIdx.x;   // not written by the fused kernel
+    const uint64_t i = base + threadIdx.x, it = blockIdx.x + i * gridDim.x;
+    if (i < nit && !(done_all && done_all[it / ZN_MERGE_SUB])) todo[atomicAdd(&n_todo, 1u)] = (uint16_t)threadIdx.x;   // not written by the fused kernel
     __syncthreads();
     const uint32_t n = n_todo;
-    for (uint32_t k = 0; k < n; k++) zn_merge_chunk_item<P>(one, segs, nseg, blockIdx.x + (base + todo[k]) * gridDim.x, descs_all, tails);
+    for (uint32_t k = 0; k < n; k++) {
+      const uint64_t it2 = blockIdx.x + (base + todo[k]) * gridDim.x;
+      zn_merge_chunk_item<P>(one, segs, nseg, it2 / ZN_MERGE_SUB, (uint32_t)(it2 % ZN_MERGE_SUB), descs_all, tails);
+    }
     __syncthreads();
   }
 }
@@ -223,7 +230,7 @@ void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint
                               ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_pdone,
                               const uint8_t* d_tail_scratch, const uint8_t* d_tail_done, hipStream_t stream) {
   if (total_k == 0) return;
-  const uint32_t gp = (uint32_t)(total_pk < 2048u ? total_pk : 2048u), gm = (uint32_t)(total_k < 512u ? total_k : 512u);
+  const uint32_t gp = (uint32_t)(total_pk < 2048u ? total_pk : 2048u), gm = (uint32_t)(total_k * ZN_MERGE_SUB < 1024u ? total_k * ZN_MERGE_SUB : 1024u);
   hipLaunchKernelGGL(zn_k_decode_planes, dim3(gp), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, total_pk, d_descs, d_status, d_pdone, d_tail_done);
   zn_note_kernel("zn_k_decode_planes");
   if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);

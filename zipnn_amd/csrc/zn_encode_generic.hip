@@ -30,35 +30,118 @@ __global__ __launch_bounds__(256) void zn_k_split_planes(ZnGeom g, uint64_t c0, 
   uint8_t* pl[P];
   for (int p = 0; p < P; p++) pl[p] = planes + ((uint64_t)p * KL + (c - c0)) * slot;
   const bool aligned = (((uint64_t)in) & 3u) == 0;
-  for (uint32_t wi = threadIdx.x; wi < nwords; wi += blockDim.x) {
+  // gridDim.y workgroups share a chunk (a lone partial chunk should not take 80 µs on one CU)
+  const uint32_t w_lo = (uint32_t)(((uint64_t)nwords * blockIdx.y) / gridDim.y), w_hi = (uint32_t)(((uint64_t)nwords * (blockIdx.y + 1u)) / gridDim.y);
+  for (uint32_t wi = w_lo + threadIdx.x; wi < w_hi; wi += blockDim.x) {
     uint32_t w = aligned ? *(const uint32_t*)(in + 4ull * wi) : zn_ld32(in + 4ull * wi);
     if (g.rot) w = (P == 2) ? zn_rot_fwd16(w) : zn_rot_fwd32(w);
     for (uint32_t t = 0; t < 4; t++) { const uint32_t j = 4u * wi + t; pl[j % P][j / P] = (uint8_t)(w >> (8 * t)); }
   }
-  if (threadIdx.x < (clen & 3u)) { const uint32_t j = 4u * nwords + threadIdx.x; pl[j % P][j / P] = in[j]; }
+  if (blockIdx.y == gridDim.y - 1u && threadIdx.x < (clen & 3u)) { const uint32_t j = 4u * nwords + threadIdx.x; pl[j % P][j / P] = in[j]; }
 }
 
 // ---------------------------------------------------------------------------
 // kernel 2: per-plane huff0 encode
 // ---------------------------------------------------------------------------
-// total code bits of src[0..n) (without the end mark)
-__device__ inline uint32_t zn_stream_bits(const uint8_t* src, uint32_t n, const uint8_t* nbits) {
+typedef struct __attribute__((aligned(1))) { uint32_t x, y, z, w; } zn_g128u;
+typedef uint32_t __attribute__((aligned(1))) zn_g32u;
+
+// total code bits of src[0..n) (without the end mark), by the whole wave
+__device__ inline uint32_t zn_stream_bits_wave(const uint8_t* src, uint32_t n, const uint8_t* nbits, uint32_t lane) {
   uint32_t t = 0;
-  for (uint32_t i = 0; i < n; i++) t += nbits[src[i]];
+  const uint32_t nv = n / 16u;
+  for (uint32_t v = lane; v < nv; v += ZN_WAVE) {
+    const zn_g128u x = *(const zn_g128u*)(src + 16u * v);
+    const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+    for (int k = 0; k < 4; k++) for (int b = 0; b < 4; b++) t += nbits[(d[k] >> (8 * b)) & 0xFFu];
+  }
+  for (uint32_t i = 16u * nv + lane; i < n; i += ZN_WAVE) t += nbits[src[i]];
+  for (int d = 32; d >= 1; d >>= 1) t += __shfl_xor(t, d);
   return t;
 }
-// codes of src[n-1] .. src[0], end mark, zero pad, LSB-first into dst (nbytes known in advance)
-__device__ inline void zn_encode_stream_serial(uint8_t* dst, const uint8_t* src, uint32_t n, const uint8_t* nbits,
-                                               const uint16_t* vals) {
-  uint64_t acc = 0; uint32_t nacc = 0, o = 0;
-  for (uint32_t i = n; i-- > 0;) {
-    const uint32_t s = src[i];
-    acc |= (uint64_t)vals[s] << nacc; nacc += nbits[s];
-    while (nacc >= 8) { dst[o++] = (uint8_t)acc; acc >>= 8; nacc -= 8; }
+
+// wave-wide exclusive prefix sum (DPP), *total = sum
+__device__ __forceinline__ uint32_t zn_gen_excl_scan(uint32_t v, uint32_t* total) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+  return (uint32_t)x - v;
+}
+
+// One huff0 stream, by the whole wave: codes of src[n-1] .. src[0], end mark, zero pad, LSB-first into dst
+// (nbytes = the stream size, known in advance).  Tiles of 2048 symbols from the END of the segment; a lane packs
+// 32 consecutive symbols (pairs, then quads of ≤ 44 bits), a prefix sum of the bit counts places the lanes (lane 63
+// lowest), ds_or merges them in the tile buffer `buf` (≥ 772 dwords of LDS), whole dwords go out.
+#define ZN_G_BUF_DW 772
+__device__ inline void zn_encode_stream_wave(uint8_t* dst, uint32_t nbytes, const uint8_t* src, uint32_t n, const uint8_t* nbits,
+                                             const uint16_t* vals, uint32_t* buf, uint32_t lane) {
+  for (uint32_t i = lane; i < ZN_G_BUF_DW; i += ZN_WAVE) buf[i] = 0;
+  __syncthreads();
+  uint32_t carry = 0, written = 0;
+  const uint32_t ntiles = (n + 2047u) / 2048u;
+  for (uint32_t t = 0; t < ntiles; t++) {
+    // this lane's symbols: indices first .. first + 31, first may be negative in the segment's first tile
+    const int32_t first = (int32_t)n - 2048 * (int32_t)(t + 1u) + 32 * (int32_t)lane;
+    uint8_t sy[32];
+    if (first >= 0) {
+      const zn_g128u a = *(const zn_g128u*)(src + first), b = *(const zn_g128u*)(src + first + 16);
+      const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      for (int e = 0; e < 32; e++) sy[e] = (uint8_t)(d[e >> 2] >> (8 * (e & 3)));
+    } else {
+      for (int e = 0; e < 32; e++) { const int32_t i = first + e; sy[e] = (i >= 0) ? src[i] : 0; }
+    }
+    uint64_t qv[8]; uint32_t qn[8];
+    for (int i = 0; i < 8; i++) {
+      uint32_t pv[2], pn[2];
+      for (int h = 0; h < 2; h++) {
+        uint32_t v[2], l[2];
+        for (int u = 0; u < 2; u++) {
+          const int e = 4 * i + 2 * h + u;
+          const bool valid = first + e >= 0;
+          v[u] = valid ? (uint32_t)vals[sy[e]] : 0u; l[u] = valid ? (uint32_t)nbits[sy[e]] : 0u;
+        }
+        pv[h] = (v[0] << l[1]) | v[1]; pn[h] = l[0] + l[1];      // the later symbol takes the lower bits
+      }
+      qv[i] = ((uint64_t)pv[0] << pn[1]) | pv[1]; qn[i] = pn[0] + pn[1];
+    }
+    uint32_t qo[8]; uint32_t T = 0;
+    for (int i = 7; i >= 0; i--) { qo[i] = T; T += qn[i]; }
+    uint32_t total = 0;
+    const uint32_t excl = zn_gen_excl_scan(T, &total);
+    const uint32_t bpos = carry + (total - excl - T);
+    for (int i = 0; i < 8; i++) {
+      const uint32_t bp = bpos + qo[i], idx = bp >> 5, sh = bp & 31u;
+      const uint64_t lo = qv[i] << sh;
+      atomicOr(&buf[idx], (uint32_t)lo);
+      atomicOr(&buf[idx + 1u], (uint32_t)(lo >> 32));
+      atomicOr(&buf[idx + 2u], (uint32_t)(((qv[i] >> 32) << sh) >> 32));
+    }
+    __syncthreads();
+    const uint32_t bits = carry + total, nd = bits >> 5;
+    uint32_t tail = 0;
+    for (uint32_t i = lane; i <= nd; i += ZN_WAVE) {
+      const uint32_t x = buf[i];
+      if (i < nd && written + 4u * i + 4u <= nbytes) *(zn_g32u*)(dst + written + 4u * i) = x;
+      if (i == nd) tail = x;
+      buf[i] = 0;
+    }
+    tail = __shfl(tail, (int)(nd & 63u));
+    __syncthreads();
+    if (lane == 0) buf[0] = tail;
+    __syncthreads();
+    written += 4u * nd; carry = bits & 31u;
   }
-  acc |= 1ull << nacc; nacc += 1;
-  while (nacc >= 8) { dst[o++] = (uint8_t)acc; acc >>= 8; nacc -= 8; }
-  if (nacc) dst[o++] = (uint8_t)acc;
+  if (lane == 0) {
+    const uint32_t x = buf[0] | (1u << carry);             // end mark; the stream ends in a non-zero byte
+    const uint32_t nb = (carry + 1u + 7u) >> 3;
+    for (uint32_t k = 0; k < nb && written + k < nbytes; k++) dst[written + k] = (uint8_t)(x >> (8 * k));
+  }
+  __syncthreads();
 }
 
 __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ planes,
@@ -67,6 +150,7 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t
   __shared__ ZnTabScratch S;
   __shared__ ZnHNode nodes[513];
   __shared__ uint32_t sh_hdr, sh_go, sh_bits[4];
+  __shared__ uint32_t sh_buf[ZN_G_BUF_DW];
 
   const uint32_t lane = threadIdx.x;
   const uint64_t KL = g.K - c0, pcl = blockIdx.x;              // local (scratch) index
@@ -80,7 +164,15 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t
 
   for (uint32_t i = lane; i < 256u; i += ZN_WAVE) S.count[i] = 0;
   __syncthreads();
-  for (uint32_t i = lane; i < n; i += ZN_WAVE) atomicAdd(&S.count[src[i]], 1u);
+  {
+    const uint32_t nv = n / 16u;                       // (scratch planes start 16-byte aligned)
+    for (uint32_t v = lane; v < nv; v += ZN_WAVE) {
+      const uint4 x = *(const uint4*)(src + 16u * v);
+      const uint32_t d[4] = {x.x, x.y, x.z, x.w};
+      for (int k = 0; k < 4; k++) for (int b = 0; b < 4; b++) atomicAdd(&S.count[(d[k] >> (8 * b)) & 0xFFu], 1u);
+    }
+    for (uint32_t i = 16u * nv + lane; i < n; i += ZN_WAVE) atomicAdd(&S.count[src[i]], 1u);
+  }
   __syncthreads();
 
   // HUF_compress_internal control flow, lane 0
@@ -113,9 +205,10 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t
   if (sh_go) {
     const uint32_t hdr = sh_hdr;
     const uint32_t seg = (n + 3u) / 4u;
-    if (lane < 4) {
-      const uint32_t len = (lane < 3) ? seg : n - 3u * seg;
-      sh_bits[lane] = zn_stream_bits(src + lane * seg, len, S.nbits) + 1u;   // + end mark
+    for (uint32_t q = 0; q < 4u; q++) {
+      const uint32_t len = (q < 3u) ? seg : n - 3u * seg;
+      const uint32_t t = zn_stream_bits_wave(src + q * seg, len, S.nbits, lane);
+      if (lane == 0) sh_bits[q] = t + 1u;                                    // + end mark
     }
     __syncthreads();
     // sizes, capacity rule of BIT_closeCStream, and the final "did it shrink" test
@@ -131,9 +224,9 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t
     if (keep) {
       for (uint32_t i = lane; i < hdr; i += ZN_WAVE) dst[i] = S.hdr[i];
       if (lane < 3) { dst[hdr + 2u * lane] = (uint8_t)sz[lane]; dst[hdr + 2u * lane + 1u] = (uint8_t)(sz[lane] >> 8); }
-      if (lane < 4) {
-        const uint32_t len = (lane < 3) ? seg : n - 3u * seg;
-        zn_encode_stream_serial(dst + start[lane], src + lane * seg, len, S.nbits, S.vals);
+      for (uint32_t q = 0; q < 4u; q++) {
+        const uint32_t len = (q < 3u) ? seg : n - 3u * seg;
+        zn_encode_stream_wave(dst + start[q], sz[q], src + q * seg, len, S.nbits, S.vals, sh_buf, lane);
       }
     }
     if (lane == 0) csize_out[pc] = cs;
@@ -236,7 +329,8 @@ __global__ __launch_bounds__(256) void zn_k_gather_payload(ZnGeom g, uint64_t c0
   const uint8_t* s = (type[pc] ? enc : planes) + pcl * slot;
   uint8_t* d = body + offs[pc];
   const uint32_t n = csize[pc];
-  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[i] = s[i];
+  const uint32_t lo = (uint32_t)(((uint64_t)n * blockIdx.y) / gridDim.y), hi = (uint32_t)(((uint64_t)n * (blockIdx.y + 1u)) / gridDim.y);
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = s[i];
 }
 
 void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t* d_src, float threshold, uint8_t* d_planes,
@@ -244,9 +338,9 @@ void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t*
   if (c0 >= g.K) return;
   const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
   const uint32_t KL = (uint32_t)(g.K - c0), PKL = (uint32_t)g.P * KL;
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_split_planes<1>, dim3(KL), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_split_planes<2>, dim3(KL), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
-  else hipLaunchKernelGGL(zn_k_split_planes<4>, dim3(KL), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+  if (g.P == 1) hipLaunchKernelGGL(zn_k_split_planes<1>, dim3(KL, 16), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+  else if (g.P == 2) hipLaunchKernelGGL(zn_k_split_planes<2>, dim3(KL, 16), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+  else hipLaunchKernelGGL(zn_k_split_planes<4>, dim3(KL, 16), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
   zn_note_kernel("zn_k_split_planes");
   hipLaunchKernelGGL(zn_k_encode_planes, dim3(PKL), dim3(ZN_WAVE), 0, stream, g, c0, d_planes, d_enc, slot, threshold, d_csize, d_type);
   zn_note_kernel("zn_k_encode_planes");
@@ -269,6 +363,6 @@ void zn_launch_encode_generic_gather(const ZnGeom& g, uint64_t c0, const uint8_t
   if (c0 >= g.K) return;
   const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
   const uint32_t PKL = (uint32_t)(g.P * (g.K - c0));
-  hipLaunchKernelGGL(zn_k_gather_payload, dim3(PKL), dim3(256), 0, stream, g, c0, d_planes, d_enc, slot, d_csize, d_type, d_offs, d_body);
+  hipLaunchKernelGGL(zn_k_gather_payload, dim3(PKL, 16), dim3(256), 0, stream, g, c0, d_planes, d_enc, slot, d_csize, d_type, d_offs, d_body);
   zn_note_kernel("zn_k_gather_payload");
 }
