@@ -1,0 +1,18 @@
+#!/usr/bin/env python
+"""PCIe-inclusive rate of the host-buffer entry points (zn_compress / zn_decompress with pageable host memory)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from zipnn_amd import _capi
+lib = _capi.lib()
+n = 1 << 30
+x = (torch.randn(n // 2, device="cuda") * 0.02).to(torch.bfloat16).cpu().view(torch.uint8).numpy()
+hdr = bytes(32)
+frame = lib.compress(hdr, x, 2, 1, 10, 262144, 0.95)
+back = lib.decompress(memoryview(frame)[32:], 2, 1, 10, 262144, n)
+assert bytes(back[:4096]) == x[:4096].tobytes() and len(back) == n
+for name, fn in (("compress", lambda: lib.compress(hdr, x, 2, 1, 10, 262144, 0.95)), ("decompress", lambda: lib.decompress(memoryview(frame)[32:], 2, 1, 10, 262144, n))):
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t0)
+    print(f"host-buffer {name}: 1 GiB bf16 in {best * 1e3:.1f} ms = {n / best / 1e9:.1f} GB/s (pageable host memory, PCIe both ways)")

@@ -95,31 +95,30 @@ class ZnLib:
 
     # -- host buffers --------------------------------------------------------------------
     def compress(self, header, data, num_buf, bits_mode, bytes_mode, chunk, threshold, device=0):
-        """header/data: bytes-like (not modified). Returns a bytearray holding the frame."""
+        """header/data: bytes-like (not modified).  Returns the frame as a writable memoryview over an
+        uninitialised numpy buffer (a zero-filled 1 GiB bytearray alone costs 180 ms)."""
         hv = memoryview(header).cast("B")
         dv = memoryview(data).cast("B")
         n = dv.nbytes
         cap = self._L.zn_compress_bound(n, num_buf, chunk, hv.nbytes)
-        out = bytearray(max(cap, 1))
+        out = np.empty(max(cap, 1), dtype=np.uint8)
         out_len = ctypes.c_size_t(0)
         hb = (ctypes.c_char * max(hv.nbytes, 1)).from_buffer_copy(hv.tobytes() or b"\0")
         src = _as_c_buffer(dv)
         rc = self._L.zn_compress(ctypes.addressof(hb), hv.nbytes, src.addr, n, num_buf, bits_mode, bytes_mode, chunk,
-                                 threshold, device, _addr_of_bytearray(out), cap, ctypes.byref(out_len))
+                                 threshold, device, out.ctypes.data, cap, ctypes.byref(out_len))
         self._check(rc)
-        del out[out_len.value:]
-        return out
+        return memoryview(out)[:out_len.value]
 
     def decompress(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, device=0):
-        """body: bytes-like after the header. Returns a bytearray of orig_size bytes."""
+        """body: bytes-like after the header.  Returns orig_size bytes as a writable memoryview (numpy-backed)."""
         bv = memoryview(body).cast("B")
-        out = bytearray(max(orig_size, 1))
+        out = np.empty(max(orig_size, 1), dtype=np.uint8)
         src = _as_c_buffer(bv)
         rc = self._L.zn_decompress(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, device,
-                                   _addr_of_bytearray(out))
+                                   out.ctypes.data)
         self._check(rc)
-        del out[orig_size:]
-        return out
+        return memoryview(out)[:orig_size]
 
     # -- device pointers (ints), used by zipnn_amd.codec with torch tensors -----------------
     def compress_dev(self, src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap, stream=0):

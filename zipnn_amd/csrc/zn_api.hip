@@ -29,17 +29,18 @@ thread_local std::string t_kernels;
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
   size_t last_tails = 0;         // tail planes of the last decompress call (for zn_last_tail_planes)
-  void* buf[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  void* buf[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched decode
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
 };
-enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_COUNT };
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_COUNT };
 
 std::mutex g_mu;
 Workspace g_ws[64];
+std::mutex g_host_mu[64];     // serialises the host-buffer entry points of a device (they share two staging buffers)
 
 int ws_reserve(Workspace& w, int slot, size_t bytes) {
   if (bytes == 0) bytes = 16;
@@ -274,9 +275,20 @@ int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int 
   if (zn_device_count() <= 0) return ZN_E_NODEV;
   ZN_HIP(hipSetDevice(device));
   const size_t bound = zn_compress_bound(n, num_buf, chunk, 0);
+  // device staging for host buffers: cached with the workspace (grow-only), one host-path call at a time per device
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> hk(g_host_mu[dev]);
   void* d_src = nullptr; void* d_body = nullptr;
-  hipError_t e1 = hipMalloc(&d_src, n ? n : 16), e2 = hipMalloc(&d_body, bound ? bound : 16);
-  if (e1 != hipSuccess || e2 != hipSuccess) { if (d_src) (void)hipFree(d_src); if (d_body) (void)hipFree(d_body); (void)hipGetLastError(); return ZN_E_ALLOC; }
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace& w = g_ws[dev];
+    int rc0;
+    if ((rc0 = ws_reserve(w, WS_HOST_IN, n ? n : 16))) return rc0;
+    if ((rc0 = ws_reserve(w, WS_HOST_OUT, bound ? bound : 16))) return rc0;
+    d_src = w.buf[WS_HOST_IN]; d_body = w.buf[WS_HOST_OUT];
+  }
   int rc = ZN_OK; size_t body_len = 0;
   do {
     if (n && hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
@@ -288,7 +300,6 @@ int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int 
     *dst_len = hdr_len + body_len;
     if (hdr_len >= 32) { const uint64_t total = *dst_len; memcpy((uint8_t*)dst + 24, &total, 8); }   // zipnn_core.c:121
   } while (0);
-  (void)hipFree(d_src); (void)hipFree(d_body);
   return rc;
 }
 
@@ -297,9 +308,19 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
   if ((body_len && !body) || (orig_size && !dst)) return ZN_E_ARG;
   if (zn_device_count() <= 0) return ZN_E_NODEV;
   ZN_HIP(hipSetDevice(device));
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> hk(g_host_mu[dev]);
   void* d_body = nullptr; void* d_dst = nullptr;
-  hipError_t e1 = hipMalloc(&d_body, body_len ? body_len : 16), e2 = hipMalloc(&d_dst, orig_size ? orig_size : 16);
-  if (e1 != hipSuccess || e2 != hipSuccess) { if (d_body) (void)hipFree(d_body); if (d_dst) (void)hipFree(d_dst); (void)hipGetLastError(); return ZN_E_ALLOC; }
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace& w = g_ws[dev];
+    int rc0;
+    if ((rc0 = ws_reserve(w, WS_HOST_IN, body_len ? body_len : 16))) return rc0;
+    if ((rc0 = ws_reserve(w, WS_HOST_OUT, orig_size ? orig_size : 16))) return rc0;
+    d_body = w.buf[WS_HOST_IN]; d_dst = w.buf[WS_HOST_OUT];
+  }
   int rc = ZN_OK;
   do {
     if (body_len && hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
@@ -307,7 +328,6 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
     if (rc) break;
     if (orig_size && hipMemcpy(dst, d_dst, orig_size, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy D2H"; break; }
   } while (0);
-  (void)hipFree(d_body); (void)hipFree(d_dst);
   return rc;
 }
 
