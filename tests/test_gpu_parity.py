@@ -256,7 +256,7 @@ def test_batched_decode_many_tensors(lib):
                                   ("burst", 100001, 1, 1, 10, 128 * KB, 1), ("rand", C + 30000, 2, 1, 10, C, 0)],
                          ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
 def test_partial_last_chunk_through_the_parallel_tail_kernel(lib, case):
-    """Big partial last chunks: Huffman planes by zn_k_decode_tail (ragged streams, padded scratch), exact output."""
+    """Big partial last chunks: Huffman planes by the tail workgroups of zn_k_decode_fused (ragged streams, padded scratch), exact output."""
     from test_kernels_simt import _gen2
     kind, nb, P, rot, bm, chunk, want_tail_planes = case
     d = _gen2(kind, nb, 17)

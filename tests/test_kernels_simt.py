@@ -218,7 +218,7 @@ TAILS = [("bf16", C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 1
 
 @pytest.mark.parametrize("case", TAILS, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
 def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
-    """A big partial last chunk: its Huffman planes are decoded by zn_k_decode_tail (4 ragged streams into padded
+    """A big partial last chunk: its Huffman planes are decoded by the tail workgroups of zn_k_decode_fused (4 ragged streams into padded
     scratch), the merge kernel interleaves; tiny / raw tails stay on the serial path.  Output == input."""
     kind, nb, P, rot, bm, chunk, want_tail_planes = case
     d = _gen2(kind, nb, 17)
@@ -227,7 +227,7 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
     out = torch.empty(nb, dtype=torch.uint8)
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
     assert out.numpy().tobytes() == d
-    assert "zn_k_decode_tail" in simt_lib.last_kernels()
+    assert "zn_k_decode_fused+tail" in simt_lib.last_kernels()
     assert simt_lib.last_tail_planes() == want_tail_planes
 
 

@@ -452,6 +452,64 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   return ok && carry == b0 && J == seg && JF >= seg;
 }
 
+// (b = index of the tail workgroup inside the launch; runs as the FIRST workgroups of zn_k_decode_fused, so that
+// the one-workgroup job overlaps the decode of the full chunks instead of following it)
+__device__ void zn_decode_tail_wg(ZnFusedLds& L, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t b,
+                                  uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status) {
+  const ZnSeg S = zn_find_seg<3>(one, segs, nseg, b);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
+  const uint8_t* body_end = body + body_len;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t p = b - S.tail0;
+  const uint64_t c = g.K - 1u;
+  ZN_PT_DECL;
+  const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
+  if (!(m.ok && m.type == 1u && m.csize > 1u && m.csize < m.plen && m.plen >= 4096u && m.plen <= 4u * ZN_TAIL_SEGPAD)) return;
+  const uint8_t* src = body + m.off;
+  if (wave == 0) {
+    uint8_t* tmp = (uint8_t*)&L.ring[0][0];
+    const ZnWaveStats st = zn_wave_read_stats(src, m.csize, body_end, lane, tmp, L.symlist[0], L.rank_start[0], L.sym_start[0], tmp + 512);
+    if (lane == 0) L.st[0] = st;
+  }
+  __syncthreads();
+  const ZnWaveStats st = L.st[0];
+  const int hs = st.hs; const uint32_t TL = st.tl;
+  if (hs < 0 || TL > ZN_F_TLMAX || (uint32_t)hs >= m.csize || m.csize - (uint32_t)hs < 10u) return;
+  __syncthreads();                             // (ring[0] held the parser's scratch)
+  zn_fused_fill_luts(L, tid, TL, 0);
+  const uint8_t* js = src + hs; const uint32_t rem = m.csize - (uint32_t)hs;
+  const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+  if (l1 + l2 + l3 + 6u > rem) return;
+  const uint32_t l4 = rem - 6u - l1 - l2 - l3;
+  if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) return;
+  const uint32_t seg3 = (m.plen + 3u) / 4u;
+  if (3u * seg3 >= m.plen) return;
+  const uint32_t segw = (wave < 3u) ? seg3 : m.plen - 3u * seg3;
+  const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
+  const uint8_t* stream = js + so; const uint32_t slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
+  __syncthreads();                             // lut16 (aliasing ring[0]) is dead from here on
+
+  constexpr uint32_t UNIT1 = 64u * 16u;        // row of the single-plane instance
+  ZnFusedPlane pl[1]; pl[0].off = m.off; pl[0].kind = ZN_KIND_HUF; pl[0].csize = m.csize;
+  const uint8_t* rawq[1] = {nullptr};
+  uint8_t* outq = scratch + (uint64_t)b * ZN_TAIL_SLOT + (uint64_t)wave * ZN_TAIL_SEGPAD;
+  uint32_t Du = ((ZN_F_RING_BYTES - UNIT1 - 128u) * slen) / (256u * segw);
+  Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+  Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
+  const bool ok = (Du == ZN_F_DCONST)
+    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
+    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
+  if (lane == 0) L.what[wave] = ok ? 1u : 0u;
+  __syncthreads();
+  if (tid == 0) {
+    if (L.what[0] & L.what[1] & L.what[2] & L.what[3]) tail_done[b] = 1;
+    else atomicOr(status, ZN_DEV_CORRUPT);
+  }
+  ZN_PT_FLUSH();
+}
+
+
 // One workgroup decodes a GROUP of up to 4 consecutive chunks.  The tree description of a huff0 block is
 // a serial job for one wave (zn_huf_wave.hpp), so the four waves first parse the descriptions of the
 // group's four chunks side by side; after that the whole workgroup decodes the chunks one after the other
@@ -460,12 +518,15 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 template <int P>
 __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
-                                                                  uint32_t* __restrict__ status) {
+                                                                  uint32_t* __restrict__ status, uint32_t ntail,
+                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
-  const ZnSeg S = zn_find_seg<0>(one, segs, nseg, blockIdx.x);
+  if (blockIdx.x < ntail) { zn_decode_tail_wg(L, one, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return; }
+  const uint32_t wg = blockIdx.x - ntail;      // workgroup index among the full-chunk groups
+  const ZnSeg S = zn_find_seg<0>(one, segs, nseg, wg);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
   uint8_t* __restrict__ dst = S.dst; uint8_t* __restrict__ done = done_all + S.chunk0;
@@ -474,7 +535,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   const uint32_t ncg = S.ncg;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c0 = (uint64_t)(blockIdx.x - S.wg0) * ncg;
+  const uint64_t c0 = (uint64_t)(wg - S.wg0) * ncg;
   const uint32_t nc = (g.K - c0 < (uint64_t)ncg) ? (uint32_t)(g.K - c0) : ncg;
   const uint32_t plen = (uint32_t)(g.chunk / P);
   const uint32_t seg = plen / 4u;             // symbols per stream == plane bytes per quarter
@@ -585,70 +646,6 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
 // parallel stream decoder (its single-plane instance), into a padded scratch slot: stream w's symbols start at
 // slot + w * ZN_TAIL_SEGPAD.  The generic merge kernel interleaves from there.  Anything unusual (raw / RLE /
 // tiny planes, tableLog 12, malformed blocks) is left to the serial generic kernel: tail_done stays 0.
-__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_tail(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
-                                                                 uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done,
-                                                                 uint32_t* __restrict__ status) {
-  __shared__ ZnFusedLds L;
-  const ZnSeg S = zn_find_seg<3>(one, segs, nseg, blockIdx.x);
-  const ZnGeom g = S.g;
-  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
-  const uint8_t* body_end = body + body_len;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t p = blockIdx.x - S.tail0;
-  const uint64_t c = g.K - 1u;
-  ZN_PT_DECL;
-  const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
-  if (!(m.ok && m.type == 1u && m.csize > 1u && m.csize < m.plen && m.plen >= 4096u && m.plen <= 4u * ZN_TAIL_SEGPAD)) return;
-  const uint8_t* src = body + m.off;
-  if (wave == 0) {
-    uint8_t* tmp = (uint8_t*)&L.ring[0][0];
-    const ZnWaveStats st = zn_wave_read_stats(src, m.csize, body_end, lane, tmp, L.symlist[0], L.rank_start[0], L.sym_start[0], tmp + 512);
-    if (lane == 0) L.st[0] = st;
-  }
-  __syncthreads();
-  const ZnWaveStats st = L.st[0];
-  const int hs = st.hs; const uint32_t TL = st.tl;
-  if (hs < 0 || TL > ZN_F_TLMAX || (uint32_t)hs >= m.csize || m.csize - (uint32_t)hs < 10u) return;
-  __syncthreads();                             // (ring[0] held the parser's scratch)
-  zn_fused_fill_luts(L, tid, TL, 0);
-  const uint8_t* js = src + hs; const uint32_t rem = m.csize - (uint32_t)hs;
-  const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
-  if (l1 + l2 + l3 + 6u > rem) return;
-  const uint32_t l4 = rem - 6u - l1 - l2 - l3;
-  if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) return;
-  const uint32_t seg3 = (m.plen + 3u) / 4u;
-  if (3u * seg3 >= m.plen) return;
-  const uint32_t segw = (wave < 3u) ? seg3 : m.plen - 3u * seg3;
-  const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
-  const uint8_t* stream = js + so; const uint32_t slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
-  __syncthreads();                             // lut16 (aliasing ring[0]) is dead from here on
-
-  constexpr uint32_t UNIT1 = 64u * 16u;        // row of the single-plane instance
-  ZnFusedPlane pl[1]; pl[0].off = m.off; pl[0].kind = ZN_KIND_HUF; pl[0].csize = m.csize;
-  const uint8_t* rawq[1] = {nullptr};
-  uint8_t* outq = scratch + (uint64_t)blockIdx.x * ZN_TAIL_SLOT + (uint64_t)wave * ZN_TAIL_SEGPAD;
-  uint32_t Du = ((ZN_F_RING_BYTES - UNIT1 - 128u) * slen) / (256u * segw);
-  Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
-  Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
-  const bool ok = (Du == ZN_F_DCONST)
-    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
-    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
-  if (lane == 0) L.what[wave] = ok ? 1u : 0u;
-  __syncthreads();
-  if (tid == 0) {
-    if (L.what[0] & L.what[1] & L.what[2] & L.what[3]) tail_done[blockIdx.x] = 1;
-    else atomicOr(status, ZN_DEV_CORRUPT);
-  }
-  ZN_PT_FLUSH();
-}
-
-void zn_launch_decode_tail(const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_tail_wg, uint8_t* d_tail_scratch,
-                           uint8_t* d_tail_done, uint32_t* d_status, hipStream_t stream) {
-  if (total_tail_wg == 0) return;
-  hipLaunchKernelGGL(zn_k_decode_tail, dim3(total_tail_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_tail_scratch, d_tail_done, d_status);
-  zn_note_kernel("zn_k_decode_tail");
-}
-
 #ifdef ZN_PHASE_TIMERS
 extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
@@ -674,10 +671,12 @@ uint32_t zn_decode_fused_group(uint64_t K) {
 }
 
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
-                            uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, hipStream_t stream) {
+                            uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
+                            uint8_t* d_tail_done, hipStream_t stream) {
   if (total_wg == 0) return;
-  if (P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status);
-  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status);
-  zn_note_kernel("zn_k_decode_fused");
+  total_wg += ntail;                             // the tail workgroups come first
+  if (P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done);
+  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done);
+  zn_note_kernel(ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused");
 }

@@ -95,7 +95,7 @@ __device__ void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, const ZnS
   }
   if (bad) { d.kind = ZN_KIND_RLE; d.off = 0; }   // keep the merge kernel in bounds; output is discarded by the caller
   if (!bad && d.kind == ZN_KIND_HUF && S.has_tail && c == g.K - 1u && tail_done && tail_done[S.tail0 + p]) {
-    d.kind = ZN_KIND_HUFS; d.off = (uint64_t)(S.tail0 + p) * ZN_TAIL_SLOT;       // already decoded by zn_k_decode_tail
+    d.kind = ZN_KIND_HUFS; d.off = (uint64_t)(S.tail0 + p) * ZN_TAIL_SLOT;       // already decoded by the tail workgroups of zn_k_decode_fused
   }
 
   if (!bad && d.kind == ZN_KIND_HUF) {

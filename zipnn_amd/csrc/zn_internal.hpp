@@ -37,13 +37,13 @@ void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint
 
 // ---- fused decode path (full chunks, ≤1 Huffman plane) : zn_decode_fused.hip ----
 uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a tensor of K chunks
-// d_done: Σ K chunk flags; d_pdone: the same per (plane, chunk) entry (Σ P·K), for the planes kernel
+// d_done: Σ K chunk flags; d_pdone: the same per (plane, chunk) entry (Σ P·K), for the planes kernel.
+// ntail: Huffman planes of partial last chunks are decoded by `ntail` extra workgroups at the front of the grid (the
+// parallel stream decoder on ragged streams) into padded scratch slots (ZN_TAIL_SLOT bytes per plane);
+// tail_done[i] = 1 where that worked — the generic kernels take it from there.
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
-                            uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, hipStream_t stream);
-// Huffman planes of partial last chunks, decoded with the parallel stream decoder into padded scratch slots
-// (ZN_TAIL_SLOT bytes per plane); tail_done[i] = 1 where that worked — the generic kernels take it from there.
-void zn_launch_decode_tail(const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_tail_wg, uint8_t* d_tail_scratch,
-                           uint8_t* d_tail_done, uint32_t* d_status, hipStream_t stream);
+                            uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
+                            uint8_t* d_tail_done, hipStream_t stream);
 
 // ---- generic encode path : zn_encode_generic.hip ----
 // Handles chunks [c0, K).  planes/enc: P*(K-c0) slots each; csize/type/offs: [P*K] (global indexing).
