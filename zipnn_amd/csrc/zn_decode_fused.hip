@@ -51,7 +51,11 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
+#ifdef ZN_F_SWZ
+#define ZN_F_IN_DW (66 * ZN_F_DMAX + 8)
+#else
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
+#endif
 #define ZN_F_TLMAX 11u
 #ifndef ZN_F_DELTA0
 #define ZN_F_DELTA0 16                   // initial sync run-in (bits); doubles after a mismatch
@@ -59,7 +63,11 @@
 
 // stream-tile dword i lives at in[ZN_IN_IDX(i)] (a padded layout against bank conflicts of the strided walk
 // was measured: no gain, the kernel is issue-bound — identity)
+#ifdef ZN_F_SWZ
+#define ZN_IN_IDX(i) ((i) + ((i) >> 5))
+#else
 #define ZN_IN_IDX(i) (i)
+#endif
 
 // 16-byte output store, non-temporal: the output is written once and never read back by this kernel
 #if !defined(ZN_SIMT_EMULATOR)
@@ -131,30 +139,32 @@ __device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, 
 template <int MODE, bool FULL>
 __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32, uint32_t sh, int32_t bound, uint32_t* stage) {
   const uint32_t idx = c.whi >> sh;
-  uint32_t meta = lut32[idx];
-  uint32_t nb, cnt, keep = 0xFFFFFFFFu;                             // keep: byte mask of the symbols 0-3 taken
+  // (LDS is a bottleneck of these passes: lanes with nothing to add stay out of the atomics; masking the table
+  //  reads the same way was measured and does not pay)
+  const bool act = FULL ? (c.pos > bound) : (c.pos > c.stop);
+  uint32_t meta = lut32[idx], syms = (MODE == 2) ? lut32[idx + (1u << ZN_F_TLMAX)] : 0u;
+  meta = act ? meta : 0u; syms = act ? syms : 0u;
+  uint32_t nb, cnt;
   if (FULL) {
-    const bool act = c.pos > bound;
-    meta = act ? meta : 0u; keep = act ? keep : 0u;
     nb = (meta >> 16) & 15u; cnt = meta >> 29;
   } else {
-    const int32_t rem = c.pos - c.stop;                             // ≤ 0: this lane is done
+    const int32_t rem = c.pos - c.stop;                             // ≤ 0: this lane is done (meta == 0)
     const uint32_t k = (uint32_t)(rem > 0) + (uint32_t)((int32_t)(meta & 15u) < rem) + (uint32_t)((int32_t)((meta >> 4) & 15u) < rem) +
                        (uint32_t)((int32_t)((meta >> 8) & 15u) < rem) + (uint32_t)((int32_t)((meta >> 12) & 15u) < rem);
     const uint32_t have = meta >> 29;
     cnt = k < have ? k : have;
     nb = k ? ((meta >> (4u * k - 4u)) & 15u) : 0u;
-    keep = cnt >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8u * cnt));
+    syms &= cnt >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8u * cnt));   // the symbols 0-3 taken
     if (cnt < 5u) meta &= ~(0xFFu << 20);                           // symbol 4 only with all five
   }
   if (MODE == 2) {
     // the ≤ 5 symbol bytes as one 40-bit value, moved to the byte position inside the dword with one 64-bit
     // shift: low dword → d[0], high dword = the bytes that spill into d[1] (0 when none)
-    const uint64_t pack = ((uint64_t)((meta >> 20) & 0xFFu) << 32) | (lut32[idx + (1u << ZN_F_TLMAX)] & keep);
+    const uint64_t pack = ((uint64_t)((meta >> 20) & 0xFFu) << 32) | syms;
     const uint64_t sp = pack << ((c.wpos & 3u) << 3);
     uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & ~3u));
-    atomicOr(d, (uint32_t)sp);
-    atomicOr(d + 1, (uint32_t)(sp >> 32));
+    if ((uint32_t)sp) atomicOr(d, (uint32_t)sp);
+    if ((uint32_t)(sp >> 32)) atomicOr(d + 1, (uint32_t)(sp >> 32));
     c.wpos += cnt;
   }
   { const uint64_t w = (((uint64_t)c.whi << 32) | c.wlo) << nb; c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w; }   // v_lshlrev_b64
