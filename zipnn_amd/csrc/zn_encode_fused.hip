@@ -360,7 +360,13 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
         }
         uint8_t* r = body + off[p] + (uint64_t)wave * seg + (uint32_t)base + ZN_E_SPL * lane;
         zn_eu128u s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
+#if !defined(ZN_SIMT_EMULATOR)                  // non-temporal: the payload is written once and not read back here
+        typedef uint32_t zn_ev4u_u __attribute__((ext_vector_type(4), aligned(1)));
+        __builtin_nontemporal_store((zn_ev4u_u){o[0], o[1], o[2], o[3]}, (zn_ev4u_u*)r);
+        __builtin_nontemporal_store((zn_ev4u_u){o[4], o[5], o[6], o[7]}, (zn_ev4u_u*)(r + 16));
+#else
         *(zn_eu128u*)r = s0; *(zn_eu128u*)(r + 16) = s1;
+#endif
       }
     }
     if (H < 0) continue;
