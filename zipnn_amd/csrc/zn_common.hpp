@@ -62,6 +62,15 @@ __device__ __forceinline__ uint32_t zn_rot_inv32(uint32_t u) {
 }
 
 // Geometry of one frame body, passed by value to every kernel.
+// A pointer that comes out of a struct / table is "generic" to the compiler: its loads and stores become FLAT
+// operations, which also count on the LDS counter (every LDS wait would then wait for HBM).  These pointers
+// are global memory: say so.
+#if defined(ZN_SIMT_EMULATOR)
+#define ZN_GLOBAL_PTR(T, p) ((T*)(p))
+#else
+#define ZN_GLOBAL_PTR(T, p) ((T*)(__attribute__((address_space(1))) T*)(unsigned long long)(p))   // (via an integer: a plain round trip is folded away)
+#endif
+
 struct ZnGeom {
   uint64_t n;         // original length in bytes
   uint64_t chunk;     // origChunkSize

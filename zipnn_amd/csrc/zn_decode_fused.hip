@@ -468,7 +468,7 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L, const ZnSeg& one, const ZnSeg* 
                                   uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status) {
   const ZnSeg S = zn_find_seg<3>(one, segs, nseg, b);
   const ZnGeom g = S.g;
-  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
+  const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
   const uint8_t* body_end = body + body_len;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t p = b - S.tail0;
@@ -538,8 +538,8 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   const uint32_t wg = blockIdx.x - ntail;      // workgroup index among the full-chunk groups
   const ZnSeg S = zn_find_seg<0>(one, segs, nseg, wg);
   const ZnGeom g = S.g;
-  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
-  uint8_t* __restrict__ dst = S.dst; uint8_t* __restrict__ done = done_all + S.chunk0;
+  const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
+  uint8_t* __restrict__ dst = ZN_GLOBAL_PTR(uint8_t, S.dst); uint8_t* __restrict__ done = done_all + S.chunk0;
   uint8_t* __restrict__ pdone = pdone_all + S.desc0;   // the same flag per (plane, chunk)
 #define ZN_SET_DONE(c_, v_) do { if (tid == 0) done[c_] = (v_); if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;

@@ -72,8 +72,8 @@ __device__ void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, const ZnS
   uint32_t* sh_rank_start = L.sh_rank_start; uint32_t* sh_sym_start = L.sh_sym_start;
   const ZnSeg S = zn_find_seg<1>(one, segs, nseg, b);
   const ZnGeom g = S.g;
-  const uint8_t* __restrict__ body = S.body; const uint64_t body_len = S.body_len;
-  uint8_t* __restrict__ dst = S.dst;
+  const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
+  uint8_t* __restrict__ dst = ZN_GLOBAL_PTR(uint8_t, S.dst);
   ZnPlaneDesc* __restrict__ descs = descs_all + S.desc0;
 
   const uint32_t lane = threadIdx.x;
@@ -173,8 +173,8 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
                                                     const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ tails) {
   const ZnSeg S = zn_find_seg<2>(one, segs, nseg, b);
   const ZnGeom g = S.g;
-  const uint8_t* __restrict__ body = S.body;
-  uint8_t* dst = S.dst;
+  const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body);
+  uint8_t* dst = ZN_GLOBAL_PTR(uint8_t, S.dst);
   const ZnPlaneDesc* __restrict__ descs = descs_all + S.desc0;
   const uint64_t c = b - S.chunk0;
   const uint32_t clen = zn_chunk_len(g, c);
