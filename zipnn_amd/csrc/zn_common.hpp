@@ -99,7 +99,8 @@ static __device__ unsigned long long zn_phase_acc[64];   // one copy per transla
 // be waited on by the kernel's own vmcnt waits and distort what they measure)
 struct ZnPhaseTimer { unsigned long long t0; unsigned int a[24]; };
 #define ZN_PT_DECL ZnPhaseTimer zn_pt_; do { for (int i_ = 0; i_ < 24; i_++) zn_pt_.a[i_] = 0; zn_pt_.t0 = __builtin_readcyclecounter(); } while (0)
-#define ZN_PT(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); zn_pt_.a[i] += (unsigned int)(t_ - zn_pt_.t0); zn_pt_.t0 = t_; } while (0)
+// (scheduling barriers pin the clock read between the phases it separates)
+#define ZN_PT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); zn_pt_.a[i] += (unsigned int)(t_ - zn_pt_.t0); zn_pt_.t0 = t_; } while (0)
 #define ZN_PT_COUNT(i, n) do { zn_pt_.a[i] += (unsigned int)(n); } while (0)
 #define ZN_PT_FLUSH() do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 24; i_++) if (zn_pt_.a[i_]) atomicAdd(&zn_phase_acc[i_], (unsigned long long)zn_pt_.a[i_]); } while (0)
 // a callee that shares its caller's timer: extra parameter / argument / local reference

@@ -263,6 +263,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   // `stage_row0` = staging-buffer row that holds symbol `first_row_sym`.
   auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0) {
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
+    ZN_PT(10);  // wait for the fetched rows
     for (int r = 0; r < RB; r++) if (r < nrows) {
       for (int p = 0; p < P; p++) {
         if (p == H) { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
