@@ -50,7 +50,7 @@ def main():
     print(f"  total                        {tot / chunks:10.0f} cyc/chunk")
     for i, nm in () if not any("ZN_PHASE_TIMERS_SUB" in a for a in sys.argv) else ((10, "readNCount"), (11, "FSE decode table"), (12, "FSE state chain"), (13, "stage+weights total"), (14, "weight statistics"), (15, "canonical order")):
         print(f"    tree description / {nm:22s} {acc[i] / chunks:10.0f} cyc/chunk")
-    print(f"  (in flush) wait for fetched rows {acc[10] / chunks:10.0f} cyc/chunk   (in stage) wait for tile + stage {acc[11] / chunks:10.0f} cyc/chunk")
+    print(f"  (in flush) wait for fetched rows {acc[10] / chunks:10.0f} cyc/chunk")
     print(f"  wait for slowest wave at chunk start {acc[21] / chunks:10.0f} cyc/chunk")
     print(f"  tiles/chunk(wave0) {acc[18] / chunks:.2f}  fix-up iterations/tile {acc[16] / max(acc[18], 1):.3f}  "
           f"mismatching lanes/tile {acc[17] / max(acc[18], 1):.3f}")

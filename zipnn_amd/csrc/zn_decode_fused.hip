@@ -241,12 +241,12 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
-#ifdef ZN_F_RBMAX
-  constexpr int RB0 = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (int)(ZN_F_RING_BYTES / 1024u);
-  constexpr int RB = RB0 > (ZN_F_RBMAX * 2 / P > 0 ? ZN_F_RBMAX * 2 / P : 1) ? (ZN_F_RBMAX * 2 / P > 0 ? ZN_F_RBMAX * 2 / P : 1) : RB0;
-#else
-  constexpr int RB = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (int)(ZN_F_RING_BYTES / 1024u);   // rows kept in registers at once
+  // rows kept in registers at once (fetched before the write pass, emitted after it).  A 4-plane row holds three
+  // raw planes in registers: two rows at a time, or the kernel spills (ZN_F_RB4).
+#ifndef ZN_F_RB4
+#define ZN_F_RB4 2
 #endif
+  constexpr int RB = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (P == 4) ? ZN_F_RB4 : (int)(ZN_F_RING_BYTES / 1024u);
   ZN_PT_SHARED;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
@@ -298,7 +298,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           uint32_t x[4];
           x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
           x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-          ZN_ST128(o + 16 * half, x[0], x[1], x[2], x[3]);
+          *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);   // (two half-line stores per lane: NOT non-temporal, the L2 merges them — nt cost 40 % here)
         }
       }
     }
