@@ -6,7 +6,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, ROOT)
 from zipnn_amd import _capi, codec
 from zipnn_amd.build import hipcc_path, sources
-VARIANTS = {"base": [], "rb4_3": ["-DZN_F_RB4=3"], "rb4_4": ["-DZN_F_RB4=4"], "w3": ["-DZN_F_WAVES_PER_SIMD=3", "-DZN_F_RB4=4"]}
+VARIANTS = {"base": [], "dmax6": ["-DZN_F_DMAX=6"], "dmax6_c6": ["-DZN_F_DMAX=6", "-DZN_F_DCONST=6"], "dmax5": ["-DZN_F_DMAX=5"]}
 def main():
     names = sys.argv[1:] or list(VARIANTS)
     n = 1 << 30

@@ -10,6 +10,7 @@ echo "== rocminfo ==" > "$OUT/env.log"; (rocminfo | grep -E 'Marketing Name|gfx|
 echo "== pytest -m gpu =="; timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee "$OUT/pytest_gpu.log"
 echo "== smoke =="; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee "$OUT/smoke.log"
 echo "== bench =="; timeout 900 python bench.py --steps "$STEPS" --warmup 2 2>&1 | tail -5 | tee "$OUT/bench.log"
+echo "== other dtypes (1 GiB) =="; timeout 300 python scripts/bench_dtypes.py 1.0 2>&1 | grep GiB | tee "$OUT/dtypes.log"
 echo "== rocprofv3 kernel stats =="
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$R/bench.py" --steps "$STEPS" --warmup 2 --no-cpu-baseline > "$OUT/rocprof.log" 2>&1

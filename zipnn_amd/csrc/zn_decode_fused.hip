@@ -46,7 +46,7 @@
 #endif
 #define ZN_F_RING_DW (ZN_F_RING_BYTES / 4u)
 #ifndef ZN_F_DMAX
-#define ZN_F_DMAX 4                      // largest sub-block (dwords); sizes the stream-tile buffer and its prefetch registers
+#define ZN_F_DMAX 6                      // largest sub-block (dwords); sizes the stream-tile buffer and its prefetch registers (LDS: 40.8 KB, still 4 workgroups/CU; dense codes — fp8, fp16 — want long sub-blocks: +22 % on fp8)
 #endif
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
