@@ -13,7 +13,6 @@ VARIANTS = {
     "ent_stats": ["-DZN_E_NTLOAD_STATS"],
     "ent_emit": ["-DZN_E_NTLOAD_EMIT"],
     "ent_both": ["-DZN_E_NTLOAD_STATS", "-DZN_E_NTLOAD_EMIT"],
-    "swz": ["-DZN_F_SWZ"],
     "dmax6": ["-DZN_F_DMAX=6"],
     "d20": ["-DZN_F_DELTA0=20"],
     "d24": ["-DZN_F_DELTA0=24"],

@@ -51,11 +51,7 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
-#ifdef ZN_F_SWZ
-#define ZN_F_IN_DW (66 * ZN_F_DMAX + 8)
-#else
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
-#endif
 #define ZN_F_TLMAX 11u
 #ifndef ZN_F_DELTA0
 #define ZN_F_DELTA0 16                   // initial sync run-in (bits); doubles after a mismatch
@@ -63,11 +59,7 @@
 
 // stream-tile dword i lives at in[ZN_IN_IDX(i)] (a padded layout against bank conflicts of the strided walk
 // was measured: no gain, the kernel is issue-bound — identity)
-#ifdef ZN_F_SWZ
-#define ZN_IN_IDX(i) ((i) + ((i) >> 5))
-#else
 #define ZN_IN_IDX(i) (i)
-#endif
 
 // 16-byte output store, non-temporal: the output is written once and never read back by this kernel
 #if !defined(ZN_SIMT_EMULATOR)
