@@ -262,11 +262,15 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
   zn_batch_item it;
   it.d_body = d_body; it.body_len = body_len; it.d_dst = d_dst; it.orig_size = orig_size;
   it.num_buf = num_buf; it.bits_mode = bits_mode; it.bytes_mode = bytes_mode; it.chunk = chunk;
-  return decompress_items(&it, 1, (hipStream_t)stream_, check);
+  try {
+    return decompress_items(&it, 1, (hipStream_t)stream_, check);
+  } catch (...) { return ZN_E_ALLOC; }
 }
 
 int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stream_, int check) {
-  return decompress_items(items, count, (hipStream_t)stream_, check);
+  try {                                          // (the segment lists are std::vectors: nothing may unwind through the C ABI)
+    return decompress_items(items, count, (hipStream_t)stream_, check);
+  } catch (...) { return ZN_E_ALLOC; }
 }
 
 int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
@@ -332,33 +336,37 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
 }
 
 long long zn_last_fused_chunks(void) {
-  int dev = 0;
-  ZN_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return ZN_E_ARG;
-  std::lock_guard<std::mutex> lk(g_mu);
-  Workspace& w = g_ws[dev];
-  if (!w.last_K || !w.buf[WS_META_B]) return 0;
-  std::string flags(w.last_K, '\0');
-  ZN_HIP(hipDeviceSynchronize());
-  ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_B], w.last_K, hipMemcpyDeviceToHost));
-  long long n = 0;
-  for (char f : flags) n += (f != 0);
-  return n;
+  try {
+    int dev = 0;
+    ZN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return ZN_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace& w = g_ws[dev];
+    if (!w.last_K || !w.buf[WS_META_B]) return 0;
+    std::string flags(w.last_K, '\0');
+    ZN_HIP(hipDeviceSynchronize());
+    ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_B], w.last_K, hipMemcpyDeviceToHost));
+    long long n = 0;
+    for (char f : flags) n += (f != 0);
+    return n;
+  } catch (...) { return ZN_E_ALLOC; }
 }
 
 long long zn_last_tail_planes(void) {
-  int dev = 0;
-  ZN_HIP(hipGetDevice(&dev));
-  if (dev < 0 || dev >= 64) return ZN_E_ARG;
-  std::lock_guard<std::mutex> lk(g_mu);
-  Workspace& w = g_ws[dev];
-  if (!w.last_tails || !w.buf[WS_META_A]) return 0;
-  std::string flags(w.last_tails, '\0');
-  ZN_HIP(hipDeviceSynchronize());
-  ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_A], w.last_tails, hipMemcpyDeviceToHost));
-  long long n = 0;
-  for (char f : flags) n += (f != 0);
-  return n;
+  try {
+    int dev = 0;
+    ZN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return ZN_E_ARG;
+    std::lock_guard<std::mutex> lk(g_mu);
+    Workspace& w = g_ws[dev];
+    if (!w.last_tails || !w.buf[WS_META_A]) return 0;
+    std::string flags(w.last_tails, '\0');
+    ZN_HIP(hipDeviceSynchronize());
+    ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_A], w.last_tails, hipMemcpyDeviceToHost));
+    long long n = 0;
+    for (char f : flags) n += (f != 0);
+    return n;
+  } catch (...) { return ZN_E_ALLOC; }
 }
 
 int zn_release_workspace(void) {
