@@ -264,3 +264,21 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(lib, case):
     assert bytes(lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == want
     assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
     assert lib.last_tail_planes() == want_tail_planes
+
+
+def test_streaming_blob_decodes_in_one_batched_launch(lib):
+    """is_streaming BYTE frames (1 MiB each): the decompress side parses every header on the host and decodes all
+    frames with one batched launch; bytes equal the input, and a delta (XOR) second buffer composes."""
+    from zipnn_amd import ZipNN
+    raw = gen_bytes("bf16", 24 * (1 << 20) + 12346, 77)
+    z = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20)
+    blob = z.compress(raw)
+    assert isinstance(blob, bytearray) and len(blob) < len(raw)
+    back = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20).decompress(blob)
+    assert isinstance(back, bytearray) and bytes(back) == raw
+    assert "zn_k_decode_fused" in lib.last_kernels()
+    other = gen_bytes("bf16", len(raw), 78)
+    zd = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20, delta_compressed_type="byte")
+    blob2 = zd.compress(raw, delta_second_data=other)
+    back2 = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20, delta_compressed_type="byte").decompress(blob2, delta_second_data=other)
+    assert bytes(back2) == raw

@@ -68,7 +68,7 @@ class _nullctx:
         return False
 
 
-def decompress_device_batch(lib, items, check=True):
+def decompress_device_batch(lib, items, check=True, into=None):
     """Many tensors, one set of kernel launches (zn_decompress_batch_dev): small tensors fill the device together.
     items: iterable of (body, num_buf, bits_mode, bytes_mode, chunk, orig_size) with `body` a uint8 tensor on
     the device (frame minus header).  Returns the list of decoded uint8 tensors (same device)."""
@@ -76,7 +76,14 @@ def decompress_device_batch(lib, items, check=True):
     if not items:
         return []
     dev = items[0][0].device
-    outs = [torch.empty(n, dtype=torch.uint8, device=dev) for (_, _, _, _, _, n) in items]
+    if into is not None:                       # one preallocated buffer: tensor i lands at the running offset
+        assert into.numel() >= sum(n for (_, _, _, _, _, n) in items)
+        offs, o = [], 0
+        for (_, _, _, _, _, n) in items:
+            offs.append(o); o += n
+        outs = [into[o:o + n] for o, (_, _, _, _, _, n) in zip(offs, items)]
+    else:
+        outs = [torch.empty(n, dtype=torch.uint8, device=dev) for (_, _, _, _, _, n) in items]
     with torch.cuda.device(dev) if dev.type == "cuda" else _nullctx():
         lib.decompress_batch_dev(((b.data_ptr(), b.numel(), nb, bi, by, ch, n, o.data_ptr() if n else 0)
                                   for (b, nb, bi, by, ch, n), o in zip(items, outs)), _stream_handle(items[0][0]), check)

@@ -281,6 +281,9 @@ class ZipNN:
         target = _resolve_device(decompress_cpu_gpu)
 
         if self.input_format == EnumFormat.BYTE.value and stream_byte > 127 and mv is not None:
+            batched = self._decompress_stream_batched(mv, delta_second_data)
+            if batched is not None:
+                return batched
             out = bytearray()
             off = od = 0
             mvd = memoryview(delta_second_data).cast("B") if delta_second_data else None
@@ -305,6 +308,49 @@ class ZipNN:
             return _xor(plain, delta_second_data)
         return self.decompress_bin(data if mv is None else mv, target)
 
+    def _decompress_stream_batched(self, mv, delta_second_data):
+        """A streaming `.znn` blob = back-to-back frames of `streaming_chunk` bytes each (reference zipnn.py:971-995,
+        scripts/zipnn_decompress_file.py:47-57).  All frame headers are parsed on the host, the blob crosses PCIe
+        once, every frame's chunks are decoded by ONE batched launch, the result comes back once.
+        None = not applicable (a single frame): the caller falls back to the per-frame loop."""
+        frames, off, first16, first_ext = [], 0, None, 0
+        while off < mv.nbytes:
+            if off + HEADER_LEN > mv.nbytes:
+                return None
+            total = int.from_bytes(mv[off + 24:off + 32], "little")
+            if total < HEADER_LEN or off + total > mv.nbytes:
+                return None
+            head16 = bytes(mv[off:off + 16])
+            if frames and head16 == first16 and first_ext == 0:
+                # same header as the first frame (the usual case: one writer, one configuration): only the length differs
+                fp = dict(frames[0][2]); fp["orig_size"] = int.from_bytes(mv[off + 16:off + 24], "little")
+            else:
+                fp = self.frame_params(mv[off:off + total])
+                if not frames:
+                    first16, first_ext = head16, fp["body_off"] - HEADER_LEN
+            frames.append((off + fp["body_off"], off + total, fp))
+            off += total
+        if len(frames) < 2:
+            return None
+        n_out = sum(fp["orig_size"] for (_, _, fp) in frames)
+        dev = torch.device("cuda", codec.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # (read-only input buffers: we only read them)
+            blob = torch.frombuffer(mv, dtype=torch.uint8).to(dev, non_blocking=True)
+        flat = torch.empty(n_out, dtype=torch.uint8, device=dev)
+        codec.decompress_device_batch(_capi.lib(), [(blob[b0:b1], fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"])
+                                                    for (b0, b1, fp) in frames], into=flat)
+        out = bytearray(n_out)
+        if n_out:
+            torch.frombuffer(out, dtype=torch.uint8).copy_(flat)
+        if delta_second_data:
+            mvd = memoryview(delta_second_data).cast("B")
+            if mvd.nbytes != n_out:
+                raise ValueError("Length of delta file has to match the length of the decompressed file.")
+            return bytearray(_xor(out, mvd))
+        return out
+
     def frame_params(self, frame):
         """Parse one frame's header -> what the C ABI needs to decode its body (no data work):
         dict(body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape)."""
@@ -313,7 +359,7 @@ class ZipNN:
         dt = dtype_from_code(self.dtype)
         chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
         return dict(body_off=body_off, num_buf=dt.planes, bits_mode=self._bit_reorder, bytes_mode=self._byte_reorder,
-                    chunk=chunk, orig_size=self.original_len, torch_dtype=dt.torch, shape=self.shape_bytes)
+                    chunk=chunk, orig_size=self.original_len, torch_dtype=dt.torch, shape=getattr(self, "shape_bytes", None))
 
     def decompress_bin(self, frame, target=None):
         """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198)."""
