@@ -18,6 +18,8 @@ def make(kind, n_bytes, dev):
     if kind == "fp8":
         x = (torch.randn(n_bytes, generator=g, device=dev) * 0.02).to(torch.float8_e4m3fn)
         return x.view(torch.uint8), 1, 1, 10, 128 * 1024
+    if kind == "rand16":   # uniform random bits: every plane is rejected by huff0 (ratio 1.0001) — the pure split / merge path
+        return torch.randint(0, 65536, (n_bytes // 2,), generator=g, device=dev, dtype=torch.int32).to(torch.int16).view(torch.bfloat16), 2, 1, 10, 256 * 1024
     raise ValueError(kind)
 
 
@@ -25,7 +27,7 @@ def main():
     gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     lib = _capi.lib(); dev = torch.device("cuda:0")
     n = int(gib * (1 << 30))
-    for kind in ("bf16", "fp16", "fp32", "fp8"):
+    for kind in ("bf16", "fp16", "fp32", "fp8", "rand16"):
         x, P, rot, bm, chunk = make(kind, n, dev)
         flat = codec.flat_bytes(x)
         body = codec.compress_device(lib, flat, P, rot, bm, chunk, 0.95).clone()
