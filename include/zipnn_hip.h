@@ -96,6 +96,19 @@ int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits
                       int bytes_mode, size_t chunk, size_t orig_size, void* d_dst, void* stream,
                       int check);
 
+/* Batched compress: `count` tensors (any mix of dtypes) through one launch per stage, one read-back of all body
+ * lengths — what a safetensors producer or the streaming writer does per file (reference
+ * scripts/zipnn_compress_safetensors.py:75-120, zipnn/zipnn.py:612-635).  Per item the semantics of
+ * zn_compress_dev; body_len is filled in for every item. */
+typedef struct zn_cbatch_item {
+  const void* d_src; size_t n;            /* tensor bytes on the current device */
+  int num_buf, bits_mode, bytes_mode;
+  size_t chunk; float threshold;
+  void* d_body; size_t body_cap;          /* >= zn_compress_bound(n, num_buf, chunk, 0) */
+  size_t body_len;                        /* out */
+} zn_cbatch_item;
+int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream);
+
 /* Batched decompress: `count` tensors (any mix of dtypes) decoded by one set of kernel launches, so that
  * many small tensors fill the device as one large one does.  What a safetensors loader does per file:
  * replaces the per-tensor loop around decompress_safetensors_tensor (reference zipnn/zipnn.py:1584-1596,

@@ -57,3 +57,33 @@ def run(name, shapes, dtype, P, rot, bm):
 if __name__ == "__main__":
     run("llama-3-8B layers x8, bf16", shapes_llama(8), torch.bfloat16, 2, 1, 10)
     run("gpt2 (124M), fp32", shapes_gpt2(), torch.float32, 4, 1, 220)
+
+
+def run_compress(name, shapes, dtype, P, rot, bm):
+    lib = _capi.lib(); dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    flats = []
+    for sh in shapes:
+        n = 1
+        for d in sh: n *= d
+        flats.append(codec.flat_bytes((torch.randn(n, generator=g, device=dev) * 0.02).to(dtype)))
+    total = sum(f.numel() for f in flats)
+    res = {}
+    def loop():
+        return [codec.compress_device(lib, f, P, rot, bm, C, 0.95) for f in flats]
+    def batch():
+        return codec.compress_device_batch(lib, [(f, P, rot, bm, C, 0.95) for f in flats])
+    a, b = loop(), batch()
+    ok = all(torch.equal(x, y) for x, y in zip(a, b))
+    for nm, fn in (("per-tensor", loop), ("batched", batch)):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        res[nm] = best
+    print(f"compress {name}: {len(shapes)} tensors, {total / 2**30:.2f} GiB, same bytes={ok}  per-tensor {res['per-tensor'] * 1e3:.2f} ms "
+          f"({total / res['per-tensor'] / 1e9:.0f} GB/s)   batched {res['batched'] * 1e3:.2f} ms ({total / res['batched'] / 1e9:.0f} GB/s)", flush=True)
+
+
+if __name__ == "__main__":
+    run_compress("llama-3-8B layers x8, bf16", shapes_llama(8), torch.bfloat16, 2, 1, 10)
+    run_compress("gpt2 (124M), fp32", shapes_gpt2(), torch.float32, 4, 1, 220)

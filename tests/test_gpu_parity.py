@@ -282,3 +282,25 @@ def test_streaming_blob_decodes_in_one_batched_launch(lib):
     blob2 = zd.compress(raw, delta_second_data=other)
     back2 = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20, delta_compressed_type="byte").decompress(blob2, delta_second_data=other)
     assert bytes(back2) == raw
+
+
+def test_batched_compress_many_tensors(lib):
+    """zn_compress_batch_dev on the GPU: every body equals the oracle's, the batch decodes back in one call."""
+    from zipnn_amd import codec
+    from test_kernels_simt import _gen2
+    dev = torch.device("cuda:0")
+    specs = [("bf16", 40 * C + 10, 2, 1, 10, C), ("fp32", 9 * C + 4, 4, 1, 220, C), ("fp8", 5 * 128 * KB + 1, 1, 1, 10, 128 * KB),
+             ("bf16", 7, 2, 1, 10, C), ("bf16", 0, 2, 1, 10, C), ("fp16", 33 * C, 2, 0, 10, C), ("rand", 4 * C, 2, 1, 10, C),
+             ("const", 2 * C, 2, 1, 10, C), ("fp32", 1000, 4, 1, 220, C), ("bf16", 4096 * 5 + 2, 2, 1, 10, 4096),
+             ("skew", C + 130000, 2, 0, 10, C)] + [("bf16", 3 * C + 2 * i, 2, 1, 10, C) for i in range(20)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = _gen2(kind, nb, 80 + i)
+        datas.append(d)
+        items.append(((torch.frombuffer(bytearray(d), dtype=torch.uint8) if d else torch.empty(0, dtype=torch.uint8)).to(dev), P, rot, bm, chunk, 0.95))
+    bodies = codec.compress_device_batch(lib, items)
+    for (kind, nb, P, rot, bm, chunk), d, b in zip(specs, datas, bodies):
+        assert b.cpu().numpy().tobytes() == O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)[32:], kind
+    outs = codec.decompress_device_batch(lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk) in zip(bodies, specs)])
+    for d, o in zip(datas, outs):
+        assert o.cpu().numpy().tobytes() == d

@@ -261,3 +261,24 @@ def test_corrupted_bodies_never_crash(simt_lib):
                 simt_lib.decompress_dev(t.data_ptr(), t.numel(), P, rot, bm, chunk, nb, out.data_ptr())
             except (RuntimeError, MemoryError, ValueError):
                 pass
+
+
+def test_batched_compress_matches_per_tensor_frames(simt_lib):
+    """zn_compress_batch_dev: tensors of all plane counts, tails, tiny / empty ones, geometries the fused encoder
+    does not take — every body equals the oracle's frame body; the batch then decodes back in one call."""
+    from zipnn_amd import codec
+    specs = [("bf16", 3 * C + 10, 2, 1, 10, C), ("fp32", 2 * C + 4, 4, 1, 220, C), ("fp8", C + 1, 1, 1, 10, C),
+             ("bf16", 7, 2, 1, 10, C), ("bf16", 0, 2, 1, 10, C), ("fp16", 5 * 16384, 2, 0, 10, 16384),
+             ("rand", 4 * C, 2, 1, 10, C), ("const", 2 * C, 2, 1, 10, C), ("fp32", 1000, 4, 1, 220, C),
+             ("bf16", 4096 * 5 + 2, 2, 1, 10, 4096), ("skew", C + 30000, 2, 0, 10, C)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = _gen2(kind, nb, 60 + i)
+        datas.append(d)
+        items.append((torch.frombuffer(bytearray(d), dtype=torch.uint8) if d else torch.empty(0, dtype=torch.uint8), P, rot, bm, chunk, 0.95))
+    bodies = codec.compress_device_batch(simt_lib, items)
+    for (kind, nb, P, rot, bm, chunk), d, b in zip(specs, datas, bodies):
+        assert b.numpy().tobytes() == O.compress_frame(HDR, d, P, rot, bm, chunk)[32:], kind
+    outs = codec.decompress_device_batch(simt_lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk) in zip(bodies, specs)])
+    for d, o in zip(datas, outs):
+        assert o.numpy().tobytes() == d

@@ -33,6 +33,13 @@ class ZnBatchItem(ctypes.Structure):
                 ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t)]
 
 
+class ZnCBatchItem(ctypes.Structure):
+    """struct zn_cbatch_item of include/zipnn_hip.h"""
+    _fields_ = [("d_src", ctypes.c_void_p), ("n", ctypes.c_size_t), ("num_buf", ctypes.c_int), ("bits_mode", ctypes.c_int),
+                ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t), ("threshold", ctypes.c_float),
+                ("d_body", ctypes.c_void_p), ("body_cap", ctypes.c_size_t), ("body_len", ctypes.c_size_t)]
+
+
 class ZnLib:
     """A loaded libzipnn_hip.so."""
 
@@ -58,6 +65,8 @@ class ZnLib:
         L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
         L.zn_decompress_dev.restype = ci
         L.zn_decompress_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, vp, vp, ci]
+        L.zn_compress_batch_dev.restype = ci
+        L.zn_compress_batch_dev.argtypes = [ctypes.POINTER(ZnCBatchItem), sz, vp]
         L.zn_decompress_batch_dev.restype = ci
         L.zn_decompress_batch_dev.argtypes = [ctypes.POINTER(ZnBatchItem), sz, vp, ci]
         L.zn_release_workspace.restype = ci
@@ -133,6 +142,16 @@ class ZnLib:
         rc = self._L.zn_decompress_dev(body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr,
                                        stream, 1 if check else 0)
         self._check(rc)
+
+    def compress_batch_dev(self, items, stream=0):
+        """items: iterable of (src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap) -> list of body lengths."""
+        items = list(items)
+        arr = (ZnCBatchItem * max(len(items), 1))()
+        for i, (sp, n, nb, bi, by, ch, th, bp, cap) in enumerate(items):
+            arr[i].d_src = sp; arr[i].n = n; arr[i].num_buf = nb; arr[i].bits_mode = bi; arr[i].bytes_mode = by
+            arr[i].chunk = ch; arr[i].threshold = th; arr[i].d_body = bp; arr[i].body_cap = cap
+        self._check(self._L.zn_compress_batch_dev(arr, len(items), stream))
+        return [int(arr[i].body_len) for i in range(len(items))]
 
     def decompress_batch_dev(self, items, stream=0, check=True):
         """items: iterable of (body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr)."""

@@ -88,3 +88,23 @@ def decompress_device_batch(lib, items, check=True, into=None):
         lib.decompress_batch_dev(((b.data_ptr(), b.numel(), nb, bi, by, ch, n, o.data_ptr() if n else 0)
                                   for (b, nb, bi, by, ch, n), o in zip(items, outs)), _stream_handle(items[0][0]), check)
     return outs
+
+
+def compress_device_batch(lib, items):
+    """Many tensors, one launch per stage (zn_compress_batch_dev), one read-back of all lengths.
+    items: iterable of (flat_uint8_device_tensor, num_buf, bits_mode, bytes_mode, chunk, threshold).
+    Returns the list of body tensors (uint8, same device; slices of one arena)."""
+    items = [(f.contiguous(), nb, bi, by, ch, th) for (f, nb, bi, by, ch, th) in items]
+    if not items:
+        return []
+    dev = items[0][0].device
+    caps = [max(lib.compress_bound(f.numel(), nb, ch, 0), 16) for (f, nb, _, _, ch, _) in items]
+    offs, o = [], 0
+    for c in caps:
+        offs.append(o); o += (c + 255) // 256 * 256
+    arena = torch.empty(max(o, 16), dtype=torch.uint8, device=dev)
+    base = arena.data_ptr()
+    with torch.cuda.device(dev) if dev.type == "cuda" else _nullctx():
+        lens = lib.compress_batch_dev(((f.data_ptr() if f.numel() else 0, f.numel(), nb, bi, by, ch, th, base + b0, c)
+                                       for (f, nb, bi, by, ch, th), c, b0 in zip(items, caps, offs)), _stream_handle(arena))
+    return [arena[b0:b0 + n] for b0, n in zip(offs, lens)]

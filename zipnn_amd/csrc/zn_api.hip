@@ -29,14 +29,15 @@ thread_local std::string t_kernels;
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
   size_t last_tails = 0;         // tail planes of the last decompress call (for zn_last_tail_planes)
-  void* buf[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched decode
+  void* buf[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched call (capacity in ZnSeg units)
+  uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;   // pinned: body lengths of a batched compress
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
 };
-enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_COUNT };
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_COUNT };
 
 std::mutex g_mu;
 Workspace g_ws[64];
@@ -117,51 +118,133 @@ size_t zn_compress_bound(size_t n, int num_buf, size_t chunk, size_t hdr_len) {
   return hdr_len + 9u * (size_t)num_buf * zn_num_chunks(n, chunk) + n;
 }
 
-int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                    float threshold, void* d_body, size_t body_cap, size_t* body_len, void* stream_) {
-  ZnGeom g;
-  int rc = check_geom(n, num_buf, bytes_mode, chunk, &g, bits_mode);
-  if (rc) return rc;
-  if (!body_len || (n && (!d_src || !d_body))) return ZN_E_ARG;
-  if (body_cap < zn_compress_bound(n, num_buf, chunk, 0)) return ZN_E_CAP;
-  hipStream_t stream = (hipStream_t)stream_;
+// Compress `count` tensors: one launch per stage and plane count over all of them (a single tensor travels to the
+// kernels as an argument, a batch as a segment table), one read-back of all body lengths.
+static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t stream) {
+  if (count && !items) return ZN_E_ARG;
+  std::vector<ZnESeg> segs[3];                   // by plane count: 1, 2, 4
+  std::vector<size_t> owner[3];                  // item index of each segment
+  uint64_t pc_all = 0, slot_all = 0; size_t slot = 0;
+  uint64_t chunks_of[3] = {0, 0, 0}, jobs_of[3] = {0, 0, 0}, tails_of[3] = {0, 0, 0}, ptails_of[3] = {0, 0, 0}, scan_of[3] = {0, 0, 0};
+  bool any_fused = false;
+  for (size_t i = 0; i < count; i++) {
+    zn_cbatch_item& it = items[i];
+    ZnESeg sg; memset(&sg, 0, sizeof(sg));
+    int rc = check_geom(it.n, it.num_buf, it.bytes_mode, it.chunk, &sg.g, it.bits_mode);
+    if (rc) return rc;
+    if (it.n && (!it.d_src || !it.d_body)) return ZN_E_ARG;
+    if (it.body_cap < zn_compress_bound(it.n, it.num_buf, it.chunk, 0)) return ZN_E_CAP;
+    it.body_len = 0;
+    const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
+    const uint64_t PK = (uint64_t)sg.g.P * sg.g.K;
+    sg.src = (const uint8_t*)it.d_src; sg.body = (uint8_t*)it.d_body; sg.threshold = it.threshold;
+    // full chunks go through the fused encoder, the partial tail (or everything, for geometries the fused
+    // kernels do not take) through the generic one
+    sg.nfull = zn_encode_fused_ok(sg.g, it.d_src) ? (uint64_t)(it.n / it.chunk) : 0;
+    any_fused = any_fused || sg.nfull;
+    const uint64_t KL = sg.g.K - sg.nfull;
+    sg.pc0 = pc_all; sg.slot0 = slot_all; sg.total_idx = i;
+    uint32_t blocks = 0; zn_scan_geometry(PK, &sg.T, &blocks);
+    sg.chunk0 = (uint32_t)chunks_of[q]; sg.job0 = (uint32_t)jobs_of[q]; sg.tail0 = (uint32_t)tails_of[q];
+    sg.ptail0 = (uint32_t)ptails_of[q]; sg.scan0 = (uint32_t)scan_of[q];
+    chunks_of[q] += sg.nfull; jobs_of[q] += sg.nfull * sg.g.P; tails_of[q] += KL; ptails_of[q] += KL * sg.g.P; scan_of[q] += blocks;
+    pc_all += PK; slot_all += KL * sg.g.P;
+    const size_t sl = zn_plane_slot(it.chunk, it.num_buf);
+    if (sl > slot) slot = sl;                    // one slot stride for the whole launch
+    if (jobs_of[q] > 0x7FFFFFFFull || ptails_of[q] > 0x7FFFFFFFull || pc_all > 0x7FFFFFFFFFull) return ZN_E_ARG;
+    segs[q].push_back(sg); owner[q].push_back(i);
+  }
+  if (count == 0) return ZN_OK;
   int dev = 0;
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   t_kernels.clear();
   std::lock_guard<std::mutex> lk(g_mu);
   Workspace& w = g_ws[dev];
-  const size_t slot = zn_plane_slot(chunk, num_buf);
-  const size_t PK = (size_t)g.P * g.K;
-  // full chunks go through the fused encoder, the partial tail (or everything, for geometries the fused
-  // kernels do not take) through the generic one
-  const uint64_t nfull = zn_encode_fused_ok(g, d_src) ? (uint64_t)(n / chunk) : 0;
-  const size_t PKL = (size_t)g.P * (g.K - nfull);
-  if ((rc = ws_reserve(w, WS_PLANES, PKL * slot))) return rc;
-  if ((rc = ws_reserve(w, WS_ENC, PKL * slot))) return rc;
-  if ((rc = ws_reserve(w, WS_META_A, PK * sizeof(uint32_t)))) return rc;   // stored sizes
-  if ((rc = ws_reserve(w, WS_META_B, PK))) return rc;                      // types
-  if ((rc = ws_reserve(w, WS_META_C, PK * sizeof(uint64_t)))) return rc;   // payload offsets
-  if ((rc = ws_reserve(w, WS_DESC, (nfull ? PK : 0) * sizeof(ZnEncDesc)))) return rc;   // indexed like csize/type (plane-major over all K)
+  int rc;
+  const size_t nseg_all = segs[0].size() + segs[1].size() + segs[2].size();
+  const bool table = nseg_all > 1;
+  if ((rc = ws_reserve(w, WS_PLANES, slot_all * slot))) return rc;
+  if ((rc = ws_reserve(w, WS_ENC, slot_all * slot))) return rc;
+  if ((rc = ws_reserve(w, WS_META_A, pc_all * sizeof(uint32_t)))) return rc;   // stored sizes
+  if ((rc = ws_reserve(w, WS_META_B, pc_all))) return rc;                      // types
+  if ((rc = ws_reserve(w, WS_META_C, pc_all * sizeof(uint64_t)))) return rc;   // payload offsets
+  if ((rc = ws_reserve(w, WS_DESC, (any_fused ? pc_all : 0) * sizeof(ZnEncDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
+  if ((rc = ws_reserve(w, WS_TOTALS, count * sizeof(uint64_t)))) return rc;
   if ((rc = ws_host_words(w))) return rc;
+  if (w.h_totals_cap < count) {
+    if (w.h_totals) { ZN_HIP(hipHostFree(w.h_totals)); w.h_totals = nullptr; w.h_totals_cap = 0; }
+    ZN_HIP(hipHostMalloc((void**)&w.h_totals, count * sizeof(uint64_t), hipHostMallocDefault));
+    w.h_totals_cap = count;
+  }
+  if (table) {
+    if ((rc = ws_reserve(w, WS_SEGS, nseg_all * sizeof(ZnESeg)))) return rc;
+    const size_t need = nseg_all * sizeof(ZnESeg);
+    if (w.h_segs_cap * sizeof(ZnSeg) < need) {
+      if (w.h_segs) { ZN_HIP(hipHostFree(w.h_segs)); w.h_segs = nullptr; w.h_segs_cap = 0; }
+      ZN_HIP(hipHostMalloc((void**)&w.h_segs, need, hipHostMallocDefault));
+      w.h_segs_cap = (need + sizeof(ZnSeg) - 1) / sizeof(ZnSeg);
+    }
+  }
   if ((rc = ws_acquire(w, stream))) return rc;
-  uint64_t* d_total = (uint64_t*)w.buf[WS_WORDS];
+  uint64_t* d_totals = (uint64_t*)w.buf[WS_TOTALS];
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
   ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
-  zn_launch_encode_fused_stats(g, nfull, (const uint8_t*)d_src, threshold, d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], stream);
-  zn_launch_encode_generic_stats(g, nfull, (const uint8_t*)d_src, threshold, (uint8_t*)w.buf[WS_PLANES], (uint8_t*)w.buf[WS_ENC], d_csize, d_type, stream);
-  zn_launch_scan_sizes(g, d_csize, d_type, d_offs, d_total, (uint8_t*)d_body, stream);
-  zn_launch_encode_fused_emit(g, nfull, (const uint8_t*)d_src, d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], (uint8_t*)d_body, d_status, stream);
-  zn_launch_encode_generic_gather(g, nfull, (const uint8_t*)w.buf[WS_PLANES], (const uint8_t*)w.buf[WS_ENC], d_csize, d_type, d_offs, (uint8_t*)d_body, stream);
+  if (table) {
+    ZN_HIP(hipEventSynchronize(w.busy));         // the previous batched call may still be reading the pinned staging
+    ZnESeg* hs = (ZnESeg*)w.h_segs; size_t o = 0;
+    for (int q = 0; q < 3; q++) for (const ZnESeg& sg : segs[q]) hs[o++] = sg;
+    ZN_HIP(hipMemcpyAsync(w.buf[WS_SEGS], hs, nseg_all * sizeof(ZnESeg), hipMemcpyHostToDevice, stream));
+  }
+  size_t seg_base = 0;
+  for (int stage = 0; stage < 3; stage++) {      // stats (fused + generic) for every plane count, then the scans, then emit / gather
+    seg_base = 0;
+    for (int q = 0; q < 3; q++) {
+      if (segs[q].empty()) continue;
+      const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
+      const ZnESeg* d_segs = table ? (const ZnESeg*)w.buf[WS_SEGS] + seg_base : nullptr;
+      const uint32_t nseg = (uint32_t)segs[q].size();
+      const ZnESeg& one = segs[q][0];
+      if (stage == 0) {
+        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], stream);
+        zn_launch_encode_generic_stats(P, one, d_segs, nseg, (uint32_t)tails_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES],
+                                       (uint8_t*)w.buf[WS_ENC], slot, d_csize, d_type, stream);
+      } else if (stage == 1) {
+        zn_launch_scan_sizes(one, d_segs, nseg, (uint32_t)scan_of[q], d_csize, d_type, d_offs, d_totals, stream);
+      } else {
+        zn_launch_encode_fused_emit(P, one, d_segs, nseg, (uint32_t)chunks_of[q], d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, stream);
+        zn_launch_encode_generic_gather(one, d_segs, nseg, (uint32_t)ptails_of[q], (const uint8_t*)w.buf[WS_PLANES], (const uint8_t*)w.buf[WS_ENC],
+                                        slot, d_csize, d_type, d_offs, stream);
+      }
+      seg_base += nseg;
+    }
+  }
   ZN_HIP(hipGetLastError());
-  ZN_HIP(hipMemcpyAsync(w.h_total, d_total, 40, hipMemcpyDeviceToHost, stream));   // total length (bytes 0-7) and the status word (bytes 32-35)
+  ZN_HIP(hipMemcpyAsync(w.h_totals, d_totals, count * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if ((rc = ws_release(w, stream))) return rc;
   ZN_HIP(hipStreamSynchronize(stream));
-  *body_len = (size_t)*w.h_total;
+  for (size_t i = 0; i < count; i++) items[i].body_len = (size_t)w.h_totals[i];
   if (*w.h_status) return ZN_E_CORRUPT;   // internal consistency check of the encoder failed
   return ZN_OK;
+}
+
+int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                    float threshold, void* d_body, size_t body_cap, size_t* body_len, void* stream_) {
+  if (!body_len) return ZN_E_ARG;
+  zn_cbatch_item it;
+  it.d_src = d_src; it.n = n; it.num_buf = num_buf; it.bits_mode = bits_mode; it.bytes_mode = bytes_mode; it.chunk = chunk;
+  it.threshold = threshold; it.d_body = d_body; it.body_cap = body_cap; it.body_len = 0;
+  int rc;
+  try { rc = compress_items(&it, 1, (hipStream_t)stream_); } catch (...) { return ZN_E_ALLOC; }
+  *body_len = it.body_len;
+  return rc;
+}
+
+int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream_) {
+  try { return compress_items(items, count, (hipStream_t)stream_); } catch (...) { return ZN_E_ALLOC; }
 }
 
 // Decode `count` tensors in one set of launches per plane count.  A single tensor travels to the kernels as an
@@ -373,12 +456,13 @@ int zn_release_workspace(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 64; d++) {
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
     for (int i = 0; i < WS_COUNT; i++) if (w.buf[i]) { (void)hipFree(w.buf[i]); w.buf[i] = nullptr; w.cap[i] = 0; }
     if (w.h_segs) { (void)hipHostFree(w.h_segs); w.h_segs = nullptr; w.h_segs_cap = 0; }
+    if (w.h_totals) { (void)hipHostFree(w.h_totals); w.h_totals = nullptr; w.h_totals_cap = 0; }
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
   }

@@ -88,12 +88,17 @@ struct ZnStatsLds {
 // quarter the columns are summed (thread = bin), which yields the per-stream symbol counts that turn code
 // lengths into stream sizes later without a second pass over the data.
 template <int P>
-__global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnGeom g, const uint8_t* __restrict__ src, float threshold,
-                                                                  uint32_t* __restrict__ csize_out, uint8_t* __restrict__ type_out,
-                                                                  ZnEncDesc* __restrict__ descs) {
+__global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                                  uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
+                                                                  ZnEncDesc* __restrict__ descs_all) {
   __shared__ ZnStatsLds<P> L;
+  const ZnESeg S = zn_efind_chunk(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); const float threshold = S.threshold;
+  uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
+  ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c = blockIdx.x;
+  const uint64_t c = blockIdx.x - S.chunk0;
   const uint32_t n = (uint32_t)(g.chunk / P);                 // plane length of a full chunk (the host launches full, eligible chunks only)
   ZN_PT_DECL;
 
@@ -176,12 +181,18 @@ struct ZnTablesLds {
   uint32_t go, hdr, cs, hl;
 };
 
-__global__ __launch_bounds__(64) void zn_k_encode_tables(ZnGeom g, uint64_t nfull, float threshold, uint32_t* __restrict__ csize_out,
-                                                         uint8_t* __restrict__ type_out, ZnEncDesc* __restrict__ descs) {
+__global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                         uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
+                                                         ZnEncDesc* __restrict__ descs_all) {
   __shared__ ZnTablesLds L;
+  const ZnESeg S = zn_efind_job(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g; const uint64_t nfull = S.nfull; const float threshold = S.threshold;
+  uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
+  ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
   const uint32_t lane = threadIdx.x;
-  const uint32_t p = (uint32_t)(blockIdx.x / nfull);
-  const uint64_t c = blockIdx.x % nfull, pc = (uint64_t)p * g.K + c;
+  const uint64_t job = blockIdx.x - S.job0;
+  const uint32_t p = (uint32_t)(job / nfull);
+  const uint64_t c = job % nfull, pc = (uint64_t)p * g.K + c;
   if (type_out[pc] != 2) return;
   const uint32_t n = (uint32_t)(g.chunk / g.P);
   const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
@@ -437,13 +448,18 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
 }
 
 template <int P>
-__global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnGeom g, const uint8_t* __restrict__ src,
-                                                                 const uint32_t* __restrict__ csize, const uint8_t* __restrict__ type,
-                                                                 const uint64_t* __restrict__ offs, const ZnEncDesc* __restrict__ descs,
-                                                                 uint8_t* __restrict__ body, uint32_t* __restrict__ status) {
+__global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                                 const uint32_t* __restrict__ csize_all, const uint8_t* __restrict__ type_all,
+                                                                 const uint64_t* __restrict__ offs_all, const ZnEncDesc* __restrict__ descs_all,
+                                                                 uint32_t* __restrict__ status) {
   __shared__ ZnEmitLds<P> L;
+  const ZnESeg S = zn_efind_chunk(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
+  const uint32_t* __restrict__ csize = csize_all + S.pc0; const uint8_t* __restrict__ type = type_all + S.pc0;
+  const uint64_t* __restrict__ offs = offs_all + S.pc0; const ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c = blockIdx.x;
+  const uint64_t c = blockIdx.x - S.chunk0;
   const uint8_t* chunk_src = src + c * g.chunk;
   uint64_t off[P]; uint32_t kind[P]; int nhuf = 0;           // kind: 0 raw, 1 RLE, 2 huff0
   for (int p = 0; p < P; p++) {
@@ -493,22 +509,23 @@ bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src) {
   return (g.chunk % 16384ull) == 0 && (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
 }
 
-void zn_launch_encode_fused_stats(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, float threshold, uint32_t* d_csize,
-                                  uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream) {
-  if (nfull == 0) return;
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_encode_stats<1>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_encode_stats<2>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
-  else hipLaunchKernelGGL(zn_k_encode_stats<4>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, threshold, d_csize, d_type, d_descs);
+void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream) {
+  if (total_chunks == 0) return;
+  if (P == 1) hipLaunchKernelGGL(zn_k_encode_stats<1>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_encode_stats<2>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
+  else hipLaunchKernelGGL(zn_k_encode_stats<4>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
   zn_note_kernel("zn_k_encode_stats");
-  hipLaunchKernelGGL(zn_k_encode_tables, dim3((uint32_t)(nfull * g.P)), dim3(64), 0, stream, g, nfull, threshold, d_csize, d_type, d_descs);
+  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
   zn_note_kernel("zn_k_encode_tables");
 }
 
-void zn_launch_encode_fused_emit(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, const uint32_t* d_csize, const uint8_t* d_type,
-                                 const uint64_t* d_offs, const ZnEncDesc* d_descs, uint8_t* d_body, uint32_t* d_status, hipStream_t stream) {
-  if (nfull == 0) return;
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_encode_emit<1>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, d_csize, d_type, d_offs, d_descs, d_body, d_status);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_encode_emit<2>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, d_csize, d_type, d_offs, d_descs, d_body, d_status);
-  else hipLaunchKernelGGL(zn_k_encode_emit<4>, dim3((uint32_t)nfull), dim3(ZN_E_THREADS), 0, stream, g, d_src, d_csize, d_type, d_offs, d_descs, d_body, d_status);
+void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
+                                 const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
+                                 uint32_t* d_status, hipStream_t stream) {
+  if (total_chunks == 0) return;
+  if (P == 1) hipLaunchKernelGGL(zn_k_encode_emit<1>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_encode_emit<2>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status);
+  else hipLaunchKernelGGL(zn_k_encode_emit<4>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status);
   zn_note_kernel("zn_k_encode_emit");
 }

@@ -21,9 +21,13 @@
 // kernel 1: rotate + split
 // ---------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void zn_k_split_planes(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ src,
-                                                         uint8_t* __restrict__ planes, uint64_t slot) {
-  const uint64_t c = c0 + blockIdx.x, KL = g.K - c0;          // scratch slots are indexed relative to c0
+__global__ __launch_bounds__(256) void zn_k_split_planes(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                         uint8_t* __restrict__ planes_all, uint64_t slot) {
+  const ZnESeg S = zn_efind_tail(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g; const uint64_t c0 = S.nfull;
+  const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src);
+  uint8_t* __restrict__ planes = planes_all + S.slot0 * slot;
+  const uint64_t c = c0 + (blockIdx.x - S.tail0), KL = g.K - c0;          // scratch slots are indexed relative to c0
   const uint32_t clen = zn_chunk_len(g, c);
   const uint8_t* in = src + c * g.chunk;
   const uint32_t nwords = clen / 4u;
@@ -144,16 +148,20 @@ __device__ inline void zn_encode_stream_wave(uint8_t* dst, uint32_t nbytes, cons
   __syncthreads();
 }
 
-__global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ planes,
-                                                              uint8_t* __restrict__ enc, uint64_t slot, float threshold,
-                                                              uint32_t* __restrict__ csize_out, uint8_t* __restrict__ type_out) {
+__global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                              const uint8_t* __restrict__ planes_all, uint8_t* __restrict__ enc_all, uint64_t slot,
+                                                              uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all) {
+  const ZnESeg SG = zn_efind_ptail(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = SG.g; const uint64_t c0 = SG.nfull; const float threshold = SG.threshold;
+  const uint8_t* __restrict__ planes = planes_all + SG.slot0 * slot; uint8_t* __restrict__ enc = enc_all + SG.slot0 * slot;
+  uint32_t* __restrict__ csize_out = csize_all + SG.pc0; uint8_t* __restrict__ type_out = type_all + SG.pc0;
   __shared__ ZnTabScratch S;
   __shared__ ZnHNode nodes[513];
   __shared__ uint32_t sh_hdr, sh_go, sh_bits[4];
   __shared__ uint32_t sh_buf[ZN_G_BUF_DW];
 
   const uint32_t lane = threadIdx.x;
-  const uint64_t KL = g.K - c0, pcl = blockIdx.x;              // local (scratch) index
+  const uint64_t KL = g.K - c0, pcl = blockIdx.x - SG.ptail0;  // local (scratch) index
   const uint32_t p = (uint32_t)(pcl / KL);
   const uint64_t c = c0 + pcl % KL;
   const uint64_t pc = (uint64_t)p * g.K + c;                   // global index
@@ -257,17 +265,23 @@ __device__ __forceinline__ uint64_t zn_wave_sum64(uint64_t v) {
   }
   return v;
 }
-__global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnGeom g, uint64_t T, const uint32_t* __restrict__ csize,
-                                                                   const uint8_t* __restrict__ type, uint64_t* __restrict__ offs,
-                                                                   uint64_t* __restrict__ total, uint8_t* __restrict__ body) {
+__global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                                   const uint32_t* __restrict__ csize_all, const uint8_t* __restrict__ type_all,
+                                                                   uint64_t* __restrict__ offs_all, uint64_t* __restrict__ total_all) {
+  const ZnESeg S = zn_efind_scan(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g; const uint64_t T = S.T;
+  const uint32_t* __restrict__ csize = csize_all + S.pc0; const uint8_t* __restrict__ type = type_all + S.pc0;
+  uint64_t* __restrict__ offs = offs_all + S.pc0; uint64_t* __restrict__ total = total_all + S.total_idx;
+  uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
+  const uint32_t blk = blockIdx.x - S.scan0;
   __shared__ uint64_t red[ZN_SCAN_THREADS / 64][4];
   __shared__ uint32_t wtot[ZN_SCAN_THREADS / 64];
   __shared__ uint64_t pb_s[4];                 // scan value at a plane start that lies inside this block
   const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
   const uint64_t PK = (uint64_t)g.P * g.K, K = g.K;
-  if (K == 0) { if (t == 0 && blockIdx.x == 0) *total = 0; return; }       // empty input: empty body
+  if (K == 0) { if (t == 0 && blk == 0) *total = 0; return; }       // empty input: empty body
   uint8_t* cum = body + PK;
-  const uint64_t i0 = (uint64_t)blockIdx.x * T, i1 = (i0 + T < PK) ? i0 + T : PK;
+  const uint64_t i0 = (uint64_t)blk * T, i1 = (i0 + T < PK) ? i0 + T : PK;
   if (i0 >= PK) return;
 
   // everything in front of the block, by plane
@@ -320,11 +334,16 @@ __global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnGeom g, uin
 // ---------------------------------------------------------------------------
 // kernel 4: payload gather
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void zn_k_gather_payload(ZnGeom g, uint64_t c0, const uint8_t* __restrict__ planes,
-                                                           const uint8_t* __restrict__ enc, uint64_t slot,
-                                                           const uint32_t* __restrict__ csize, const uint8_t* __restrict__ type,
-                                                           const uint64_t* __restrict__ offs, uint8_t* __restrict__ body) {
-  const uint64_t KL = g.K - c0, pcl = blockIdx.x;
+__global__ __launch_bounds__(256) void zn_k_gather_payload(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                           const uint8_t* __restrict__ planes_all, const uint8_t* __restrict__ enc_all, uint64_t slot,
+                                                           const uint32_t* __restrict__ csize_all, const uint8_t* __restrict__ type_all,
+                                                           const uint64_t* __restrict__ offs_all) {
+  const ZnESeg S = zn_efind_ptail(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g; const uint64_t c0 = S.nfull;
+  const uint8_t* __restrict__ planes = planes_all + S.slot0 * slot; const uint8_t* __restrict__ enc = enc_all + S.slot0 * slot;
+  const uint32_t* __restrict__ csize = csize_all + S.pc0; const uint8_t* __restrict__ type = type_all + S.pc0;
+  const uint64_t* __restrict__ offs = offs_all + S.pc0; uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
+  const uint64_t KL = g.K - c0, pcl = blockIdx.x - S.ptail0;
   const uint64_t pc = (pcl / KL) * g.K + c0 + pcl % KL;
   const uint8_t* s = (type[pc] ? enc : planes) + pcl * slot;
   uint8_t* d = body + offs[pc];
@@ -333,36 +352,35 @@ __global__ __launch_bounds__(256) void zn_k_gather_payload(ZnGeom g, uint64_t c0
   for (uint32_t i = lo + threadIdx.x; i < hi; i += blockDim.x) d[i] = s[i];
 }
 
-void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t* d_src, float threshold, uint8_t* d_planes,
-                                    uint8_t* d_enc, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream) {
-  if (c0 >= g.K) return;
-  const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
-  const uint32_t KL = (uint32_t)(g.K - c0), PKL = (uint32_t)g.P * KL;
-  if (g.P == 1) hipLaunchKernelGGL(zn_k_split_planes<1>, dim3(KL, 16), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
-  else if (g.P == 2) hipLaunchKernelGGL(zn_k_split_planes<2>, dim3(KL, 16), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
-  else hipLaunchKernelGGL(zn_k_split_planes<4>, dim3(KL, 16), dim3(256), 0, stream, g, c0, d_src, d_planes, slot);
+void zn_launch_encode_generic_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_tails, uint32_t total_ptails,
+                                    uint8_t* d_planes, uint8_t* d_enc, uint64_t slot, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream) {
+  if (total_tails == 0) return;
+  if (P == 1) hipLaunchKernelGGL(zn_k_split_planes<1>, dim3(total_tails, 16), dim3(256), 0, stream, one, d_segs, nseg, d_planes, slot);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_split_planes<2>, dim3(total_tails, 16), dim3(256), 0, stream, one, d_segs, nseg, d_planes, slot);
+  else hipLaunchKernelGGL(zn_k_split_planes<4>, dim3(total_tails, 16), dim3(256), 0, stream, one, d_segs, nseg, d_planes, slot);
   zn_note_kernel("zn_k_split_planes");
-  hipLaunchKernelGGL(zn_k_encode_planes, dim3(PKL), dim3(ZN_WAVE), 0, stream, g, c0, d_planes, d_enc, slot, threshold, d_csize, d_type);
+  hipLaunchKernelGGL(zn_k_encode_planes, dim3(total_ptails), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, d_planes, d_enc, slot, d_csize, d_type);
   zn_note_kernel("zn_k_encode_planes");
 }
 
-void zn_launch_scan_sizes(const ZnGeom& g, const uint32_t* d_csize, const uint8_t* d_type, uint64_t* d_offs,
-                          uint64_t* d_total, uint8_t* d_body, hipStream_t stream) {
-  // ≤ 256 blocks of T entries each, T a multiple of the tile size
-  const uint64_t PK = (uint64_t)g.P * g.K;
+// ≤ 256 blocks of T entries each, T a multiple of the tile size
+void zn_scan_geometry(uint64_t PK, uint64_t* T_out, uint32_t* blocks) {
   uint64_t nb = (PK + 511u) / 512u; if (nb > 256u) nb = 256u; if (nb < 1u) nb = 1u;
   uint64_t T = (PK + nb - 1u) / nb; T = (T + ZN_SCAN_THREADS - 1u) / ZN_SCAN_THREADS * ZN_SCAN_THREADS; if (T == 0) T = ZN_SCAN_THREADS;
-  const uint32_t grid = PK ? (uint32_t)((PK + T - 1u) / T) : 1u;
-  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(grid), dim3(ZN_SCAN_THREADS), 0, stream, g, T, d_csize, d_type, d_offs, d_total, d_body);
+  *T_out = T; *blocks = PK ? (uint32_t)((PK + T - 1u) / T) : 1u;
+}
+
+void zn_launch_scan_sizes(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_blocks, const uint32_t* d_csize,
+                          const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, hipStream_t stream) {
+  if (total_blocks == 0) return;
+  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(total_blocks), dim3(ZN_SCAN_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_total);
   zn_note_kernel("zn_k_scan_sizes");
 }
 
-void zn_launch_encode_generic_gather(const ZnGeom& g, uint64_t c0, const uint8_t* d_planes, const uint8_t* d_enc,
-                                     const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, uint8_t* d_body,
-                                     hipStream_t stream) {
-  if (c0 >= g.K) return;
-  const uint64_t slot = zn_plane_slot(g.chunk, (int)g.P);
-  const uint32_t PKL = (uint32_t)(g.P * (g.K - c0));
-  hipLaunchKernelGGL(zn_k_gather_payload, dim3(PKL, 16), dim3(256), 0, stream, g, c0, d_planes, d_enc, slot, d_csize, d_type, d_offs, d_body);
+void zn_launch_encode_generic_gather(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_ptails, const uint8_t* d_planes,
+                                     const uint8_t* d_enc, uint64_t slot, const uint32_t* d_csize, const uint8_t* d_type,
+                                     const uint64_t* d_offs, hipStream_t stream) {
+  if (total_ptails == 0) return;
+  hipLaunchKernelGGL(zn_k_gather_payload, dim3(total_ptails, 16), dim3(256), 0, stream, one, d_segs, nseg, d_planes, d_enc, slot, d_csize, d_type, d_offs);
   zn_note_kernel("zn_k_gather_payload");
 }

@@ -45,18 +45,7 @@ void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
                             uint8_t* d_tail_done, hipStream_t stream);
 
-// ---- generic encode path : zn_encode_generic.hip ----
-// Handles chunks [c0, K).  planes/enc: P*(K-c0) slots each; csize/type/offs: [P*K] (global indexing).
-void zn_launch_encode_generic_stats(const ZnGeom& g, uint64_t c0, const uint8_t* d_src, float threshold, uint8_t* d_planes,
-                                    uint8_t* d_enc, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream);
-// per-plane scan over ALL chunks: types, cumSizes (into the body), payload offsets, total body length
-void zn_launch_scan_sizes(const ZnGeom& g, const uint32_t* d_csize, const uint8_t* d_type, uint64_t* d_offs,
-                          uint64_t* d_total, uint8_t* d_body, hipStream_t stream);
-void zn_launch_encode_generic_gather(const ZnGeom& g, uint64_t c0, const uint8_t* d_planes, const uint8_t* d_enc,
-                                     const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, uint8_t* d_body,
-                                     hipStream_t stream);
-
-// ---- fused encode path (full chunks [0, nfull)) : zn_encode_fused.hip ----
+// ---- encode ----
 struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs for a plane kept as huff0 / RLE
   uint32_t code[256];        // code value | code length << 16
   uint8_t  hdr[136];         // tree description (RLE: hdr[0] = the byte)
@@ -64,11 +53,62 @@ struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs f
   uint32_t ssize[4];         // stream sizes in bytes
   uint16_t qcount[4][256];   // symbol counts of each quarter (stats kernel → tables kernel)
 };
+
+// One tensor of a compress launch (a single tensor travels as a kernel argument, a batch — tensors of the same
+// plane count — as a table in device memory; workgroups find their tensor by binary search over the running
+// grid indices).  The per-(plane, chunk) arrays (stored size, type, payload offset, descriptor) of the whole
+// launch are concatenated; pc0 is this tensor's base in them, index p·K + c inside.
+struct ZnESeg {
+  ZnGeom g;
+  const uint8_t* src; uint8_t* body;
+  float threshold; uint32_t pad_;
+  uint64_t nfull;      // chunks [0, nfull) go through the fused kernels, [nfull, K) through the generic ones
+  uint64_t pc0;        // base of its (plane, chunk) entries
+  uint64_t slot0;      // base of its generic-path scratch slots (P·(K-nfull) of them)
+  uint64_t total_idx;  // where its body length goes (d_total[total_idx])
+  uint64_t T;          // scan: entries per block
+  uint32_t chunk0;     // grid key: first fused chunk (stats / emit)
+  uint32_t job0;       // grid key: first (plane, fused chunk) job (tables)
+  uint32_t tail0;      // grid key: first generic chunk (split)
+  uint32_t ptail0;     // grid key: first generic (plane, chunk) (encode planes / gather)
+  uint32_t scan0;      // grid key: first scan block
+  uint32_t pad2_;
+};
+
+// Slot stride of the generic path's scratch planes = zn_plane_slot(chunk, P).  All launchers: `one` when
+// d_segs == nullptr, else the table; grid totals are sums over the launch's tensors.
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src);
-void zn_launch_encode_fused_stats(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, float threshold, uint32_t* d_csize,
-                                  uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream);
-void zn_launch_encode_fused_emit(const ZnGeom& g, uint64_t nfull, const uint8_t* d_src, const uint32_t* d_csize, const uint8_t* d_type,
-                                 const uint64_t* d_offs, const ZnEncDesc* d_descs, uint8_t* d_body, uint32_t* d_status, hipStream_t stream);
+void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream);
+void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
+                                 const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
+                                 uint32_t* d_status, hipStream_t stream);
+void zn_launch_encode_generic_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_tails, uint32_t total_ptails,
+                                    uint8_t* d_planes, uint8_t* d_enc, uint64_t slot, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream);
+// per-tensor scan over ALL its chunks: types, cumSizes (into the body), payload offsets, total body length → d_total[total_idx]
+void zn_launch_scan_sizes(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_blocks, const uint32_t* d_csize,
+                          const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, hipStream_t stream);
+void zn_scan_geometry(uint64_t PK, uint64_t* T, uint32_t* blocks);     // entries per block / number of blocks for PK entries
+void zn_launch_encode_generic_gather(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_ptails, const uint8_t* d_planes,
+                                     const uint8_t* d_enc, uint64_t slot, const uint32_t* d_csize, const uint8_t* d_type,
+                                     const uint64_t* d_offs, hipStream_t stream);
 
 // kernel-name log for zn_last_kernels()
 void zn_note_kernel(const char* name);
+
+#if defined(__HIPCC__) || defined(ZN_SIMT_EMULATOR)
+// which tensor of a batched compress launch does grid index `b` belong to?  (last segment with key ≤ b; wave-uniform)
+#define ZN_DEF_EFIND(NAME, FIELD)                                                                                           \
+  __device__ __forceinline__ ZnESeg NAME(const ZnESeg& one, const ZnESeg* __restrict__ segs, uint32_t nseg, uint64_t b) { \
+    if (segs == nullptr) return one;                                                                                       \
+    uint32_t lo = 0, hi = nseg;                                                                                            \
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)segs[mid].FIELD <= b) lo = mid; else hi = mid; } \
+    return segs[lo];                                                                                                       \
+  }
+ZN_DEF_EFIND(zn_efind_chunk, chunk0)
+ZN_DEF_EFIND(zn_efind_job, job0)
+ZN_DEF_EFIND(zn_efind_tail, tail0)
+ZN_DEF_EFIND(zn_efind_ptail, ptail0)
+ZN_DEF_EFIND(zn_efind_scan, scan0)
+#undef ZN_DEF_EFIND
+#endif
