@@ -43,6 +43,12 @@ def test_safetensors_file_roundtrip_and_plugin(use_simt, tmp_path):
             got = f.get_tensor(k)
             assert got.dtype == v.dtype and got.shape == v.shape
             assert got.view(torch.uint8).numpy().tobytes() == v.contiguous().view(torch.uint8).numpy().tobytes()
+    # the producer's batched path (one compress call for the whole file) writes the same file
+    znn_b = safetensors_io.compress_safetensors_file(src, out_path=os.path.join(tmp_path, "b.znn.safetensors"), batched=True)
+    with safetensors.safe_open(znn_b, "pt", "cpu") as fb, safetensors.safe_open(znn_path, "pt", "cpu") as fa:
+        assert fa.metadata() == fb.metadata() and set(fa.keys()) == set(fb.keys())      # (safetensors orders metadata keys randomly)
+        for k in fa.keys():
+            assert fa.get_tensor(k).dtype == fb.get_tensor(k).dtype and torch.equal(fa.get_tensor(k).view(torch.uint8), fb.get_tensor(k).view(torch.uint8)), k
     # whole file in one batched decode (device = cpu memory under the emulator)
     loaded = safetensors_io.load_file(znn_path, device="cpu")
     assert set(loaded) == set(tensors)
@@ -94,3 +100,24 @@ def test_zipnn_api_errors_and_types(use_simt):
     zs = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 12)
     blob = zs.compress(raw)
     assert isinstance(blob, bytearray) and bytes(ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 12).decompress(blob)) == raw
+
+
+def test_streaming_compress_batched_equals_per_frame_loop(use_simt):
+    """The batched streaming compress produces exactly the frames of the per-piece loop (== the reference's
+    streaming output), also with a delta buffer; and decompresses back."""
+    import numpy as np
+    from zipnn_amd import ZipNN
+    g = torch.Generator().manual_seed(5)
+    raw = (torch.randn(150_000, generator=g) * 0.02).to(torch.bfloat16).view(torch.uint8).numpy().tobytes() + b"\x01\x02\x03"
+    z = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 16)
+    blob = z.compress(raw)
+    want = bytearray()
+    for off in range(0, len(raw), 1 << 16):
+        want += bytes(ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 16).compress_torch_numpy_byte(raw[off:off + (1 << 16)]))
+    assert bytes(blob) == bytes(want)
+    assert bytes(ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 16).decompress(blob)) == raw
+    other = np.random.default_rng(1).integers(0, 256, len(raw), dtype=np.uint8).tobytes()
+    zd = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 16, delta_compressed_type="byte")
+    blob2 = zd.compress(raw, delta_second_data=other)
+    back2 = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 16, delta_compressed_type="byte").decompress(blob2, delta_second_data=other)
+    assert bytes(back2) == raw

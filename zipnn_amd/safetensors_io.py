@@ -14,14 +14,16 @@ from .zipnn import (COMPRESSED_DTYPE, COMPRESSION_METHOD, METADATA_KEY, ZipNN, b
 SUFFIX = ".znn.safetensors"
 
 
-def compress_safetensors_file(filename, out_path=None, device="cpu", method=None):
+def compress_safetensors_file(filename, out_path=None, device="cpu", method=None, batched=None):
     """-> path of the compressed file.  `device` = where tensors are staged for compression
-    ("cuda:N" compresses in HBM; the compressed frames come back to the host for writing)."""
+    ("cuda:N" compresses in HBM; the compressed frames come back to the host for writing).  Tensors staged in HBM
+    are compressed by ONE batched call for the whole file (`batched=None`: automatic; True forces it)."""
     from safetensors import safe_open
     from safetensors.torch import save_file
     assert filename.endswith(".safetensors")
     out_path = out_path or filename[: -len(".safetensors")] + SUFFIX
     tensors, infos = {}, {}
+    batch = []                                        # (name, tensor, header, planes, bits, bytes, chunk)
     with safe_open(filename, "pt", device) as f:
         for name in f.keys():
             t = f.get_tensor(name)
@@ -29,6 +31,9 @@ def compress_safetensors_file(filename, out_path=None, device="cpu", method=None
                 tensors[name] = t.cpu()
                 continue
             znn = ZipNN(input_format="torch", bytearray_dtype=t.dtype, method=method or COMPRESSION_METHOD)
+            if t.is_cuda if batched is None else batched:
+                batch.append((name, t) + znn.torch_frame_plan(t) + (znn.compression_threshold,))
+                continue
             frame = znn.compress(t)                       # our compress never modifies `t`
             if len(frame) >= t.element_size() * t.nelement():
                 tensors[name] = t.cpu()
@@ -36,6 +41,20 @@ def compress_safetensors_file(filename, out_path=None, device="cpu", method=None
             tensors[name] = torch.frombuffer(bytearray(frame), dtype=COMPRESSED_DTYPE)
             infos[name] = build_compressed_tensor_info(t)
         metadata = dict(f.metadata() or {})
+    if batch:
+        # tensors staged in HBM: one batched compress for the whole file (zn_compress_batch_dev)
+        from . import _capi, codec
+        bodies = codec.compress_device_batch(_capi.lib(), [(codec.flat_bytes(t), P, bits, byts, chunk, th) for (_, t, _, P, bits, byts, chunk, th) in batch])
+        for (name, t, hdr, *_), body in zip(batch, bodies):
+            total = len(hdr) + body.numel()
+            if total >= t.element_size() * t.nelement():
+                tensors[name] = t.cpu()
+                continue
+            frame = bytearray(hdr)
+            frame[24:32] = total.to_bytes(8, "little")     # what the core writes at zipnn_core.c:121
+            frame += body.cpu().numpy().tobytes()
+            tensors[name] = torch.frombuffer(frame, dtype=COMPRESSED_DTYPE)
+            infos[name] = build_compressed_tensor_info(t)
     if not metadata:
         metadata = {"format": "pt"}                       # the reference silently drops the list when a file has no metadata
     set_compressed_tensors_metadata(infos, metadata)

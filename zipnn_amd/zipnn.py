@@ -191,6 +191,9 @@ class ZipNN:
         if self.is_streaming and self.input_format == EnumFormat.BYTE.value:
             mv = memoryview(data).cast("B")
             mvd = memoryview(delta_second_data).cast("B") if delta_second_data else None
+            batched = self._compress_stream_batched(mv, mvd)
+            if batched is not None:
+                return batched
             out = bytearray()
             for off in range(0, mv.nbytes, self.streaming_chunk):
                 piece = mv[off:off + self.streaming_chunk]
@@ -201,6 +204,51 @@ class ZipNN:
         if delta_second_data:
             data = _xor(data, delta_second_data)
         return self.compress_torch_numpy_byte(data, lossy_compressed_type, lossy_compressed_factor)
+
+    def _compress_stream_batched(self, mv, mvd):
+        """Streaming BYTE input (reference zipnn.py:612-635): the buffer crosses PCIe once, all `streaming_chunk`
+        pieces are compressed by ONE batched call (zn_compress_batch_dev), one copy back; the frames are the ones
+        the per-piece loop produces.  None = not applicable (the loop then raises the reference's errors for
+        unsupported dtypes, or handles the single-piece case)."""
+        dt = dtype_from_user(self.bytearray_dtype)
+        is_float = self.bytearray_dtype in ("float64", "float32", "float16", "bfloat16", "float8_e4m3fn", "float8_e5m2")
+        if dt is None or not is_float or mv.nbytes <= self.streaming_chunk:
+            return None
+        if mvd is not None:
+            mv = memoryview(_xor(mv, mvd[:mv.nbytes]))
+        h = self._header
+        h[5], h[6], h[15] = dt.byte_mode, dt.rotate, dt.code
+        chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
+        dev = torch.device("cuda", codec.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")      # (read-only input buffers: we only read them)
+            flat = torch.frombuffer(mv, dtype=torch.uint8).to(dev, non_blocking=True)
+        pieces = [flat[off:off + self.streaming_chunk] for off in range(0, mv.nbytes, self.streaming_chunk)]
+        bodies = codec.compress_device_batch(_capi.lib(), [(p, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold)
+                                                           for p in pieces])
+        payload = (torch.cat(bodies) if len(bodies) > 1 else bodies[0]).cpu().numpy()
+        out = bytearray()
+        o = 0
+        for p, b in zip(pieces, bodies):
+            h[16:24] = p.numel().to_bytes(8, "little")
+            h[24:32] = (HEADER_LEN + b.numel()).to_bytes(8, "little")     # what the core writes at zipnn_core.c:121
+            out += bytes(h)
+            out += payload[o:o + b.numel()].tobytes()
+            o += b.numel()
+        return out
+
+    def torch_frame_plan(self, t):
+        """Header and core parameters for compressing torch tensor `t` (no data work): (header bytes incl. the shape
+        extension and the length field, planes, bits_mode, bytes_mode, chunk) — what compress_torch_numpy_byte would use."""
+        dt = dtype_from_user(t.dtype)
+        if dt is None or not torch.is_floating_point(t):
+            raise ValueError("Support only torch.dtype float32/bfloat16/float16")
+        h = bytearray(self._header)
+        h[5], h[6], h[15] = dt.byte_mode, dt.rotate, dt.code
+        h[16:24] = (t.numel() * t.element_size()).to_bytes(8, "little")
+        chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
+        return bytes(h) + pack_shape(tuple(t.shape)), dt.planes, dt.rotate, dt.byte_mode, chunk
 
     def compress_torch_numpy_byte(self, data, lossy_compressed_type=None, lossy_compressed_factor=None):
         """dtype -> (planes, rotate, byte mode), header, flat byte view, core call.
