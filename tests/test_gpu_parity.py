@@ -304,3 +304,31 @@ def test_batched_compress_many_tensors(lib):
     outs = codec.decompress_device_batch(lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk) in zip(bodies, specs)])
     for d, o in zip(datas, outs):
         assert o.cpu().numpy().tobytes() == d
+
+
+def test_safetensors_file_through_hbm_batched_both_ways(lib, tmp_path):
+    """compress_safetensors_file(device="cuda:0") stages the tensors in HBM and compresses the file with one batched
+    call; load_file decodes it with one batched call; a CPU-side per-tensor read of the same file agrees."""
+    import os
+    import safetensors
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    g = torch.Generator().manual_seed(3)
+    tensors = {"w_bf16": (torch.randn(700, 1000, generator=g) * 0.02).to(torch.bfloat16),
+               "w_fp16": (torch.randn(300, 1001, generator=g) * 0.02).half(),
+               "w_fp32": torch.randn(513, 400, generator=g) * 0.02,
+               "ids": torch.arange(1000), "tiny": torch.randn(3, generator=g).to(torch.bfloat16),
+               "w_fp8": (torch.randn(200, 3000, generator=g) * 0.02).to(torch.float8_e4m3fn)}
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    znn = safetensors_io.compress_safetensors_file(src, device="cuda:0")
+    assert os.path.getsize(znn) < os.path.getsize(src)
+    assert "zn_k_encode_emit" in lib.last_kernels()
+    loaded = safetensors_io.load_file(znn, device="cuda:0")
+    for k, v in tensors.items():
+        assert loaded[k].dtype == v.dtype and loaded[k].shape == v.shape and loaded[k].is_cuda
+        assert torch.equal(loaded[k].cpu().contiguous().view(torch.uint8), v.contiguous().view(torch.uint8)), k
+    cpu_path = safetensors_io.compress_safetensors_file(src, out_path=os.path.join(tmp_path, "c.znn.safetensors"))
+    with safetensors.safe_open(cpu_path, "pt", "cpu") as fa, safetensors.safe_open(znn, "pt", "cpu") as fb:
+        for k in fa.keys():
+            assert torch.equal(fa.get_tensor(k).view(torch.uint8), fb.get_tensor(k).view(torch.uint8)), k
