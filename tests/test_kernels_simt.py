@@ -282,3 +282,22 @@ def test_batched_compress_matches_per_tensor_frames(simt_lib):
     outs = codec.decompress_device_batch(simt_lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk) in zip(bodies, specs)])
     for d, o in zip(datas, outs):
         assert o.numpy().tobytes() == d
+
+
+def test_batch_entry_points_reject_bad_items(simt_lib):
+    """An invalid item fails the whole batch with the same error a single call gives; nothing is decoded / written."""
+    d = gen_bytes("bf16", 3 * C, 1)
+    src = torch.frombuffer(bytearray(d), dtype=torch.uint8)
+    body = torch.empty(simt_lib.compress_bound(len(d), 2, C, 0), dtype=torch.uint8)
+    good = (src.data_ptr(), len(d), 2, 1, 10, C, 0.95, body.data_ptr(), body.numel())
+    with pytest.raises(RuntimeError):                      # capacity below zn_compress_bound
+        simt_lib.compress_batch_dev([good, (src.data_ptr(), len(d), 2, 1, 10, C, 0.95, body.data_ptr(), 100)])
+    with pytest.raises(ValueError):                        # 3 planes do not exist
+        simt_lib.compress_batch_dev([good, (src.data_ptr(), len(d), 3, 1, 10, C, 0.95, body.data_ptr(), body.numel())])
+    assert simt_lib.compress_batch_dev([good]) == [len(O.compress_frame(HDR, d, 2, 1, 10, C)) - 32]
+    out = torch.empty(len(d), dtype=torch.uint8)
+    n = simt_lib.compress_batch_dev([good])[0]
+    with pytest.raises(RuntimeError):                      # body shorter than its own metadata
+        simt_lib.decompress_batch_dev([(body.data_ptr(), n, 2, 1, 10, C, len(d), out.data_ptr()), (body.data_ptr(), 5, 2, 1, 10, C, len(d), out.data_ptr())])
+    simt_lib.decompress_batch_dev([(body.data_ptr(), n, 2, 1, 10, C, len(d), out.data_ptr())])
+    assert out.numpy().tobytes() == d
