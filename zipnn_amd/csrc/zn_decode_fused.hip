@@ -1,29 +1,33 @@
 // zn_decode_fused.hip — the bandwidth path of decompress: one kernel, one pass over HBM.
 //
-// One workgroup (4 waves) per full chunk whose planes are raw/RLE plus at most one huff0
-// block (what real weights look like: bf16/fp32 exponent plane Huffman-coded, mantissa
-// planes stored raw).  Wave w owns quarter w of the chunk = stream w of the huff0 block.
+// One workgroup (4 waves) per GROUP of up to 4 consecutive full chunks whose planes are raw/RLE plus at
+// most one huff0 block (what real weights look like: bf16/fp32 exponent plane Huffman-coded, mantissa
+// planes stored raw).  Inside a chunk, wave w owns quarter w = stream w of the huff0 block.
 //
-//   1. threads < P parse the chunk's metadata; wave 0 turns the tree description into the
-//      canonical symbol order (zn_huf_wave.hpp: FSE chain on the scalar ALU, everything else
-//      with ballots); all 256 threads fill the single-symbol LUT and from it the MULTI-symbol
-//      LUT: one 64-bit entry per 11-bit window = up to 5 symbols, their start offsets, total.
-//   2. each wave decodes its backward bit-stream IN PARALLEL ACROSS ITS 64 LANES.  huff0 has no
-//      gap array, so this uses Huffman self-synchronisation, format-transparently: the stream
-//      is cut into tiles of 64 sub-blocks of D dwords; lane k guesses a start 48 bits
-//      above its sub-block, decodes until it crosses into it ("sync"), then decodes its
-//      sub-block counting symbols (branch-free steps, "refill + 3 lookups" unrolled); a wave shuffle checks that every lane's exit position is the
-//      next lane's start (mismatching lanes restart from the exact position until the chain is
-//      consistent, and the run-in is doubled for the rest of the stream — the top lane always
-//      starts from the true position carried from the previous tile); a prefix sum of the
-//      counts gives each lane its output offset and a second decode ORs the symbols into a
-//      small LDS ring (ds_or_b32: neighbouring lanes share boundary dwords).
-//   3. the number of complete output rows is known after the prefix sum, so the raw planes'
-//      bytes for exactly those rows are requested from HBM before the write pass and consumed
-//      after it: ring bytes + raw bytes are byte-interleaved with v_perm_b32, the sign-bit rotate
-//      is undone and 16-byte stores go out coalesced.  The next tile of the stream is prefetched
-//      into registers the same way.  Decoded symbols never touch HBM; the float stream is
-//      written once.
+//   1. one thread per (chunk, plane) parses the metadata; wave j turns chunk j's tree description into
+//      the canonical symbol order (zn_huf_wave.hpp: FSE chain on the scalar ALU, everything else with
+//      ballots) — four serial jobs side by side; then, chunk by chunk, all 256 threads fill the
+//      single-symbol LUT and from it the MULTI-symbol LUT: per 11-bit window up to 5 symbols, the bit
+//      offset at which each of them starts, the total.
+//   2. each wave decodes its backward bit-stream IN PARALLEL ACROSS ITS 64 LANES.  huff0 has no gap array,
+//      so this uses Huffman self-synchronisation, format-transparently: the stream is cut into tiles of 64
+//      sub-blocks of D dwords (D from the stream's average code length); lane k guesses a start 16 bits
+//      above its sub-block, decodes until it crosses into it ("sync"), then decodes its sub-block counting
+//      symbols ("refill + 3 whole-group steps", then a boundary step that takes exactly the symbols that
+//      start above the sub-block's end); a wave shuffle checks that every lane's exit position is the next
+//      lane's start (mismatching lanes restart from the exact position until the chain is consistent, and
+//      the run-in is doubled for the rest of the stream — the top lane always starts from the true
+//      position carried from the previous tile); a prefix sum of the counts gives each lane its output
+//      offset and a second decode ORs the symbols into a small LDS staging buffer (ds_or_b32: neighbouring
+//      lanes share boundary dwords; a tile denser than expected is written in lane groups).
+//   3. the number of complete output rows is known after the prefix sum, so the raw planes' bytes for
+//      exactly those rows are requested from HBM before the write pass and consumed after it: staging
+//      bytes + raw bytes get the sign-bit rotate undone at plane level, are byte-interleaved with
+//      v_perm_b32 and go out as coalesced 16-byte stores.  The next tile of the stream is prefetched
+//      into registers the same way.  Decoded symbols never touch HBM; the float stream is written once.
+//
+// A launch decodes one tensor or a batch (segment table, zn_internal.hpp); the Huffman planes of partial
+// last chunks are decoded by extra workgroups at the front of the same grid (zn_decode_tail_wg).
 //
 // Algorithmic HBM traffic per chunk: stored bytes in + chunk bytes out.
 // Chunks this kernel does not take (partial tail, ≥2 Huffman planes, tableLog 12, odd chunk
