@@ -241,7 +241,7 @@ static inline void zn_simt_wave_barrier() { zn_simt::collective(0, nullptr); }
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 
-// DPP data movement used by the wave scan: row_shr:n (0x110+n), row_bcast15 (0x142), row_bcast31 (0x143).
+// DPP data movement: quad_perm (0x00-0xFF), row_shr:n (0x110+n), row_bcast15 (0x142), row_bcast31 (0x143).
 // Lanes whose row is masked off, or whose source lane does not exist, return `old`.
 template <typename T> static inline T zn_simt_update_dpp(T old, T src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
   (void)bank_mask; (void)bound_ctrl;
@@ -249,7 +249,8 @@ template <typename T> static inline T zn_simt_update_dpp(T old, T src, int ctrl,
   const int l = (int)(zn_simt::E().cur->flat % 64), row = l >> 4, idx = l & 15;
   const uint64_t* r = zn_simt::collective(raw, nullptr);
   int from = -1;
-  if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (idx >= n) from = l - n; }
+  if (ctrl >= 0 && ctrl <= 0xFF) from = (l & ~3) | ((ctrl >> (2 * (l & 3))) & 3);        // quad_perm
+  else if (ctrl >= 0x111 && ctrl <= 0x11F) { const int n = ctrl - 0x110; if (idx >= n) from = l - n; }
   else if (ctrl == 0x142) { if (row >= 1) from = 16 * row - 1; }
   else if (ctrl == 0x143) { if (row >= 2) from = 31; }
   else { fprintf(stderr, "zn_simt: unsupported dpp_ctrl 0x%x\n", ctrl); abort(); }
