@@ -395,7 +395,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       if (!__any(mism)) { chained = true; break; }
       ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
       ZN_PT_COUNT(17, __popcll(__ballot(mism)));
-      if (it == 0) { delta *= 2; if (delta > 32 * Di) delta = 32 * Di; }
+      // a longer run-in for the rest of the stream: first to 21 bits (still one refill: the short sync path), then doubling
+      if (it == 0) { delta = (delta < 21) ? 21 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; }
       need = mism;
       if (mism) s = e_prev;
     }
