@@ -332,3 +332,52 @@ def test_safetensors_file_through_hbm_batched_both_ways(lib, tmp_path):
     with safetensors.safe_open(cpu_path, "pt", "cpu") as fa, safetensors.safe_open(znn, "pt", "cpu") as fb:
         for k in fa.keys():
             assert torch.equal(fa.get_tensor(k).view(torch.uint8), fb.get_tensor(k).view(torch.uint8)), k
+
+
+def _random_cases(n_cases, seed, max_bytes):
+    r = np.random.default_rng(seed)
+    kinds = ["bf16", "fp16", "fp32", "fp8", "rand", "const", "skew", "burst", "u11"]
+    out = []
+    for _ in range(n_cases):
+        P = int(r.choice([1, 2, 2, 2, 4]))
+        kind = str(r.choice(kinds))
+        bm = 220 if P == 4 else 10
+        rot = int(r.integers(0, 2)) if P > 1 else int(r.integers(0, 2))
+        # chunk: any multiple of P — tiny, odd multiples, fused-eligible ones, the default
+        chunk = int(r.choice([P * int(r.integers(1, 400)), 4096 * P, 16384, 65536, 3 * 16384, C, 12 * P * 1024 + P]))
+        chunk -= chunk % P
+        chunk = max(chunk, P)
+        nb = int(r.integers(0, max_bytes))
+        if r.random() < 0.3:
+            nb -= nb % chunk                                  # exact multiples too
+        thr = float(r.choice([0.95, 0.95, 0.5, 1.0, 0.99]))
+        out.append((kind, nb, P, rot, bm, chunk, thr))
+    return out
+
+
+def test_randomised_geometry_sweep_bit_exact(lib):
+    """160 random (distribution, size, planes, rotate, chunk size, threshold) combinations, incl. chunk sizes the fused
+    kernels do not take: frame == oracle frame byte for byte, decode == input; then all of them again through the
+    batched entry points."""
+    from test_kernels_simt import _gen2
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    cases = _random_cases(160, 2026, 3 * C)
+    datas, frames = [], []
+    for i, (kind, nb, P, rot, bm, chunk, thr) in enumerate(cases):
+        d = _gen2(kind, nb, 1000 + i)
+        nb = len(d)                                            # 'u11' rounds down to whole bf16 values
+        cases[i] = (kind, nb, P, rot, bm, chunk, thr)
+        want = O.compress_frame(HDR, d, P, rot, bm, chunk, thr, threads=4)
+        got = bytes(lib.compress(HDR, d, P, rot, bm, chunk, thr))
+        assert got == want, (i, cases[i])
+        if nb:
+            assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d, (i, cases[i])
+        datas.append(d); frames.append(want)
+    flats = [(torch.frombuffer(bytearray(d), dtype=torch.uint8) if d else torch.empty(0, dtype=torch.uint8)).to(dev) for d in datas]
+    bodies = codec.compress_device_batch(lib, [(f, P, rot, bm, chunk, thr) for f, (kind, nb, P, rot, bm, chunk, thr) in zip(flats, cases)])
+    for i, (b, fr) in enumerate(zip(bodies, frames)):
+        assert b.cpu().numpy().tobytes() == fr[32:], (i, cases[i])
+    outs = codec.decompress_device_batch(lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk, thr) in zip(bodies, cases)])
+    for i, (o, d) in enumerate(zip(outs, datas)):
+        assert o.cpu().numpy().tobytes() == d, (i, cases[i])

@@ -301,3 +301,28 @@ def test_batch_entry_points_reject_bad_items(simt_lib):
         simt_lib.decompress_batch_dev([(body.data_ptr(), n, 2, 1, 10, C, len(d), out.data_ptr()), (body.data_ptr(), 5, 2, 1, 10, C, len(d), out.data_ptr())])
     simt_lib.decompress_batch_dev([(body.data_ptr(), n, 2, 1, 10, C, len(d), out.data_ptr())])
     assert out.numpy().tobytes() == d
+
+
+def test_randomised_geometry_sweep_bit_exact(simt_lib):
+    """24 random (distribution, size, planes, rotate, chunk size, threshold) combinations under the emulator:
+    frame == oracle frame, decode == input, per call and batched."""
+    from test_gpu_parity import _random_cases
+    from zipnn_amd import codec
+    cases = _random_cases(24, 7, 70000)
+    datas, frames = [], []
+    for i, (kind, nb, P, rot, bm, chunk, thr) in enumerate(cases):
+        d = _gen2(kind, nb, 500 + i)
+        nb = len(d)                                            # 'u11' rounds down to whole bf16 values
+        cases[i] = (kind, nb, P, rot, bm, chunk, thr)
+        want = O.compress_frame(HDR, d, P, rot, bm, chunk, thr)
+        assert bytes(simt_lib.compress(HDR, d, P, rot, bm, chunk, thr)) == want, (i, cases[i])
+        if nb:
+            assert bytes(simt_lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d, (i, cases[i])
+        datas.append(d); frames.append(want)
+    flats = [torch.frombuffer(bytearray(d), dtype=torch.uint8) if d else torch.empty(0, dtype=torch.uint8) for d in datas]
+    bodies = codec.compress_device_batch(simt_lib, [(f, P, rot, bm, chunk, thr) for f, (kind, nb, P, rot, bm, chunk, thr) in zip(flats, cases)])
+    for i, (b, fr) in enumerate(zip(bodies, frames)):
+        assert b.numpy().tobytes() == fr[32:], (i, cases[i])
+    outs = codec.decompress_device_batch(simt_lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk, thr) in zip(bodies, cases)])
+    for i, (o, d) in enumerate(zip(outs, datas)):
+        assert o.numpy().tobytes() == d, (i, cases[i])
