@@ -106,6 +106,7 @@ typedef struct zn_cbatch_item {
   size_t chunk; float threshold;
   void* d_body; size_t body_cap;          /* >= zn_compress_bound(n, num_buf, chunk, 0) */
   size_t body_len;                        /* out */
+  const void* d_delta;                    /* NULL, or n bytes on the device: the tensor is compressed as src ^ delta */
 } zn_cbatch_item;
 int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream);
 
@@ -119,8 +120,25 @@ typedef struct zn_batch_item {
   void* d_dst; size_t orig_size;         /* receives orig_size bytes */
   int num_buf, bits_mode, bytes_mode;
   size_t chunk;
+  const void* d_delta;                   /* NULL, or orig_size bytes on the device: dst <- decoded ^ delta */
 } zn_batch_item;
 int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stream, int check);
+
+/* Delta ("byte"/"file" delta_compressed_type of the reference, zipnn/zipnn.py:625-640 and :983-1004: the bytes
+ * are XORed with a second buffer of the same length before compression and after decompression).  The XOR is
+ * fused into the kernels that read the tensor / write the output — no extra pass over HBM.  d_delta = NULL gives
+ * zn_compress_dev / zn_decompress_dev.  Batched: set d_delta in the items above. */
+int zn_compress_delta_dev(const void* d_src, const void* d_delta, size_t n, int num_buf, int bits_mode,
+                          int bytes_mode, size_t chunk, float threshold, void* d_body, size_t body_cap,
+                          size_t* body_len, void* stream);
+int zn_decompress_delta_dev(const void* d_body, size_t body_len, const void* d_delta, int num_buf, int bits_mode,
+                            int bytes_mode, size_t chunk, size_t orig_size, void* d_dst, void* stream, int check);
+/* … and with host buffers (`delta`: n / orig_size host bytes, or NULL): zn_compress / zn_decompress plus one more upload. */
+int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const void* delta, size_t n, int num_buf,
+                      int bits_mode, int bytes_mode, size_t chunk, float threshold, int device,
+                      void* dst, size_t dst_cap, size_t* dst_len);
+int zn_decompress_delta(const void* body, size_t body_len, const void* delta, int num_buf, int bits_mode,
+                        int bytes_mode, size_t chunk, size_t orig_size, int device, void* dst);
 
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);

@@ -50,14 +50,14 @@ def test_c_abi_bit_exact_vs_oracle(lib, case):
         assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d
 
 
-EDGE = [("skew", 4 * C, 1, 1, 10, 128 * KB, 8), ("skew", 4 * C, 2, 0, 10, C, 0), ("burst", 4 * C, 1, 1, 10, 128 * KB, 8),
+EDGE = [("skew", 4 * C, 1, 1, 10, 128 * KB, 8), ("skew", 4 * C, 2, 0, 10, C, 4), ("skew", 4 * C, 4, 1, 220, C, 4), ("skew", 4 * C, 2, 1, 10, C, 4), ("burst", 4 * C, 1, 1, 10, 128 * KB, 8),
         ("burst16", 8 * C, 2, 0, 10, C, 8), ("u11", 8 * C, 2, 1, 10, C, 8), ("burst16", 3 * 65536, 2, 0, 10, 65536, 3)]
 
 
 @pytest.mark.parametrize("case", EDGE, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
 def test_fused_kernels_on_hostile_distributions(lib, case):
     """1-bit codes, tiles far denser than the stream average (staging buffer flushed in lane groups), 11-bit
-    codes: frame identical to the oracle's, decode through the fused kernel gives the input back."""
+    codes, every plane Huffman-coded (one accumulate pass per further plane): frame identical to the oracle's, decode through the fused kernel gives the input back."""
     from test_kernels_simt import _gen2
     kind, nb, P, rot, bm, chunk, want_fused = case
     d = _gen2(kind, nb, 13)
@@ -103,7 +103,7 @@ def test_fused_decode_chunk_groups(lib, group, monkeypatch):
     want = O.compress_frame(HDR, d, 2, 0, 10, ch, threads=4)
     assert bytes(lib.compress(HDR, d, 2, 0, 10, ch, 0.95)) == want
     assert bytes(lib.decompress(want[32:], 2, 0, 10, ch, len(d))) == d
-    assert lib.last_fused_chunks() == 23 - 3            # the three "pair" chunks have two Huffman planes
+    assert lib.last_fused_chunks() == 23               # incl. the three "pair" chunks (two Huffman planes: two passes)
 
 
 @pytest.mark.parametrize("name", G.names())
@@ -381,3 +381,55 @@ def test_randomised_geometry_sweep_bit_exact(lib):
     outs = codec.decompress_device_batch(lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk, thr) in zip(bodies, cases)])
     for i, (o, d) in enumerate(zip(outs, datas)):
         assert o.cpu().numpy().tobytes() == d, (i, cases[i])
+
+
+@pytest.mark.parametrize("case", [("bf16", 6 * C + 1234, 2, 1, 10, C), ("fp32", 3 * C + 4 * 77, 4, 1, 220, C), ("fp8", 5 * 65536 + 5, 1, 1, 10, 65536),
+                                  ("bf16", 70001, 2, 1, 10, 4442), ("fp16", 4 * C, 2, 0, 10, C)],
+                         ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
+def test_delta_xor_fused_into_the_kernels(lib, case):
+    """compress(data, delta=base) == oracle frame of data ^ base; decompress(frame, delta=base) == data: host and
+    device entry points, aligned (fused kernels) and unaligned (generic kernels) base."""
+    from test_kernels_simt import _delta_pair
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    kind, nb, P, rot, bm, chunk = case
+    a, b = _delta_pair(kind, nb, 31)
+    nb = len(a)
+    x = (np.frombuffer(a, dtype=np.uint8) ^ np.frombuffer(b, dtype=np.uint8)).tobytes()
+    want = O.compress_frame(HDR, x, P, rot, bm, chunk, threads=4)
+    assert bytes(lib.compress(HDR, a, P, rot, bm, chunk, 0.95, delta=b)) == want
+    assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb, delta=b)) == a
+    assert "zn_k_decode_fused^delta" in lib.last_kernels()
+    ta = torch.frombuffer(bytearray(a), dtype=torch.uint8).to(dev)
+    for shift in (0, 1):
+        pad = torch.zeros(nb + 16, dtype=torch.uint8, device=dev)
+        pad[shift:shift + nb] = torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+        tb = pad[shift:shift + nb]
+        body = codec.compress_device(lib, ta, P, rot, bm, chunk, 0.95, delta=tb)
+        assert body.cpu().numpy().tobytes() == want[32:]
+        out = codec.decompress_device(lib, body, P, rot, bm, chunk, nb, delta=tb)
+        assert out.cpu().numpy().tobytes() == a
+        if shift:
+            assert lib.last_fused_chunks() == 0
+        elif nb >= chunk and chunk % 16384 == 0:
+            assert lib.last_fused_chunks() == nb // chunk
+
+
+def test_delta_device_resident_256MiB_roundtrip_and_ratio(lib):
+    """A `fine-tuned` bf16 tensor against its base, both in HBM: the body of x ^ base is what compressing the XOR
+    computed by torch gives, decoding with the base returns x; a sparse delta compresses far below the plain ratio."""
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev).manual_seed(5)
+    base = (torch.randn(128 << 20, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+    x = base.clone()
+    idx = torch.randint(0, x.numel(), (x.numel() // 50,), device=dev, generator=g)
+    x[idx] = (x[idx].float() * 1.01).to(torch.bfloat16)
+    fx, fb = codec.flat_bytes(x), codec.flat_bytes(base)
+    body = codec.compress_device(lib, fx, 2, 1, 10, C, 0.95, delta=fb)
+    ref = codec.compress_device(lib, torch.bitwise_xor(fx, fb), 2, 1, 10, C, 0.95)
+    assert torch.equal(body, ref)
+    out = codec.decompress_device(lib, body, 2, 1, 10, C, fx.numel(), delta=fb)
+    assert torch.equal(out, fx)
+    assert lib.last_fused_chunks() == fx.numel() // C
+    assert body.numel() < 0.2 * fx.numel()

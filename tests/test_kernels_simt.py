@@ -88,7 +88,9 @@ FUSED = [("bf16", 3 * C, 2, 1, 10, C, 3), ("bf16", 2 * C + 100, 2, 1, 10, C, 2),
          ("fp32", 2 * C, 4, 1, 220, C, 2), ("fp8", 2 * C, 1, 1, 10, C, 2), ("const", 2 * C, 2, 1, 10, C, 2),
          ("rand", 2 * C, 2, 1, 10, C, 2), ("u11", 2 * C, 2, 1, 10, C, 2), ("skew", 2 * C, 1, 1, 10, C, 2),
          ("burst", 2 * C, 1, 1, 10, C, 2), ("burst16", 4 * C, 2, 0, 10, 2 * C, 2),
-         ("bf16", 2 * 4096 * 3, 2, 1, 10, 4096, 6), ("bf16", 256 * 1024, 2, 1, 10, 256 * 1024, 1)]
+         ("bf16", 2 * 4096 * 3, 2, 1, 10, 4096, 6), ("bf16", 256 * 1024, 2, 1, 10, 256 * 1024, 1),
+         # every plane Huffman-coded: one accumulate pass per further plane
+         ("skew", 2 * C, 2, 0, 10, C, 2), ("skew", 2 * C, 2, 1, 10, C, 2), ("skew", 2 * C, 4, 1, 220, C, 2), ("skew", 65536, 4, 0, 220, 16384, 4)]
 
 
 def _gen2(kind, nb, seed):
@@ -114,7 +116,7 @@ def _gen2(kind, nb, seed):
 
 @pytest.mark.parametrize("case", FUSED, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
 def test_fused_decode_path(simt_lib, case):
-    """Full chunks with ≤ 1 Huffman plane must go through zn_k_decode_fused and give the input back."""
+    """Full chunks must go through zn_k_decode_fused (further Huffman planes: extra passes) and give the input back."""
     kind, nb, P, rot, bm, chunk, want_fused = case
     d = _gen2(kind, nb, 11)
     frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
@@ -129,14 +131,14 @@ def test_fused_decode_path(simt_lib, case):
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
 def test_fused_decode_chunk_groups(simt_lib, group, monkeypatch):
     """A workgroup decodes `group` consecutive chunks; groups may mix Huffman, raw-only, RLE and
-    two-Huffman-plane (generic path) chunks, and the last group may be short."""
+    two-Huffman-plane (one extra accumulate pass) chunks, and the last group may be short."""
     monkeypatch.setenv("ZN_DECODE_GROUP", str(group))
     ch = 16384
     r = np.random.default_rng(5)
     parts = []
     for k in range(11):
         kind = ["bf16", "rand", "const", "u11", "skewpair", "bf16"][k % 6]
-        if kind == "skewpair":   # both planes compressible → two Huffman planes → not fused
+        if kind == "skewpair":   # both planes compressible → two Huffman planes → a second pass of the fused kernel
             parts.append(r.choice(np.array([1, 2, 3, 4], dtype=np.uint8), ch, p=[0.7, 0.1, 0.1, 0.1]).tobytes())
         else:
             parts.append(_gen2(kind, ch, 20 + k))
@@ -146,7 +148,7 @@ def test_fused_decode_chunk_groups(simt_lib, group, monkeypatch):
     out = torch.empty(len(d), dtype=torch.uint8)
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), 2, 0, 10, ch, len(d), out.data_ptr())
     assert out.numpy().tobytes() == d
-    assert simt_lib.last_fused_chunks() == 9            # 11 full chunks minus the two "skewpair" ones
+    assert simt_lib.last_fused_chunks() == 11           # every full chunk, incl. the two "skewpair" ones (two passes)
 
 
 def test_fused_detects_corrupt_stream(simt_lib):
@@ -326,3 +328,70 @@ def test_randomised_geometry_sweep_bit_exact(simt_lib):
     outs = codec.decompress_device_batch(simt_lib, [(b, P, rot, bm, chunk, nb) for b, (kind, nb, P, rot, bm, chunk, thr) in zip(bodies, cases)])
     for i, (o, d) in enumerate(zip(outs, datas)):
         assert o.numpy().tobytes() == d, (i, cases[i])
+
+
+def _delta_pair(kind, nb, seed):
+    """(tensor bytes, base bytes): `fine-tuned` = base with a sparse perturbation, so the XOR is mostly zero bytes."""
+    a = np.frombuffer(_gen2(kind, nb, seed), dtype=np.uint8).copy()
+    r = np.random.default_rng(seed)
+    b = a.copy()
+    hit = r.random(len(a)) < 0.03
+    b[hit] ^= r.integers(1, 256, int(hit.sum()), dtype=np.uint8)
+    return a.tobytes(), b.tobytes()
+
+
+DELTA = [("bf16", 2 * C + 1234, 2, 1, 10, C), ("fp32", C + 4 * 77, 4, 1, 220, C), ("fp8", 3 * 65536 + 5, 1, 1, 10, 65536),
+         ("bf16", 70001, 2, 1, 10, 4442), ("fp16", 2 * C, 2, 0, 10, C), ("rand", C, 2, 1, 10, C)]
+
+
+@pytest.mark.parametrize("case", DELTA, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
+def test_delta_xor_fused_into_the_kernels(simt_lib, case):
+    """compress(data, delta=base) == oracle frame of data ^ base (reference XORs on the host first, zipnn.py:625-640);
+    decompress(frame, delta=base) == data.  Fused and generic kernels, host and device entry points, an unaligned base."""
+    from zipnn_amd import codec
+    kind, nb, P, rot, bm, chunk = case
+    a, b = _delta_pair(kind, nb, 31)
+    nb = len(a)
+    x = (np.frombuffer(a, dtype=np.uint8) ^ np.frombuffer(b, dtype=np.uint8)).tobytes()
+    want = O.compress_frame(HDR, x, P, rot, bm, chunk)
+    assert bytes(simt_lib.compress(HDR, a, P, rot, bm, chunk, 0.95, delta=b)) == want
+    if nb >= chunk and chunk % 16384 == 0:
+        assert "zn_k_encode_emit^delta" in simt_lib.last_kernels()
+    assert bytes(simt_lib.decompress(want[32:], P, rot, bm, chunk, nb, delta=b)) == a
+    assert "zn_k_decode_fused^delta" in simt_lib.last_kernels()
+    if chunk % 16384 == 0:
+        assert simt_lib.last_fused_chunks() == nb // chunk     # (a sparse delta: every plane is Huffman-coded)
+    # device entry points; the base at an odd address takes the generic kernels
+    ta = torch.frombuffer(bytearray(a), dtype=torch.uint8)
+    pad = torch.zeros(nb + 1, dtype=torch.uint8); pad[1:] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+    tb = pad[1:]
+    body = codec.compress_device(simt_lib, ta, P, rot, bm, chunk, 0.95, delta=tb)
+    assert body.numpy().tobytes() == want[32:]
+    assert "zn_k_encode_emit" not in simt_lib.last_kernels()
+    out = codec.decompress_device(simt_lib, body, P, rot, bm, chunk, nb, delta=tb)
+    assert out.numpy().tobytes() == a
+    assert simt_lib.last_fused_chunks() == 0
+    with pytest.raises(ValueError):
+        codec.compress_device(simt_lib, ta, P, rot, bm, chunk, 0.95, delta=tb[:-1])
+
+
+def test_delta_in_a_batch_is_per_tensor(simt_lib):
+    """A batch mixes tensors with and without a base (and plane counts): every frame equals its own oracle frame."""
+    from zipnn_amd import codec
+    specs = [("bf16", 2 * C, 2, 1, 10, C, True), ("bf16", C + 10, 2, 1, 10, C, False), ("fp32", C, 4, 1, 220, C, True),
+             ("fp8", 65536 * 2, 1, 1, 10, 65536, False), ("fp16", 1000, 2, 0, 10, C, True)]
+    items, wants, datas = [], [], []
+    for i, (kind, nb, P, rot, bm, chunk, has) in enumerate(specs):
+        a, b = _delta_pair(kind, nb, 40 + i)
+        x = (np.frombuffer(a, dtype=np.uint8) ^ np.frombuffer(b, dtype=np.uint8)).tobytes() if has else a
+        wants.append(O.compress_frame(HDR, x, P, rot, bm, chunk)[32:])
+        ta = torch.frombuffer(bytearray(a), dtype=torch.uint8)
+        tb = torch.frombuffer(bytearray(b), dtype=torch.uint8) if has else None
+        items.append((ta, P, rot, bm, chunk, 0.95, tb)); datas.append(a)
+    bodies = codec.compress_device_batch(simt_lib, items)
+    for b, w in zip(bodies, wants):
+        assert b.numpy().tobytes() == w
+    outs = codec.decompress_device_batch(simt_lib, [(b, P, rot, bm, chunk, len(a), tb)
+                                                    for b, (ta, P, rot, bm, chunk, thr, tb), a in zip(bodies, items, datas)])
+    for o, a in zip(outs, datas):
+        assert o.numpy().tobytes() == a

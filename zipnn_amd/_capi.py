@@ -30,14 +30,15 @@ class ZnBatchItem(ctypes.Structure):
     """struct zn_batch_item of include/zipnn_hip.h"""
     _fields_ = [("d_body", ctypes.c_void_p), ("body_len", ctypes.c_size_t), ("d_dst", ctypes.c_void_p),
                 ("orig_size", ctypes.c_size_t), ("num_buf", ctypes.c_int), ("bits_mode", ctypes.c_int),
-                ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t)]
+                ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t), ("d_delta", ctypes.c_void_p)]
 
 
 class ZnCBatchItem(ctypes.Structure):
     """struct zn_cbatch_item of include/zipnn_hip.h"""
     _fields_ = [("d_src", ctypes.c_void_p), ("n", ctypes.c_size_t), ("num_buf", ctypes.c_int), ("bits_mode", ctypes.c_int),
                 ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t), ("threshold", ctypes.c_float),
-                ("d_body", ctypes.c_void_p), ("body_cap", ctypes.c_size_t), ("body_len", ctypes.c_size_t)]
+                ("d_body", ctypes.c_void_p), ("body_cap", ctypes.c_size_t), ("body_len", ctypes.c_size_t),
+                ("d_delta", ctypes.c_void_p)]
 
 
 class ZnLib:
@@ -65,6 +66,14 @@ class ZnLib:
         L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
         L.zn_decompress_dev.restype = ci
         L.zn_decompress_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, vp, vp, ci]
+        L.zn_compress_delta.restype = ci
+        L.zn_compress_delta.argtypes = [vp, sz, vp, vp, sz, ci, ci, ci, sz, cf, ci, vp, sz, ctypes.POINTER(sz)]
+        L.zn_decompress_delta.restype = ci
+        L.zn_decompress_delta.argtypes = [vp, sz, vp, ci, ci, ci, sz, sz, ci, vp]
+        L.zn_compress_delta_dev.restype = ci
+        L.zn_compress_delta_dev.argtypes = [vp, vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
+        L.zn_decompress_delta_dev.restype = ci
+        L.zn_decompress_delta_dev.argtypes = [vp, sz, vp, ci, ci, ci, sz, sz, vp, vp, ci]
         L.zn_compress_batch_dev.restype = ci
         L.zn_compress_batch_dev.argtypes = [ctypes.POINTER(ZnCBatchItem), sz, vp]
         L.zn_decompress_batch_dev.restype = ci
@@ -73,7 +82,7 @@ class ZnLib:
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
         L.zn_last_tail_planes.restype = ctypes.c_longlong
         self._L = L
-        if L.zn_abi_version() != 1:
+        if L.zn_abi_version() != 2:
             raise ImportError(f"{path}: unexpected ABI version {L.zn_abi_version()}")
 
     # -- error mapping: the Python-visible exceptions of the reference ------------------
@@ -103,9 +112,10 @@ class ZnLib:
         return self._L.zn_last_kernels().decode()
 
     # -- host buffers --------------------------------------------------------------------
-    def compress(self, header, data, num_buf, bits_mode, bytes_mode, chunk, threshold, device=0):
+    def compress(self, header, data, num_buf, bits_mode, bytes_mode, chunk, threshold, device=0, delta=None):
         """header/data: bytes-like (not modified).  Returns the frame as a writable memoryview over an
-        uninitialised numpy buffer (a zero-filled 1 GiB bytearray alone costs 180 ms)."""
+        uninitialised numpy buffer (a zero-filled 1 GiB bytearray alone costs 180 ms).  delta: bytes-like of
+        the same length — the frame then holds data ^ delta (XOR fused into the device kernels)."""
         hv = memoryview(header).cast("B")
         dv = memoryview(data).cast("B")
         n = dv.nbytes
@@ -114,50 +124,63 @@ class ZnLib:
         out_len = ctypes.c_size_t(0)
         hb = (ctypes.c_char * max(hv.nbytes, 1)).from_buffer_copy(hv.tobytes() or b"\0")
         src = _as_c_buffer(dv)
-        rc = self._L.zn_compress(ctypes.addressof(hb), hv.nbytes, src.addr, n, num_buf, bits_mode, bytes_mode, chunk,
-                                 threshold, device, out.ctypes.data, cap, ctypes.byref(out_len))
+        dl = _as_c_buffer(memoryview(delta).cast("B")) if delta is not None else None
+        if dl is not None and memoryview(delta).nbytes != n:
+            raise ValueError("delta buffer and data differ in length")
+        rc = self._L.zn_compress_delta(ctypes.addressof(hb), hv.nbytes, src.addr, dl.addr if dl else None, n, num_buf, bits_mode,
+                                       bytes_mode, chunk, threshold, device, out.ctypes.data, cap, ctypes.byref(out_len))
         self._check(rc)
         return memoryview(out)[:out_len.value]
 
-    def decompress(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, device=0):
-        """body: bytes-like after the header.  Returns orig_size bytes as a writable memoryview (numpy-backed)."""
+    def decompress(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, device=0, delta=None):
+        """body: bytes-like after the header.  Returns orig_size bytes as a writable memoryview (numpy-backed).
+        delta: bytes-like of orig_size bytes XORed into the output on the device."""
         bv = memoryview(body).cast("B")
         out = np.empty(max(orig_size, 1), dtype=np.uint8)
         src = _as_c_buffer(bv)
-        rc = self._L.zn_decompress(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, device,
-                                   out.ctypes.data)
+        dl = _as_c_buffer(memoryview(delta).cast("B")) if delta is not None else None
+        if dl is not None and memoryview(delta).nbytes != orig_size:
+            raise ValueError("delta buffer and original size differ")
+        rc = self._L.zn_decompress_delta(src.addr, bv.nbytes, dl.addr if dl else None, num_buf, bits_mode, bytes_mode, chunk,
+                                         orig_size, device, out.ctypes.data)
         self._check(rc)
         return memoryview(out)[:orig_size]
 
     # -- device pointers (ints), used by zipnn_amd.codec with torch tensors -----------------
-    def compress_dev(self, src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap, stream=0):
+    def compress_dev(self, src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap, stream=0,
+                     delta_ptr=None):
         out_len = ctypes.c_size_t(0)
-        rc = self._L.zn_compress_dev(src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap,
-                                     ctypes.byref(out_len), stream)
+        rc = self._L.zn_compress_delta_dev(src_ptr, delta_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr,
+                                           body_cap, ctypes.byref(out_len), stream)
         self._check(rc)
         return out_len.value
 
     def decompress_dev(self, body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr, stream=0,
-                       check=True):
-        rc = self._L.zn_decompress_dev(body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr,
-                                       stream, 1 if check else 0)
+                       check=True, delta_ptr=None):
+        rc = self._L.zn_decompress_delta_dev(body_ptr, body_len, delta_ptr, num_buf, bits_mode, bytes_mode, chunk, orig_size,
+                                             dst_ptr, stream, 1 if check else 0)
         self._check(rc)
 
     def compress_batch_dev(self, items, stream=0):
-        """items: iterable of (src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap) -> list of body lengths."""
+        """items: iterable of (src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap[, delta_ptr])
+        -> list of body lengths."""
         items = list(items)
         arr = (ZnCBatchItem * max(len(items), 1))()
-        for i, (sp, n, nb, bi, by, ch, th, bp, cap) in enumerate(items):
+        for i, it in enumerate(items):
+            sp, n, nb, bi, by, ch, th, bp, cap = it[:9]
+            arr[i].d_delta = it[9] if len(it) > 9 else None
             arr[i].d_src = sp; arr[i].n = n; arr[i].num_buf = nb; arr[i].bits_mode = bi; arr[i].bytes_mode = by
             arr[i].chunk = ch; arr[i].threshold = th; arr[i].d_body = bp; arr[i].body_cap = cap
         self._check(self._L.zn_compress_batch_dev(arr, len(items), stream))
         return [int(arr[i].body_len) for i in range(len(items))]
 
     def decompress_batch_dev(self, items, stream=0, check=True):
-        """items: iterable of (body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr)."""
+        """items: iterable of (body_ptr, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dst_ptr[, delta_ptr])."""
         items = list(items)
         arr = (ZnBatchItem * max(len(items), 1))()
-        for i, (bp, bl, nb, bi, by, ch, n, dp) in enumerate(items):
+        for i, it in enumerate(items):
+            bp, bl, nb, bi, by, ch, n, dp = it[:8]
+            arr[i].d_delta = it[8] if len(it) > 8 else None
             arr[i].d_body = bp; arr[i].body_len = bl; arr[i].d_dst = dp; arr[i].orig_size = n
             arr[i].num_buf = nb; arr[i].bits_mode = bi; arr[i].bytes_mode = by; arr[i].chunk = ch
         self._check(self._L.zn_decompress_batch_dev(arr, len(items), stream, 1 if check else 0))

@@ -23,15 +23,28 @@ def _stream_handle(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
 
-def compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold):
+def _delta_ptr(delta, like):
+    """delta base: None, or a uint8 tensor of the same length on the same device (contiguous)."""
+    if delta is None:
+        return None, None
+    delta = delta.contiguous()
+    if delta.dtype != torch.uint8 or delta.numel() != like.numel() or delta.device != like.device:
+        raise ValueError("delta base must be a uint8 tensor of the same length on the same device")
+    return delta, (delta.data_ptr() if delta.numel() else None)
+
+
+def compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold, delta=None):
     """flat: uint8 tensor in HBM -> uint8 tensor (same device) holding the frame BODY
-    (types ‖ cumSizes ‖ payload).  One 8-byte read-back for the length."""
+    (types ‖ cumSizes ‖ payload).  One 8-byte read-back for the length.
+    delta: optional uint8 tensor of the same length — the body then encodes flat ^ delta, the XOR being fused
+    into the kernels that read the tensor (the reference's delta step, zipnn/zipnn.py:625-640)."""
     n = flat.numel()
+    delta, dptr = _delta_ptr(delta, flat)
     cap = lib.compress_bound(n, num_buf, chunk, 0)
     body = torch.empty(max(cap, 16), dtype=torch.uint8, device=flat.device)
     with torch.cuda.device(flat.device) if flat.is_cuda else _nullctx():
         used = lib.compress_dev(flat.data_ptr() if n else 0, n, num_buf, bits_mode, bytes_mode, chunk, threshold,
-                                body.data_ptr(), body.numel(), _stream_handle(flat))
+                                body.data_ptr(), body.numel(), _stream_handle(flat), delta_ptr=dptr)
     return body[:used]
 
 
@@ -46,17 +59,19 @@ def compress_device_to_frame(lib, header, flat, num_buf, bits_mode, bytes_mode, 
     return frame
 
 
-def decompress_device(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, out=None, check=True):
+def decompress_device(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, out=None, check=True, delta=None):
     """body: uint8 tensor in HBM (frame minus header) -> uint8 tensor of orig_size bytes on
-    the same device."""
+    the same device.  delta: optional uint8 tensor of orig_size bytes XORed into the output inside the
+    kernels that write it (reference zipnn/zipnn.py:983-1004)."""
     if out is None:
         out = torch.empty(orig_size, dtype=torch.uint8, device=body.device)
     if orig_size == 0:
         return out
     body = body.contiguous()
+    delta, dptr = _delta_ptr(delta, out)
     with torch.cuda.device(body.device) if body.is_cuda else _nullctx():
         lib.decompress_dev(body.data_ptr(), body.numel(), num_buf, bits_mode, bytes_mode, chunk, orig_size,
-                           out.data_ptr(), _stream_handle(body), check)
+                           out.data_ptr(), _stream_handle(body), check, delta_ptr=dptr)
     return out
 
 
@@ -70,11 +85,17 @@ class _nullctx:
 
 def decompress_device_batch(lib, items, check=True, into=None):
     """Many tensors, one set of kernel launches (zn_decompress_batch_dev): small tensors fill the device together.
-    items: iterable of (body, num_buf, bits_mode, bytes_mode, chunk, orig_size) with `body` a uint8 tensor on
-    the device (frame minus header).  Returns the list of decoded uint8 tensors (same device)."""
-    items = [(b.contiguous(), nb, bi, by, ch, n) for (b, nb, bi, by, ch, n) in items]
+    items: iterable of (body, num_buf, bits_mode, bytes_mode, chunk, orig_size[, delta]) with `body` a uint8 tensor on
+    the device (frame minus header) and `delta` an optional uint8 base of orig_size bytes.  Returns the list of
+    decoded uint8 tensors (same device)."""
+    items = list(items)
+    deltas = [(it[6].contiguous() if len(it) > 6 and it[6] is not None else None) for it in items]
+    items = [(it[0].contiguous(),) + tuple(it[1:6]) for it in items]
     if not items:
         return []
+    for d, it in zip(deltas, items):
+        if d is not None and (d.dtype != torch.uint8 or d.numel() != it[5] or d.device != it[0].device):
+            raise ValueError("delta base must be a uint8 tensor of orig_size bytes on the same device")
     dev = items[0][0].device
     if into is not None:                       # one preallocated buffer: tensor i lands at the running offset
         assert into.numel() >= sum(n for (_, _, _, _, _, n) in items)
@@ -85,18 +106,24 @@ def decompress_device_batch(lib, items, check=True, into=None):
     else:
         outs = [torch.empty(n, dtype=torch.uint8, device=dev) for (_, _, _, _, _, n) in items]
     with torch.cuda.device(dev) if dev.type == "cuda" else _nullctx():
-        lib.decompress_batch_dev(((b.data_ptr(), b.numel(), nb, bi, by, ch, n, o.data_ptr() if n else 0)
-                                  for (b, nb, bi, by, ch, n), o in zip(items, outs)), _stream_handle(items[0][0]), check)
+        lib.decompress_batch_dev(((b.data_ptr(), b.numel(), nb, bi, by, ch, n, o.data_ptr() if n else 0,
+                                   d.data_ptr() if (d is not None and n) else None)
+                                  for (b, nb, bi, by, ch, n), o, d in zip(items, outs, deltas)), _stream_handle(items[0][0]), check)
     return outs
 
 
 def compress_device_batch(lib, items):
     """Many tensors, one launch per stage (zn_compress_batch_dev), one read-back of all lengths.
-    items: iterable of (flat_uint8_device_tensor, num_buf, bits_mode, bytes_mode, chunk, threshold).
+    items: iterable of (flat_uint8_device_tensor, num_buf, bits_mode, bytes_mode, chunk, threshold[, delta]).
     Returns the list of body tensors (uint8, same device; slices of one arena)."""
-    items = [(f.contiguous(), nb, bi, by, ch, th) for (f, nb, bi, by, ch, th) in items]
+    items = list(items)
+    deltas = [(it[6].contiguous() if len(it) > 6 and it[6] is not None else None) for it in items]
+    items = [(it[0].contiguous(),) + tuple(it[1:6]) for it in items]
     if not items:
         return []
+    for d, it in zip(deltas, items):
+        if d is not None and (d.dtype != torch.uint8 or d.numel() != it[0].numel() or d.device != it[0].device):
+            raise ValueError("delta base must be a uint8 tensor of the same length on the same device")
     dev = items[0][0].device
     caps = [max(lib.compress_bound(f.numel(), nb, ch, 0), 16) for (f, nb, _, _, ch, _) in items]
     offs, o = [], 0
@@ -105,6 +132,7 @@ def compress_device_batch(lib, items):
     arena = torch.empty(max(o, 16), dtype=torch.uint8, device=dev)
     base = arena.data_ptr()
     with torch.cuda.device(dev) if dev.type == "cuda" else _nullctx():
-        lens = lib.compress_batch_dev(((f.data_ptr() if f.numel() else 0, f.numel(), nb, bi, by, ch, th, base + b0, c)
-                                       for (f, nb, bi, by, ch, th), c, b0 in zip(items, caps, offs)), _stream_handle(arena))
+        lens = lib.compress_batch_dev(((f.data_ptr() if f.numel() else 0, f.numel(), nb, bi, by, ch, th, base + b0, c,
+                                        d.data_ptr() if (d is not None and f.numel()) else None)
+                                       for (f, nb, bi, by, ch, th), c, b0, d in zip(items, caps, offs, deltas)), _stream_handle(arena))
     return [arena[b0:b0 + n] for b0, n in zip(offs, lens)]

@@ -29,15 +29,16 @@ thread_local std::string t_kernels;
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
   size_t last_tails = 0;         // tail planes of the last decompress call (for zn_last_tail_planes)
-  void* buf[11] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  void* buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched call (capacity in ZnSeg units)
   uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;   // pinned: body lengths of a batched compress
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
 };
-enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_COUNT };
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
+static_assert(WS_COUNT == 12, "Workspace::buf size");
 
 std::mutex g_mu;
 Workspace g_ws[64];
@@ -87,7 +88,7 @@ void zn_note_kernel(const char* name) { if (!t_kernels.empty()) t_kernels += ";"
 
 extern "C" {
 
-int zn_abi_version(void) { return 1; }
+int zn_abi_version(void) { return 2; }
 
 const char* zn_strerror(int s) {
   switch (s) {
@@ -126,7 +127,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   std::vector<size_t> owner[3];                  // item index of each segment
   uint64_t pc_all = 0, slot_all = 0; size_t slot = 0;
   uint64_t chunks_of[3] = {0, 0, 0}, jobs_of[3] = {0, 0, 0}, tails_of[3] = {0, 0, 0}, ptails_of[3] = {0, 0, 0}, scan_of[3] = {0, 0, 0};
-  bool any_fused = false;
+  bool any_fused = false; bool delta_of[3] = {false, false, false};
   for (size_t i = 0; i < count; i++) {
     zn_cbatch_item& it = items[i];
     ZnESeg sg; memset(&sg, 0, sizeof(sg));
@@ -138,9 +139,11 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
     const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
     const uint64_t PK = (uint64_t)sg.g.P * sg.g.K;
     sg.src = (const uint8_t*)it.d_src; sg.body = (uint8_t*)it.d_body; sg.threshold = it.threshold;
+    sg.xr = it.n ? (const uint8_t*)it.d_delta : nullptr;
+    if (sg.xr) delta_of[q] = true;
     // full chunks go through the fused encoder, the partial tail (or everything, for geometries the fused
     // kernels do not take) through the generic one
-    sg.nfull = zn_encode_fused_ok(sg.g, it.d_src) ? (uint64_t)(it.n / it.chunk) : 0;
+    sg.nfull = zn_encode_fused_ok(sg.g, it.d_src, sg.xr) ? (uint64_t)(it.n / it.chunk) : 0;
     any_fused = any_fused || sg.nfull;
     const uint64_t KL = sg.g.K - sg.nfull;
     sg.pc0 = pc_all; sg.slot0 = slot_all; sg.total_idx = i;
@@ -208,13 +211,13 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
       const uint32_t nseg = (uint32_t)segs[q].size();
       const ZnESeg& one = segs[q][0];
       if (stage == 0) {
-        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], stream);
+        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream);
         zn_launch_encode_generic_stats(P, one, d_segs, nseg, (uint32_t)tails_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES],
                                        (uint8_t*)w.buf[WS_ENC], slot, d_csize, d_type, stream);
       } else if (stage == 1) {
         zn_launch_scan_sizes(one, d_segs, nseg, (uint32_t)scan_of[q], d_csize, d_type, d_offs, d_totals, stream);
       } else {
-        zn_launch_encode_fused_emit(P, one, d_segs, nseg, (uint32_t)chunks_of[q], d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, stream);
+        zn_launch_encode_fused_emit(P, one, d_segs, nseg, (uint32_t)chunks_of[q], d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, delta_of[q], stream);
         zn_launch_encode_generic_gather(one, d_segs, nseg, (uint32_t)ptails_of[q], (const uint8_t*)w.buf[WS_PLANES], (const uint8_t*)w.buf[WS_ENC],
                                         slot, d_csize, d_type, d_offs, stream);
       }
@@ -231,16 +234,21 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   return ZN_OK;
 }
 
-int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                    float threshold, void* d_body, size_t body_cap, size_t* body_len, void* stream_) {
+int zn_compress_delta_dev(const void* d_src, const void* d_delta, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                          float threshold, void* d_body, size_t body_cap, size_t* body_len, void* stream_) {
   if (!body_len) return ZN_E_ARG;
-  zn_cbatch_item it;
+  zn_cbatch_item it; it.d_delta = d_delta;
   it.d_src = d_src; it.n = n; it.num_buf = num_buf; it.bits_mode = bits_mode; it.bytes_mode = bytes_mode; it.chunk = chunk;
   it.threshold = threshold; it.d_body = d_body; it.body_cap = body_cap; it.body_len = 0;
   int rc;
   try { rc = compress_items(&it, 1, (hipStream_t)stream_); } catch (...) { return ZN_E_ALLOC; }
   *body_len = it.body_len;
   return rc;
+}
+
+int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                    float threshold, void* d_body, size_t body_cap, size_t* body_len, void* stream_) {
+  return zn_compress_delta_dev(d_src, nullptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, body_cap, body_len, stream_);
 }
 
 int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream_) {
@@ -253,6 +261,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if (count && !items) return ZN_E_ARG;
   std::vector<ZnSeg> segs[3];                    // by plane count: 1, 2, 4
   uint64_t pk_of[3] = {0, 0, 0}, k_of[3] = {0, 0, 0}; uint64_t wg_of[3] = {0, 0, 0}, tail_of[3] = {0, 0, 0};
+  bool delta_of[3] = {false, false, false};
   uint64_t total_chunks = 0;
   for (size_t i = 0; i < count; i++) total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk);
   const uint32_t ncg = zn_decode_fused_group(total_chunks);
@@ -266,6 +275,8 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (!it.d_body || !it.d_dst) return ZN_E_ARG;
     const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
     sg.body = (const uint8_t*)it.d_body; sg.body_len = it.body_len; sg.dst = (uint8_t*)it.d_dst;
+    sg.xr = (const uint8_t*)it.d_delta;
+    if (sg.xr) delta_of[q] = true;
     sg.chunk0 = k_of[q]; sg.desc0 = pk_of[q]; sg.wg0 = (uint32_t)wg_of[q]; sg.ncg = ncg;
     sg.tail0 = (uint32_t)tail_of[q]; sg.has_tail = (it.orig_size % it.chunk) != 0 ? 1u : 0u;   // partial last chunk
     if (sg.has_tail) tail_of[q] += sg.g.P;
@@ -324,7 +335,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
-                           d_tail_done, stream);
+                           d_tail_done, delta_of[q], stream);
     zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
   }
@@ -340,14 +351,19 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   return ZN_OK;
 }
 
-int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                      size_t orig_size, void* d_dst, void* stream_, int check) {
-  zn_batch_item it;
+int zn_decompress_delta_dev(const void* d_body, size_t body_len, const void* d_delta, int num_buf, int bits_mode, int bytes_mode,
+                            size_t chunk, size_t orig_size, void* d_dst, void* stream_, int check) {
+  zn_batch_item it; it.d_delta = d_delta;
   it.d_body = d_body; it.body_len = body_len; it.d_dst = d_dst; it.orig_size = orig_size;
   it.num_buf = num_buf; it.bits_mode = bits_mode; it.bytes_mode = bytes_mode; it.chunk = chunk;
   try {
     return decompress_items(&it, 1, (hipStream_t)stream_, check);
   } catch (...) { return ZN_E_ALLOC; }
+}
+
+int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                      size_t orig_size, void* d_dst, void* stream_, int check) {
+  return zn_decompress_delta_dev(d_body, body_len, nullptr, num_buf, bits_mode, bytes_mode, chunk, orig_size, d_dst, stream_, check);
 }
 
 int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stream_, int check) {
@@ -356,8 +372,8 @@ int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stre
   } catch (...) { return ZN_E_ALLOC; }
 }
 
-int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
-                size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
+int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const void* delta, size_t n, int num_buf, int bits_mode,
+                      int bytes_mode, size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
   if (!dst_len || (hdr_len && !hdr) || (n && !src) || !dst) return ZN_E_ARG;
   if (zn_device_count() <= 0) return ZN_E_NODEV;
   ZN_HIP(hipSetDevice(device));
@@ -367,11 +383,12 @@ int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int 
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   std::lock_guard<std::mutex> hk(g_host_mu[dev]);
-  void* d_src = nullptr; void* d_body = nullptr;
+  void* d_src = nullptr; void* d_body = nullptr; void* d_delta = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     Workspace& w = g_ws[dev];
     int rc0;
+    if (delta && n) { if ((rc0 = ws_reserve(w, WS_HOST_DELTA, n))) return rc0; d_delta = w.buf[WS_HOST_DELTA]; }
     if ((rc0 = ws_reserve(w, WS_HOST_IN, n ? n : 16))) return rc0;
     if ((rc0 = ws_reserve(w, WS_HOST_OUT, bound ? bound : 16))) return rc0;
     d_src = w.buf[WS_HOST_IN]; d_body = w.buf[WS_HOST_OUT];
@@ -379,7 +396,8 @@ int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int 
   int rc = ZN_OK; size_t body_len = 0;
   do {
     if (n && hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
-    rc = zn_compress_dev(d_src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, bound ? bound : 16, &body_len, nullptr);
+    if (d_delta && hipMemcpy(d_delta, delta, n, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
+    rc = zn_compress_delta_dev(d_src, d_delta, n, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, bound ? bound : 16, &body_len, nullptr);
     if (rc) break;
     if (hdr_len + body_len > dst_cap) { rc = ZN_E_CAP; break; }
     if (hdr_len) memcpy(dst, hdr, hdr_len);
@@ -390,8 +408,13 @@ int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int 
   return rc;
 }
 
-int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                  size_t orig_size, int device, void* dst) {
+int zn_compress(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
+  return zn_compress_delta(hdr, hdr_len, src, nullptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, device, dst, dst_cap, dst_len);
+}
+
+int zn_decompress_delta(const void* body, size_t body_len, const void* delta, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                        size_t orig_size, int device, void* dst) {
   if ((body_len && !body) || (orig_size && !dst)) return ZN_E_ARG;
   if (zn_device_count() <= 0) return ZN_E_NODEV;
   ZN_HIP(hipSetDevice(device));
@@ -399,11 +422,12 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   std::lock_guard<std::mutex> hk(g_host_mu[dev]);
-  void* d_body = nullptr; void* d_dst = nullptr;
+  void* d_body = nullptr; void* d_dst = nullptr; void* d_delta = nullptr;
   {
     std::lock_guard<std::mutex> lk(g_mu);
     Workspace& w = g_ws[dev];
     int rc0;
+    if (delta && orig_size) { if ((rc0 = ws_reserve(w, WS_HOST_DELTA, orig_size))) return rc0; d_delta = w.buf[WS_HOST_DELTA]; }
     if ((rc0 = ws_reserve(w, WS_HOST_IN, body_len ? body_len : 16))) return rc0;
     if ((rc0 = ws_reserve(w, WS_HOST_OUT, orig_size ? orig_size : 16))) return rc0;
     d_body = w.buf[WS_HOST_IN]; d_dst = w.buf[WS_HOST_OUT];
@@ -411,11 +435,17 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
   int rc = ZN_OK;
   do {
     if (body_len && hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
-    rc = zn_decompress_dev(d_body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, d_dst, nullptr, 1);
+    if (d_delta && hipMemcpy(d_delta, delta, orig_size, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
+    rc = zn_decompress_delta_dev(d_body, body_len, d_delta, num_buf, bits_mode, bytes_mode, chunk, orig_size, d_dst, nullptr, 1);
     if (rc) break;
     if (orig_size && hipMemcpy(dst, d_dst, orig_size, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy D2H"; break; }
   } while (0);
   return rc;
+}
+
+int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                  size_t orig_size, int device, void* dst) {
+  return zn_decompress_delta(body, body_len, nullptr, num_buf, bits_mode, bytes_mode, chunk, orig_size, device, dst);
 }
 
 long long zn_last_fused_chunks(void) {

@@ -65,9 +65,16 @@ __device__ __forceinline__ uint32_t zn_rot_inv32(uint32_t u) {
 // A pointer that comes out of a struct / table is "generic" to the compiler: its loads and stores become FLAT
 // operations, which also count on the LDS counter (every LDS wait would then wait for HBM).  These pointers
 // are global memory: say so.
+// (ZN_LDS_PTR: the same for a pointer into LDS that crossed a real function call.)
 #if defined(ZN_SIMT_EMULATOR)
 #define ZN_GLOBAL_PTR(T, p) ((T*)(p))
+#define ZN_LDS_PTR(T, p) ((T*)(p))
 #else
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZN_LDS_PTR(T, p) ((T*)(__attribute__((address_space(3))) T*)(unsigned int)(unsigned long long)(p))
+#else
+#define ZN_LDS_PTR(T, p) ((T*)(p))       /* (host pass of the same source: never executed) */
+#endif
 #define ZN_GLOBAL_PTR(T, p) ((T*)(__attribute__((address_space(1))) T*)(unsigned long long)(p))   // (via an integer: a plain round trip is folded away)
 #endif
 

@@ -229,9 +229,11 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
 // compile time (H = -1: no Huffman plane) so that register arrays are statically indexed.
 // DC: the sub-block size when it is known at compile time (the common value gets its own instance,
 // which lets the tile loads / staging loops unroll exactly), 0 = run-time Du.
-template <int P, int H, int DC>
+// X: the output is XORed with the delta base `xq` (same offsets as outq; may still be null for a tensor without one).
+// xq == outq accumulates into rows already written (every row is loaded before it is stored, once).
+template <int P, int H, int DC, bool X = false>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
-                                              uint8_t* __restrict__ outq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
+                                              uint8_t* outq, const uint8_t* xq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
                                               const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
                                               uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen, bool ragged ZN_PT_PARAM) {
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
@@ -260,6 +262,21 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0) {
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
     ZN_PT(10);  // wait for the fetched rows
+    // delta base of these rows, two rows at a time, double-buffered: the next pair is requested before the current
+    // pair is stored (more rows in flight would spill: the fetched raw rows are live here too)
+    constexpr int XW = X ? (P == 4 ? 8 : 4) : 1, XG = 2;
+    uint32_t xd[2][XG][XW];
+    auto load_delta = [&](int grp) {
+      for (int i = 0; i < XG; i++) {
+        const int r = grp * XG + i;
+        for (int k = 0; k < XW; k++) xd[grp & 1][i][k] = 0;
+        if (xq && r < RB && r < nrows) {
+          const uint8_t* a = xq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane) * P;
+          for (int k = 0; k < XW / 4; k++) { const uint4 t = *(const uint4*)(a + 16 * k); xd[grp & 1][i][4 * k] = t.x; xd[grp & 1][i][4 * k + 1] = t.y; xd[grp & 1][i][4 * k + 2] = t.z; xd[grp & 1][i][4 * k + 3] = t.w; }
+        }
+      }
+    };
+    if (X) load_delta(0);
     for (int r = 0; r < RB; r++) if (r < nrows) {
       for (int p = 0; p < P; p++) {
         if (p == H) { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
@@ -277,14 +294,18 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         }
     }
     for (int r = 0; r < RB; r++) if (r < nrows) {
+      if (X && r % XG == 0 && r + XG < RB) load_delta(r / XG + 1);
+      const uint32_t* xr_ = xd[(r / XG) & 1][r % XG];
       const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
       uint8_t* o = outq + (uint64_t)si * P;
       if (P == 1) {
-        ZN_ST128(o, pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
+        if (X) ZN_ST128(o, pre[r][0][0] ^ xr_[0], pre[r][0][1 % EW] ^ xr_[1 % XW], pre[r][0][2 % EW] ^ xr_[2 % XW], pre[r][0][3 % EW] ^ xr_[3 % XW]);
+        else ZN_ST128(o, pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
       } else if (P == 2) {
         uint32_t x[4];
         x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
         x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
+        if (X) for (int k = 0; k < 4; k++) x[k] ^= xr_[k % XW];
         ZN_ST128(o, x[0], x[1], x[2], x[3]);
       } else {
         for (int half = 0; half < 2; half++) {
@@ -294,6 +315,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           uint32_t x[4];
           x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
           x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+          if (X) for (int k = 0; k < 4; k++) x[k] ^= xr_[(4 * half + k) % XW];
           *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);   // (two half-line stores per lane: NOT non-temporal, the L2 merges them — nt cost 40 % here)
         }
       }
@@ -462,8 +484,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
 // (b = index of the tail workgroup inside the launch; runs as the FIRST workgroups of zn_k_decode_fused, so that
 // the one-workgroup job overlaps the decode of the full chunks instead of following it)
-__device__ void zn_decode_tail_wg(ZnFusedLds& L, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t b,
+__device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t b,
                                   uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status) {
+  ZnFusedLds& L = *ZN_LDS_PTR(ZnFusedLds, &L_);     // (this is a real call: keep the LDS accesses DS operations)
   const ZnSeg S = zn_find_seg<3>(one, segs, nseg, b);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
@@ -506,8 +529,8 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L, const ZnSeg& one, const ZnSeg* 
   Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
   Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
   const bool ok = (Du == ZN_F_DCONST)
-    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
-    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
+    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
+    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
   if (lane == 0) L.what[wave] = ok ? 1u : 0u;
   __syncthreads();
   if (tid == 0) {
@@ -518,13 +541,72 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L, const ZnSeg& one, const ZnSeg* 
 }
 
 
+// Further Huffman planes of a chunk whose first one zn_k_decode_fused has just decoded: one more pass per plane.
+// The rows are already in the output with zero bytes in that plane; the pass XORs its bytes in (the un-rotate is a
+// bit permutation, so it distributes over the XOR) — the delta instance of the wave function with the output itself
+// as the base.  The tree description is parsed by wave 0 between the passes.  Returns 1 = ok, 0 = a stream did not
+// decode cleanly, -1 = a plane this kernel does not take (the generic path redoes the chunk).
+// (Inlined: as a real call it halved the speed of the common one-plane case — measured, profiles/README.md.)
+template <int P>
+__device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
+                                                    uint8_t* outq, uint32_t j, uint32_t more, uint32_t seg ZN_PT_PARAM) {
+  constexpr int EPL = (P == 1) ? 16 : 8;
+  constexpr uint32_t UNIT = 64u * EPL;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
+  bool ok = true;
+  for (int p2 = 1; p2 < P; p2++) {
+    if (!((more >> p2) & 1u)) continue;
+    __syncthreads();                         // every wave is done with the tables and rings of the previous pass
+    const uint64_t off2 = L.plane[j][p2].off; const uint32_t cs2 = L.plane[j][p2].csize;
+    if (wave == 0) {
+      uint8_t* scratch = (uint8_t*)&L.ring[0][0];
+      ZnWaveStats st2 = zn_wave_read_stats(body + off2, cs2, body_end, lane, scratch, L.symlist[j], L.rank_start[j], L.sym_start[j], scratch + 512);
+      if (st2.hs < 0 || st2.tl > ZN_F_TLMAX || (uint32_t)st2.hs >= cs2 || cs2 - (uint32_t)st2.hs < 10u) st2.hs = -1;
+      if (lane == 0) L.st[j] = st2;
+    }
+    __syncthreads();
+    const ZnWaveStats st2 = L.st[j];
+    if (st2.hs < 0) return -1;
+    const uint32_t TL2 = st2.tl;
+    zn_fused_fill_luts(L, tid, TL2, j);
+    const uint8_t* js = body + off2 + st2.hs; const uint32_t rem = cs2 - (uint32_t)st2.hs;
+    const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+    uint32_t l4 = 0; bool bad = false;
+    if (l1 + l2 + l3 + 6u > rem) bad = true; else l4 = rem - 6u - l1 - l2 - l3;
+    if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) bad = true;
+    __syncthreads();                         // lut16 (aliasing ring[0]) is dead from here on
+    if (bad) return -1;
+    const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
+    const uint8_t* stream2 = js + so; const uint32_t slen2 = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
+    ZnFusedPlane pl2[P]; const uint8_t* rawq[P];
+    for (int p = 0; p < P; p++) { pl2[p] = L.plane[j][p]; rawq[p] = body; if (p != p2) { pl2[p].kind = ZN_KIND_RLE; pl2[p].off = 0; } }
+    uint32_t Du2 = ((ZN_F_RING_BYTES - UNIT - 128u) * slen2) / (256u * seg);
+    Du2 = Du2 > ZN_F_DMAX ? ZN_F_DMAX : (Du2 < 1u ? 1u : Du2);
+    Du2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du2);
+#define ZN_ACC_ARGS g, body, body_end, outq, outq, pl2, rawq, L.lut, ring, in, lane, seg, TL2, Du2, stream2, slen2, false ZN_PT_PASS
+    bool ok2;
+    if (p2 == 1) ok2 = zn_fused_wave<P, (P >= 2 ? 1 : 0), 0, true>(ZN_ACC_ARGS);
+    else if (p2 == 2) ok2 = zn_fused_wave<P, (P >= 4 ? 2 : 0), 0, true>(ZN_ACC_ARGS);
+    else ok2 = zn_fused_wave<P, (P >= 4 ? 3 : 0), 0, true>(ZN_ACC_ARGS);
+#undef ZN_ACC_ARGS
+    ok = ok && ok2;
+  }
+  return ok ? 1 : 0;
+}
+
 // One workgroup decodes a GROUP of up to 4 consecutive chunks.  The tree description of a huff0 block is
 // a serial job for one wave (zn_huf_wave.hpp), so the four waves first parse the descriptions of the
 // group's four chunks side by side; after that the whole workgroup decodes the chunks one after the other
 // (LUT fill by 256 threads, then wave w = stream w).  ncg = chunks per group (1..4, chosen by the host so
 // that small inputs still spread over every CU).
-template <int P>
-__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+// (the delta instance at 3 waves per SIMD — 168 VGPRs, fewer spills — was 50 % slower than at 4: occupancy matters
+// more than the spills, measured in profiles/r01z_delta_path.txt; ZN_F_XWAVES is that knob)
+#ifndef ZN_F_XWAVES
+#define ZN_F_XWAVES ZN_F_WAVES_PER_SIMD
+#endif
+template <int P, bool X>
+__global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                   uint32_t* __restrict__ status, uint32_t ntail,
                                                                   uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done) {
@@ -570,12 +652,13 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   if (wave < nc) {
     int h = -1; uint32_t nhuf = 0;
     bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
+    if (X) elig = elig && ((((uint64_t)S.xr) & 15u) == 0);   // (the host picks the X instance whenever a tensor has a base)
     for (int p = 0; p < P; p++) {
       const uint32_t kind = L.plane[wave][p].kind;
       if (kind == 99u) elig = false;
-      if (kind == ZN_KIND_HUF) { h = p; nhuf++; }
+      if (kind == ZN_KIND_HUF) { if (h < 0) h = p; nhuf++; }     // h: the FIRST Huffman plane (further ones: extra passes below)
     }
-    if (nhuf > 1u) elig = false;
+    (void)nhuf;
     ZnWaveStats st; st.hs = 0; st.nsym = 0; st.tl = 0; st.lmin = 1;
     if (elig && h >= 0) {
       const uint32_t csize = L.plane[wave][h].csize;
@@ -597,7 +680,11 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     if (what == 0u) { ZN_SET_DONE(c, 0); continue; }
     const int h = (int)what - 2;
     ZnFusedPlane pl[P];
-    for (int p = 0; p < P; p++) pl[p] = L.plane[j][p];
+    uint32_t more = 0;                          // further Huffman planes (bit p): decoded by extra passes, zero bytes in this one
+    for (int p = 0; p < P; p++) {
+      pl[p] = L.plane[j][p];
+      if (p > h && h >= 0 && pl[p].kind == ZN_KIND_HUF) { more |= 1u << p; pl[p].kind = ZN_KIND_RLE; pl[p].off = 0; }
+    }
 
     uint32_t TL = 0;
     const uint8_t* stream = nullptr; uint32_t slen = 0;
@@ -627,6 +714,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     const uint8_t* rawq[P];
     for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
     uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
+    const uint8_t* xq = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk + (uint64_t)wave * (g.chunk / 4u) : nullptr;
     uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
     // sub-block size (dwords): a tile of 64 sub-blocks should decode to about one staging buffer minus the
     // carried remainder, at this stream's average code length (8 slen / seg bits per symbol)
@@ -634,15 +722,21 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
-#define ZN_WAVE_ARGS g, body, body_end, outq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
-#define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0>(ZN_WAVE_ARGS)
-    if (h < 0) ok = zn_fused_wave<P, -1, 0>(ZN_WAVE_ARGS);
+#define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
+#define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
+    if (h < 0) ok = zn_fused_wave<P, -1, 0, X>(ZN_WAVE_ARGS);
     else if (h == 0) ZN_WAVE_CASE(0);
     else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
     else if (P >= 4 && h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
     else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
 #undef ZN_WAVE_CASE
 #undef ZN_WAVE_ARGS
+    // ---- further Huffman planes (deltas, sparse tensors: every plane compresses): one more pass per plane
+    if (P >= 2 && __builtin_expect(more != 0u, 0)) {
+      const int r2 = zn_fused_more_passes<P>(L, g, body, body_end, outq, j, more, seg ZN_PT_PASS);
+      if (r2 < 0) { ZN_SET_DONE(c, 0); continue; }   // a later plane this kernel does not take: the generic path redoes the chunk
+      ok = ok && r2 > 0;
+    }
     if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
     ZN_SET_DONE(c, 1);
     ZN_PT_COUNT(19, 1);                        // chunks
@@ -680,11 +774,12 @@ uint32_t zn_decode_fused_group(uint64_t K) {
 
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, hipStream_t stream) {
+                            uint8_t* d_tail_done, bool delta, hipStream_t stream) {
   if (total_wg == 0) return;
   total_wg += ntail;                             // the tail workgroups come first
-  if (P == 1) hipLaunchKernelGGL(zn_k_decode_fused<1>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_decode_fused<2>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done);
-  else hipLaunchKernelGGL(zn_k_decode_fused<4>, dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done);
-  zn_note_kernel(ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused");
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done)
+  if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
+  else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
+#undef ZN_GO
+  zn_note_kernel(delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
 }

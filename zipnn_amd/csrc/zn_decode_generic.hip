@@ -6,7 +6,7 @@
 //                        LDS and decode the four backward streams straight into the plane's
 //                        (strided) byte positions of the output — no scratch memory.
 //   zn_k_merge_planes    one workgroup per chunk: fill in the raw / RLE planes from the body,
-//                        undo the sign-bit rotate (in place, word by word).
+//                        undo the sign-bit rotate (in place, word by word), XOR with the delta base if there is one.
 //
 // Replaces: decompression_chunk_worker (reference csrc/zipnn_core.c:768-861), the metadata
 // parse of py_combine_dtype (:929-1028), HUF_decompress (call site :807) and
@@ -179,6 +179,7 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
   const uint64_t c = b - S.chunk0;
   const uint32_t clen = zn_chunk_len(g, c);
   uint8_t* out = dst + c * g.chunk;
+  const uint8_t* xo = S.xr ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;   // delta base of this chunk
   ZnPlaneDesc d[P];
   for (int p = 0; p < P; p++) d[p] = descs[(uint64_t)p * g.K + c];
   const uint32_t nwords = clen / 4u;
@@ -191,6 +192,7 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
       w |= zn_plane_byte(d[j % P], body, out, tails, j, j / P) << (8 * t);
     }
     if (g.rot) w = (P == 2) ? zn_rot_inv16(w) : zn_rot_inv32(w);
+    if (xo) for (uint32_t t = 0; t < 4; t++) w ^= (uint32_t)xo[4ull * wi + t] << (8 * t);
     const uint64_t a = (uint64_t)(out + 4ull * wi);
     if ((a & 3u) == 0) *(uint32_t*)(out + 4ull * wi) = w;
     else for (uint32_t t = 0; t < 4; t++) out[4ull * wi + t] = (uint8_t)(w >> (8 * t));
@@ -198,7 +200,7 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
   // trailing clen % 4 bytes are never rotated (reference rotates len/4 words only)
   if (sub == ZN_MERGE_SUB - 1u && threadIdx.x < (clen & 3u)) {
     const uint32_t j = 4u * nwords + threadIdx.x;
-    out[j] = (uint8_t)zn_plane_byte(d[j % P], body, out, tails, j, j / P);
+    out[j] = (uint8_t)(zn_plane_byte(d[j % P], body, out, tails, j, j / P) ^ (xo ? (uint32_t)xo[j] : 0u));
   }
 }
 

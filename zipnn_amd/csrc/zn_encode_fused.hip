@@ -87,7 +87,8 @@ struct ZnStatsLds {
 // The chunk is histogrammed quarter by quarter (a quarter = the symbols of one huff0 stream); after each
 // quarter the columns are summed (thread = bin), which yields the per-stream symbol counts that turn code
 // lengths into stream sizes later without a second pass over the data.
-template <int P>
+// X: the encoder sees src ^ xr (delta base; the host picks this instance when some tensor of the launch has one).
+template <int P, bool X>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                   uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
                                                                   ZnEncDesc* __restrict__ descs_all) {
@@ -113,10 +114,12 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
   uint32_t* hbase = &L.hist[0][lane & (COLS - 1u)];
   for (int q = 0; q < 4; q++) {
     const uint8_t* qs = src + c * g.chunk + (uint64_t)q * (g.chunk / 4u);
+    const uint8_t* xqs = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk + (uint64_t)q * (g.chunk / 4u) : nullptr;
     // 4 independent 16-byte loads in flight per thread per step
     for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
       uint4 xs[4];
       for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ZN_LD_STATS(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
+      if (X && xqs) for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nvec) { const uint4 t = ZN_LD_STATS(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
       for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
         const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
         for (int k = 0; k < 4; k++)
@@ -334,8 +337,8 @@ struct ZnEmitLds {
 };
 
 // H = plane to Huffman-encode in this pass (or -1: raw planes only); raw planes are written when `do_raw`.
-template <int P>
-__device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __restrict__ chunk_src, uint8_t* __restrict__ body,
+template <int P, bool X>
+__device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __restrict__ chunk_src, const uint8_t* __restrict__ chunk_xr, uint8_t* __restrict__ body,
                                              const uint64_t (&off)[P], const uint32_t (&kind)[P], int H, bool do_raw,
                                              const ZnEncDesc* D, const uint32_t* code, uint32_t* buf, uint32_t lane, uint32_t wave) {
   const uint32_t n = (uint32_t)(g.chunk / P), seg = n / 4u;
@@ -359,6 +362,10 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
     uint32_t d[8 * P];
     const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + ZN_E_SPL * lane);
     for (int k = 0; k < 2 * P; k++) { const uint4 x = ZN_LD_EMIT(a + 16 * k); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w; }
+    if (X && chunk_xr) {
+      const uint8_t* xa = chunk_xr + (a - chunk_src);
+      for (int k = 0; k < 2 * P; k++) { const uint4 x = ZN_LD_EMIT(xa + 16 * k); d[4 * k] ^= x.x; d[4 * k + 1] ^= x.y; d[4 * k + 2] ^= x.z; d[4 * k + 3] ^= x.w; }
+    }
     for (int k = 0; k < 8 * P; k++) d[k] = zn_rot_fwd<P>(d[k], g.rot);
     // raw planes: 32 bytes per lane, contiguous across the wave
     if (do_raw) {
@@ -447,7 +454,7 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
   return true;
 }
 
-template <int P>
+template <int P, bool X>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                  const uint32_t* __restrict__ csize_all, const uint8_t* __restrict__ type_all,
                                                                  const uint64_t* __restrict__ offs_all, const ZnEncDesc* __restrict__ descs_all,
@@ -461,6 +468,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t c = blockIdx.x - S.chunk0;
   const uint8_t* chunk_src = src + c * g.chunk;
+  const uint8_t* chunk_xr = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;
   uint64_t off[P]; uint32_t kind[P]; int nhuf = 0;           // kind: 0 raw, 1 RLE, 2 huff0
   for (int p = 0; p < P; p++) {
     const uint64_t pc = (uint64_t)p * g.K + c;
@@ -479,14 +487,14 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
     }
   }
   bool ok = true, raw_done = false;
-  if (nhuf == 0) ok = zn_emit_pass<P>(g, chunk_src, body, off, kind, -1, true, nullptr, L.code, L.buf[wave], lane, wave);
+  if (nhuf == 0) ok = zn_emit_pass<P, X>(g, chunk_src, chunk_xr, body, off, kind, -1, true, nullptr, L.code, L.buf[wave], lane, wave);
   else {
     for (int p = 0; p < P; p++) if (kind[p] == 2u) {
       const ZnEncDesc* D = descs + ((uint64_t)p * g.K + c);
       __syncthreads();
       L.code[tid] = D->code[tid];
       __syncthreads();
-      ok = zn_emit_pass<P>(g, chunk_src, body, off, kind, p, !raw_done, D, L.code, L.buf[wave], lane, wave) && ok;
+      ok = zn_emit_pass<P, X>(g, chunk_src, chunk_xr, body, off, kind, p, !raw_done, D, L.code, L.buf[wave], lane, wave) && ok;
       raw_done = true;
     }
   }
@@ -503,29 +511,32 @@ extern "C" int zn_debug_phase_read_enc(unsigned long long* out, int reset) {
 #endif
 
 // The fused encoder takes chunks [0, nfull): full chunks of a geometry zn_encode_fused_ok() accepted.
-bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src) {
+bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr) {
+  if ((((uint64_t)d_xr) & 15u) != 0) return false;
   const uint64_t n = g.chunk / g.P;
   // quarters are read 256 vectors of 16 bytes at a time; streams are packed in tiles of 2048 symbols
   return (g.chunk % 16384ull) == 0 && (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
 }
 
 void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
-                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream) {
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream) {
   if (total_chunks == 0) return;
-  if (P == 1) hipLaunchKernelGGL(zn_k_encode_stats<1>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_encode_stats<2>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
-  else hipLaunchKernelGGL(zn_k_encode_stats<4>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
-  zn_note_kernel("zn_k_encode_stats");
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_stats<P_, X_>), dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs)
+  if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
+  else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
+#undef ZN_GO
+  zn_note_kernel(delta ? "zn_k_encode_stats^delta" : "zn_k_encode_stats");
   hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
   zn_note_kernel("zn_k_encode_tables");
 }
 
 void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
-                                 uint32_t* d_status, hipStream_t stream) {
+                                 uint32_t* d_status, bool delta, hipStream_t stream) {
   if (total_chunks == 0) return;
-  if (P == 1) hipLaunchKernelGGL(zn_k_encode_emit<1>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_encode_emit<2>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status);
-  else hipLaunchKernelGGL(zn_k_encode_emit<4>, dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status);
-  zn_note_kernel("zn_k_encode_emit");
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_emit<P_, X_>), dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status)
+  if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
+  else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
+#undef ZN_GO
+  zn_note_kernel(delta ? "zn_k_encode_emit^delta" : "zn_k_encode_emit");
 }

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void zn_k_split_planes(ZnESeg one, const ZnESe
   const uint64_t c = c0 + (blockIdx.x - S.tail0), KL = g.K - c0;          // scratch slots are indexed relative to c0
   const uint32_t clen = zn_chunk_len(g, c);
   const uint8_t* in = src + c * g.chunk;
+  const uint8_t* xin = S.xr ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;   // delta base: the encoder sees in ^ xin
   const uint32_t nwords = clen / 4u;
   uint8_t* pl[P];
   for (int p = 0; p < P; p++) pl[p] = planes + ((uint64_t)p * KL + (c - c0)) * slot;
@@ -38,10 +39,11 @@ __global__ __launch_bounds__(256) void zn_k_split_planes(ZnESeg one, const ZnESe
   const uint32_t w_lo = (uint32_t)(((uint64_t)nwords * blockIdx.y) / gridDim.y), w_hi = (uint32_t)(((uint64_t)nwords * (blockIdx.y + 1u)) / gridDim.y);
   for (uint32_t wi = w_lo + threadIdx.x; wi < w_hi; wi += blockDim.x) {
     uint32_t w = aligned ? *(const uint32_t*)(in + 4ull * wi) : zn_ld32(in + 4ull * wi);
+    if (xin) w ^= zn_ld32(xin + 4ull * wi);
     if (g.rot) w = (P == 2) ? zn_rot_fwd16(w) : zn_rot_fwd32(w);
     for (uint32_t t = 0; t < 4; t++) { const uint32_t j = 4u * wi + t; pl[j % P][j / P] = (uint8_t)(w >> (8 * t)); }
   }
-  if (blockIdx.y == gridDim.y - 1u && threadIdx.x < (clen & 3u)) { const uint32_t j = 4u * nwords + threadIdx.x; pl[j % P][j / P] = in[j]; }
+  if (blockIdx.y == gridDim.y - 1u && threadIdx.x < (clen & 3u)) { const uint32_t j = 4u * nwords + threadIdx.x; pl[j % P][j / P] = (uint8_t)(in[j] ^ (xin ? xin[j] : 0)); }
 }
 
 // ---------------------------------------------------------------------------

@@ -26,6 +26,7 @@ struct ZnSeg {
   uint32_t ncg;      // chunks per fused workgroup
   uint32_t tail0;    // a partial last chunk gets P workgroups of the tail kernel / P tail-scratch slots from here …
   uint32_t has_tail; // … if this is non-zero
+  const uint8_t* xr; // delta base (orig_size bytes) the decoded bytes are XORed with on the way out, or null
 };
 
 // ---- generic decode path (any dtype, any tail) : zn_decode_generic.hip ----
@@ -35,7 +36,7 @@ void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint
                               ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_pdone,
                               const uint8_t* d_tail_scratch, const uint8_t* d_tail_done, hipStream_t stream);
 
-// ---- fused decode path (full chunks, ≤1 Huffman plane) : zn_decode_fused.hip ----
+// ---- fused decode path (full chunks; one pass per Huffman plane) : zn_decode_fused.hip ----
 uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a tensor of K chunks
 // d_done: Σ K chunk flags; d_pdone: the same per (plane, chunk) entry (Σ P·K), for the planes kernel.
 // ntail: Huffman planes of partial last chunks are decoded by `ntail` extra workgroups at the front of the grid (the
@@ -43,7 +44,7 @@ uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a te
 // tail_done[i] = 1 where that worked — the generic kernels take it from there.
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, hipStream_t stream);
+                            uint8_t* d_tail_done, bool delta, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
 
 // ---- encode ----
 struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs for a plane kept as huff0 / RLE
@@ -73,16 +74,17 @@ struct ZnESeg {
   uint32_t ptail0;     // grid key: first generic (plane, chunk) (encode planes / gather)
   uint32_t scan0;      // grid key: first scan block
   uint32_t pad2_;
+  const uint8_t* xr;   // delta base (g.n bytes): the encoder sees src ^ xr; null = none
 };
 
 // Slot stride of the generic path's scratch planes = zn_plane_slot(chunk, P).  All launchers: `one` when
 // d_segs == nullptr, else the table; grid totals are sums over the launch's tensors.
-bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src);
+bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr);    // d_xr: delta base or null
 void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
-                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, hipStream_t stream);
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream);
 void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
-                                 uint32_t* d_status, hipStream_t stream);
+                                 uint32_t* d_status, bool delta, hipStream_t stream);
 void zn_launch_encode_generic_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_tails, uint32_t total_ptails,
                                     uint8_t* d_planes, uint8_t* d_enc, uint64_t slot, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream);
 // per-tensor scan over ALL its chunks: types, cumSizes (into the body), payload offsets, total body length → d_total[total_idx]

@@ -202,6 +202,9 @@ class ZipNN:
                 out += self.compress_torch_numpy_byte(piece, lossy_compressed_type, lossy_compressed_factor)
             return out
         if delta_second_data:
+            if self.input_format == EnumFormat.BYTE.value:
+                # the XOR with the second buffer happens inside the kernels that read the data (fused, no host pass)
+                return self.compress_torch_numpy_byte(data, lossy_compressed_type, lossy_compressed_factor, delta=delta_second_data)
             data = _xor(data, delta_second_data)
         return self.compress_torch_numpy_byte(data, lossy_compressed_type, lossy_compressed_factor)
 
@@ -214,8 +217,6 @@ class ZipNN:
         is_float = self.bytearray_dtype in ("float64", "float32", "float16", "bfloat16", "float8_e4m3fn", "float8_e5m2")
         if dt is None or not is_float or mv.nbytes <= self.streaming_chunk:
             return None
-        if mvd is not None:
-            mv = memoryview(_xor(mv, mvd[:mv.nbytes]))
         h = self._header
         h[5], h[6], h[15] = dt.byte_mode, dt.rotate, dt.code
         chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
@@ -224,9 +225,12 @@ class ZipNN:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")      # (read-only input buffers: we only read them)
             flat = torch.frombuffer(mv, dtype=torch.uint8).to(dev, non_blocking=True)
-        pieces = [flat[off:off + self.streaming_chunk] for off in range(0, mv.nbytes, self.streaming_chunk)]
-        bodies = codec.compress_device_batch(_capi.lib(), [(p, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold)
-                                                           for p in pieces])
+            base = torch.frombuffer(mvd[:mv.nbytes], dtype=torch.uint8).to(dev, non_blocking=True) if mvd is not None else None
+        offs = range(0, mv.nbytes, self.streaming_chunk)
+        pieces = [flat[off:off + self.streaming_chunk] for off in offs]
+        bases = [base[off:off + self.streaming_chunk] if base is not None else None for off in offs]   # XOR fused on the device
+        bodies = codec.compress_device_batch(_capi.lib(), [(p, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold, b)
+                                                           for p, b in zip(pieces, bases)])
         payload = (torch.cat(bodies) if len(bodies) > 1 else bodies[0]).cpu().numpy()
         out = bytearray()
         o = 0
@@ -250,7 +254,7 @@ class ZipNN:
         chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
         return bytes(h) + pack_shape(tuple(t.shape)), dt.planes, dt.rotate, dt.byte_mode, chunk
 
-    def compress_torch_numpy_byte(self, data, lossy_compressed_type=None, lossy_compressed_factor=None):
+    def compress_torch_numpy_byte(self, data, lossy_compressed_type=None, lossy_compressed_factor=None, delta=None):
         """dtype -> (planes, rotate, byte mode), header, flat byte view, core call.
         Reference: zipnn.py:748-867 and compress_bin :670-746."""
         fmt = self.input_format
@@ -296,7 +300,7 @@ class ZipNN:
         self._ext_header = pack_shape(shape) if shape is not None else self._ext_header
         hdr = bytes(h) + (pack_shape(shape) if shape is not None else b"")
         frame = lib.compress(hdr, ba, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold,
-                             device=codec.current_device())
+                             device=codec.current_device(), delta=delta)
         h[24:32] = frame[24:32]   # the core patches the total length into the caller's header (zipnn_core.c:121)
         return memoryview(frame)
 
@@ -350,6 +354,8 @@ class ZipNN:
                 raise ValueError("Length of delta file has to match the length of the decompressed file.")
             return out
         if delta_second_data:
+            if self.input_format == EnumFormat.BYTE.value and mv is not None:
+                return self.decompress_bin(mv, delta=delta_second_data)     # XOR fused into the kernels that write the output
             plain = self.decompress_bin(mv)
             if len(plain) != len(delta_second_data):
                 raise ValueError("Length of delta file has to match the length of the decompressed file.")
@@ -386,17 +392,23 @@ class ZipNN:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")      # (read-only input buffers: we only read them)
             blob = torch.frombuffer(mv, dtype=torch.uint8).to(dev, non_blocking=True)
+            base = None
+            if delta_second_data:
+                mvd = memoryview(delta_second_data).cast("B")
+                if mvd.nbytes != n_out:
+                    raise ValueError("Length of delta file has to match the length of the decompressed file.")
+                base = torch.frombuffer(mvd, dtype=torch.uint8).to(dev, non_blocking=True) if n_out else None
         flat = torch.empty(n_out, dtype=torch.uint8, device=dev)
-        codec.decompress_device_batch(_capi.lib(), [(blob[b0:b1], fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"])
-                                                    for (b0, b1, fp) in frames], into=flat)
+        items, o = [], 0
+        for (b0, b1, fp) in frames:                  # frame i's slice of the second buffer: XOR fused on the device
+            n = fp["orig_size"]
+            items.append((blob[b0:b1], fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], n,
+                          base[o:o + n] if base is not None else None))
+            o += n
+        codec.decompress_device_batch(_capi.lib(), items, into=flat)
         out = bytearray(n_out)
         if n_out:
             torch.frombuffer(out, dtype=torch.uint8).copy_(flat)
-        if delta_second_data:
-            mvd = memoryview(delta_second_data).cast("B")
-            if mvd.nbytes != n_out:
-                raise ValueError("Length of delta file has to match the length of the decompressed file.")
-            return bytearray(_xor(out, mvd))
         return out
 
     def frame_params(self, frame):
@@ -409,8 +421,9 @@ class ZipNN:
         return dict(body_off=body_off, num_buf=dt.planes, bits_mode=self._bit_reorder, bytes_mode=self._byte_reorder,
                     chunk=chunk, orig_size=self.original_len, torch_dtype=dt.torch, shape=getattr(self, "shape_bytes", None))
 
-    def decompress_bin(self, frame, target=None):
-        """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198)."""
+    def decompress_bin(self, frame, target=None, delta=None):
+        """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198).  delta (BYTE format): second buffer
+        of the original length, XORed into the output on the device."""
         on_device = isinstance(frame, torch.Tensor) and frame.is_cuda
         head = bytes(frame[:HEADER_LEN + 80].cpu().numpy()) if isinstance(frame, torch.Tensor) else frame
         body_off = self._retrieve_header(head)
@@ -435,8 +448,10 @@ class ZipNN:
 
         if isinstance(frame, torch.Tensor):
             frame = memoryview(frame.cpu().contiguous().view(torch.uint8).reshape(-1).numpy())
+        if delta is not None and memoryview(delta).nbytes != self.original_len:
+            raise ValueError("Length of delta file has to match the length of the decompressed file.")
         raw = lib.decompress(memoryview(frame)[body_off:], dt.planes, self._bit_reorder, self._byte_reorder, chunk,
-                             self.original_len, device=codec.current_device())
+                             self.original_len, device=codec.current_device(), delta=delta if self.original_len else None)
         if fmt == EnumFormat.BYTE.value:
             return memoryview(raw)
         if fmt == EnumFormat.TORCH.value:
