@@ -433,3 +433,15 @@ def test_delta_device_resident_256MiB_roundtrip_and_ratio(lib):
     assert torch.equal(out, fx)
     assert lib.last_fused_chunks() == fx.numel() // C
     assert body.numel() < 0.2 * fx.numel()
+
+
+def test_replicated_decode_single_rank(lib):
+    """sharding.decompress_replicated without a process group: rank 0 of 1 decodes everything (the N>1 path is covered
+    by the gloo test; 8-GPU boxes are the driver's)."""
+    from test_oracle import gen_bytes
+    from zipnn_amd import sharding
+    nb = 9 * C + 4321
+    d = gen_bytes("bf16", nb, 4)
+    body = O.compress_frame(b"", d, 2, 1, 10, C, threads=4)
+    out = sharding.decompress_replicated(lib, body, 2, 1, 10, C, nb, torch.device("cuda:0"))
+    assert out.cpu().numpy().tobytes() == d

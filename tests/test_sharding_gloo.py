@@ -65,3 +65,41 @@ def test_split_bodies_decode_independently(world):
     K = (nb + C - 1) // C
     again = sharding.merge_bodies([(sub, hi - lo) for (sub, _, _), (lo, hi) in zip(parts, sharding.chunk_ranges(K, world))], P)
     assert again == body
+
+
+def _replicated_worker(rank, world, port, case, q):
+    """Each rank decodes its chunk range with the PRODUCT kernels (SIMT-emulated build, CPU tensors), gloo all-gather."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zipnn_amd._capi import ZnLib
+    lib = ZnLib(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt", "libzipnn_simt.so"))
+    kind, nb, P, rot, bm = case
+    data = gen_bytes(kind, nb, 9)
+    body = O.compress_frame(b"", data, P, rot, bm, C)
+    out = sharding.decompress_replicated(lib, body, P, rot, bm, C, nb, torch.device("cpu"))
+    q.put((rank, out.numpy().tobytes() == data, out.numel()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[3], ("fp32", 3 * C, 4, 1, 220)], ids=lambda c: f"{c[0]}-{c[1]}")
+def test_replicated_decode_all_gathers_the_shards(case, simt_lib):
+    """every rank decodes 1/G of the chunks, one all-gather leaves the whole tensor on every rank
+    (3 chunks on 2 ranks, a single partial chunk on 2 ranks — rank 1 idle —, and 8 chunks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() + case[1]) % 2000
+    procs = [ctx.Process(target=_replicated_worker, args=(r, 2, port, case, q)) for r in range(2)]
+    [p.start() for p in procs]
+    got = sorted([q.get(timeout=180) for _ in range(2)])
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert [g[1] for g in got] == [True, True] and all(g[2] == case[1] for g in got)
+
+
+def test_uniform_ranges_cover_every_chunk_once():
+    for K in (0, 1, 2, 7, 8, 9, 1000):
+        for G in (1, 2, 3, 8):
+            r = sharding.uniform_ranges(K, G)
+            assert r[0][0] == 0 and r[-1][1] == K and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert len({hi - lo for lo, hi in r if hi - lo} | {0}) <= 3

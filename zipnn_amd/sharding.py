@@ -7,6 +7,8 @@ regions of the final payload; these helpers do that arithmetic:
   chunk_ranges(K, G)                 contiguous ranges [g*K/G, (g+1)*K/G)
   split_body(body, P, chunk, n, G)   one standalone body per rank (types / re-based cumSizes / payload slices)
   merge_bodies(parts, P)             the inverse: bodies of consecutive chunk ranges -> one body
+  decompress_replicated(...)         every rank decodes its chunk range in HBM, one all-gather (RCCL over xGMI)
+                                     leaves the whole tensor on every GPU (replicated-weight loading)
 
 A merged body is byte-identical to the body a single device produces for the whole buffer.
 """
@@ -25,14 +27,21 @@ def _parse(body, P, K):
     return types, cum, payload
 
 
-def split_body(body, num_buf, chunk, orig_size, world):
-    """-> list of (sub_body: bytes, byte_offset, byte_length) for each rank's chunk range."""
+def uniform_ranges(num_chunks, world):
+    """ceil(K / G) chunks per rank (the last ranks may get fewer or none): equal shard sizes, as an all-gather wants."""
+    per = (num_chunks + world - 1) // world if world else 0
+    return [(min(g * per, num_chunks), min((g + 1) * per, num_chunks)) for g in range(world)]
+
+
+def split_body(body, num_buf, chunk, orig_size, world, ranges=None):
+    """-> list of (sub_body: bytes, byte_offset, byte_length) for each rank's chunk range
+    (ranges: explicit [(lo, hi)] per rank; default chunk_ranges(K, world))."""
     P = num_buf
     K = (orig_size + chunk - 1) // chunk
     types, cum, payload = _parse(body, P, K)
     plane_base = np.concatenate([[0], np.cumsum(cum[:, -1])[:-1]]) if K else np.zeros(P, dtype=np.int64)
     out = []
-    for lo, hi in chunk_ranges(K, world):
+    for lo, hi in (ranges if ranges is not None else chunk_ranges(K, world)):
         k = hi - lo
         pieces, cums = [], []
         for p in range(P):
@@ -67,3 +76,29 @@ def merge_bodies(parts, num_buf):
     cat = lambda xs, dt: (np.concatenate(xs).astype(dt).tobytes() if xs else b"")  # noqa: E731
     return (b"".join(cat(types_all[p], np.uint8) for p in range(P)) + b"".join(cat(cum_all[p], np.uint64) for p in range(P))
             + b"".join(cat(pay_all[p], np.uint8) for p in range(P)))
+
+
+def decompress_replicated(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, device, group=None):
+    """Replicated-weight loading: `body` (host bytes-like, the same on every rank) -> the decoded tensor bytes on
+    EVERY rank's device.  Rank g uploads and decodes only its chunk range (1/G of the compressed bytes cross its PCIe
+    link, 1/G of the decode work), then one all-gather of equal shards — RCCL over xGMI on GPUs — fills in the rest.
+    This is the one place the path has a real exchange step; plain sharded decode (each rank keeps its slice) has none.
+    Returns a uint8 tensor of orig_size bytes on `device`."""
+    import torch
+    import torch.distributed as dist
+    from . import codec
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    K = (orig_size + chunk - 1) // chunk
+    ranges = uniform_ranges(K, world)
+    shard = ((K + world - 1) // world) * chunk if world else 0          # bytes per rank in the gathered buffer
+    full = torch.empty(max(shard * world, 1), dtype=torch.uint8, device=device)
+    lo, hi = ranges[rank]
+    if hi > lo:
+        sub, off, length = split_body(body, num_buf, chunk, orig_size, world, ranges)[rank]
+        sub_t = torch.frombuffer(bytearray(sub), dtype=torch.uint8).to(device, non_blocking=True)
+        codec.decompress_device(lib, sub_t, num_buf, bits_mode, bytes_mode, chunk, length, out=full[off:off + length])
+    if world > 1:
+        mine = full[rank * shard:(rank + 1) * shard].clone()            # (gloo does not take an aliasing input)
+        dist.all_gather_into_tensor(full[:shard * world], mine, group=group)
+    return full[:orig_size]
