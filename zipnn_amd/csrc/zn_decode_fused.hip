@@ -621,7 +621,9 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
   const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
   uint8_t* __restrict__ dst = ZN_GLOBAL_PTR(uint8_t, S.dst); uint8_t* __restrict__ done = done_all + S.chunk0;
   uint8_t* __restrict__ pdone = pdone_all + S.desc0;   // the same flag per (plane, chunk)
-#define ZN_SET_DONE(c_, v_) do { if (tid == 0) done[c_] = (v_); if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
+// (status[1 + q], q = 0/1/2 for 1/2/4 planes: how many chunks of this launch are left to the generic kernels — they
+//  return at once when it is zero)
+#define ZN_SET_DONE(c_, v_) do { if (tid == 0) { done[c_] = (v_); if (!(v_)) atomicAdd(status + 1 + (P == 1 ? 0 : P == 2 ? 1 : 2), 1u); } if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;

@@ -134,7 +134,9 @@ __device__ void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, const ZnS
 // (checked before anything else, so a launch where everything is done costs a few microseconds).
 __global__ __launch_bounds__(ZN_WAVE) void zn_k_decode_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t total,
                                                               ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
-                                                              const uint8_t* __restrict__ pdone, const uint8_t* __restrict__ tail_done) {
+                                                              const uint8_t* __restrict__ pdone, const uint8_t* __restrict__ tail_done,
+                                                              const uint32_t* __restrict__ left) {
+  if (left && *left == 0u) return;             // the fused kernel took every chunk of the launch
   __shared__ ZnPlanesLds L;
   __shared__ uint32_t n_todo; __shared__ uint16_t todo[ZN_WAVE];
   // this wave's items are b = blockIdx.x + i * gridDim.x; their flags are read 64 at a time (one latency)
@@ -207,7 +209,8 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
 template <int P>
 __global__ __launch_bounds__(256) void zn_k_merge_planes(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t total,
                                                          const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ done_all,
-                                                         const uint8_t* __restrict__ tails) {
+                                                         const uint8_t* __restrict__ tails, const uint32_t* __restrict__ left) {
+  if (left && *left == 0u) return;             // the fused kernel took every chunk of the launch
   __shared__ uint32_t n_todo; __shared__ uint16_t todo[256];
   // items = (chunk, sixteenth); this workgroup's items are it = blockIdx.x + i * gridDim.x; the chunks' flags are
   // read 256 at a time (one latency)
@@ -232,11 +235,13 @@ void zn_launch_decode_generic(int P, const ZnSeg& one, const ZnSeg* d_segs, uint
                               ZnPlaneDesc* d_descs, uint32_t* d_status, const uint8_t* d_done, const uint8_t* d_pdone,
                               const uint8_t* d_tail_scratch, const uint8_t* d_tail_done, hipStream_t stream) {
   if (total_k == 0) return;
+  // d_done != null: the fused kernel ran before us and counted the chunks it left in d_status[1 + q]
+  const uint32_t* left = d_done ? d_status + 1 + (P == 1 ? 0 : P == 2 ? 1 : 2) : nullptr;
   const uint32_t gp = (uint32_t)(total_pk < 2048u ? total_pk : 2048u), gm = (uint32_t)(total_k * ZN_MERGE_SUB < 1024u ? total_k * ZN_MERGE_SUB : 1024u);
-  hipLaunchKernelGGL(zn_k_decode_planes, dim3(gp), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, total_pk, d_descs, d_status, d_pdone, d_tail_done);
+  hipLaunchKernelGGL(zn_k_decode_planes, dim3(gp), dim3(ZN_WAVE), 0, stream, one, d_segs, nseg, total_pk, d_descs, d_status, d_pdone, d_tail_done, left);
   zn_note_kernel("zn_k_decode_planes");
-  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);
-  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);
-  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch);
+  if (P == 1) hipLaunchKernelGGL(zn_k_merge_planes<1>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch, left);
+  else if (P == 2) hipLaunchKernelGGL(zn_k_merge_planes<2>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch, left);
+  else hipLaunchKernelGGL(zn_k_merge_planes<4>, dim3(gm), dim3(256), 0, stream, one, d_segs, nseg, total_k, d_descs, d_done, d_tail_scratch, left);
   zn_note_kernel("zn_k_merge_planes");
 }
