@@ -57,6 +57,9 @@
 #endif
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
+#ifndef ZN_F_EARLY_STAGE
+#define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
+#endif
 #ifndef ZN_F_DELTA0
 #define ZN_F_DELTA0 16                   // initial sync run-in (bits); doubles after a mismatch
 #endif
@@ -259,9 +262,13 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   // interleave rows (ring bytes for the Huffman plane, fetched bytes for raw planes) and store them.
   // All loads are complete before the first store is issued, so no store latency is ever waited on.
   // `stage_row0` = staging-buffer row that holds symbol `first_row_sym`.
-  auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0) {
+  // `after_wait` runs right behind the wait, before the first store is issued: whatever else has to consume
+  // loaded registers (the staging of the next stream tile) does it there, so that nothing ever waits on a STORE
+  // (gfx9 has one in-order counter for loads and stores: a wait for a load issued after stores waits for their acks)
+  auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0, auto&& after_wait) {
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
     ZN_PT(10);  // wait for the fetched rows
+    after_wait();
     // delta base of these rows, two rows at a time, double-buffered: the next pair is requested before the current
     // pair is stored (more rows in flight would spill: the fetched raw rows are live here too)
     constexpr int XW = X ? (P == 4 ? 8 : 4) : 1, XG = 2;
@@ -327,7 +334,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     // no Huffman plane: the chunk is a pure P-way interleave of raw / RLE planes
     while (JF < seg) {
       const uint32_t left = (seg - JF) / UNIT; const int nr = left < (uint32_t)RB ? (int)left : RB;
-      fetch_rows(JF, nr); emit_rows(JF, nr, 0); JF += (uint32_t)nr * UNIT;
+      fetch_rows(JF, nr); emit_rows(JF, nr, 0, [] {}); JF += (uint32_t)nr * UNIT;
     }
     ZN_PT(3);
     return true;
@@ -349,40 +356,54 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
   int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
 
-  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D
+  // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D-1, and (lane 0) the
+  // tile's last dword, in a register of its own so that nothing selects on a loaded value before the staging
   // (the stream's top dword may straddle the end of the buffer: that one dword is assembled from bytes)
-  uint32_t nx[ZN_F_DMAX + 1];
+  uint32_t nx[ZN_F_DMAX], nx_last = 0;
   const int32_t top_dw = hi_dw - 1;
   const bool top_guard = ((const uint8_t*)(gdw + hi_dw) > body_end);
   auto fetch_tile = [&](int32_t lo_dw_, int32_t hi_dw_) {
     const uint32_t* p = gdw + (lo_dw_ - 1) + (int32_t)lane;
     if (lo_dw_ >= 0 && !(top_guard && hi_dw_ - 1 == top_dw)) {
-      // common case: every dword of the tile exists in the buffer; lane 0 also fetches the tile's last dword
+      // common case: every dword of the tile exists in the buffer
       for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? p[64 * i] : 0u;
-      nx[ZN_F_DMAX] = 0u;
-      const uint32_t last = (lane == 0) ? p[TD] : 0u;
-      for (int i = 0; i <= ZN_F_DMAX; i++) if (i == Di) nx[i] = last;
+      nx_last = gdw[__builtin_amdgcn_readfirstlane(hi_dw_) - 1];   // (every lane, the same address: no select on the way into the register)
     } else {
-      for (int i = 0; i <= ZN_F_DMAX; i++) {
-        const int32_t li = (int32_t)lane + 64 * i, gi = lo_dw_ - 1 + li;
+      auto dword_at = [&](int32_t li) -> uint32_t {
+        const int32_t gi = lo_dw_ - 1 + li;
         uint32_t x = 0;
         if (li <= TD && gi >= -1 && gi < hi_dw_) {
           if (top_guard && gi == top_dw) { const uint8_t* pa = (const uint8_t*)(gdw + gi); for (int b = 0; b < 4; b++) if (pa + b < body_end) x |= (uint32_t)pa[b] << (8 * b); }
           else x = gdw[gi];
         }
-        nx[i] = x;
-      }
+        return x;
+      };
+      for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? dword_at((int32_t)lane + 64 * i) : 0u;
+      nx_last = (lane == 0) ? dword_at(TD) : 0u;
     }
   };
+  // stage the prefetched tile into LDS.  Done for the first tile here and for every later one from inside the flush
+  // of its predecessor (behind the flush's wait, ahead of its stores): at the top of the tile loop the wait for
+  // the prefetch registers is a wait for those stores to be acknowledged as well (gfx9 counts loads and stores on
+  // one in-order counter) — the phase timers had 19 % of a wave's time there.
+  auto stage_tile = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    for (int i = 0; i < ZN_F_DMAX; i++) if (i < Di) in[ZN_IN_IDX((int32_t)lane + 64 * i)] = nx[i];
+    if (lane == 0) in[ZN_IN_IDX(TD)] = nx_last;
+    __builtin_amdgcn_wave_barrier();
+  };
   fetch_tile(hi_dw - TD, hi_dw);
+#if ZN_F_EARLY_STAGE
+  stage_tile();
+#endif
 
   bool ok = true;
   while (32 * hi_dw > b0) {
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
-    __builtin_amdgcn_wave_barrier();
-    for (int i = 0; i <= ZN_F_DMAX; i++) { const int32_t li = (int32_t)lane + 64 * i; if (li <= TD) in[ZN_IN_IDX(li)] = nx[i]; }
-    __builtin_amdgcn_wave_barrier();
+#if !ZN_F_EARLY_STAGE
+    stage_tile();
+#endif
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
     ZN_PT(4);   // stage tile
     const int32_t base_bit = 32 * (lo_dw - 1);
@@ -459,8 +480,14 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
       const int total_rows = rows;
       uint32_t srow = 0;
-      emit_rows(JF, first, srow); JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
-      while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
+      // (the write pass of the tile's last lane group is over: the stream-tile buffer is free for the next tile)
+      emit_rows(JF, first, srow, [&] {
+#if ZN_F_EARLY_STAGE
+        if (lane_hi >= 64u && 32 * hi_dw > b0) stage_tile();
+#endif
+      });
+      JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
+      while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
       if (total_rows > 0 && J > JF) {
         // move the incomplete last row (< UNIT symbols) to the start of the staging buffer
         const uint32_t i = ((uint32_t)total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
@@ -477,7 +504,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   }
   if (ragged && ok && carry == b0 && J == seg && JF < seg) {
     // a stream of a partial chunk: the last row is incomplete — store it whole (the destination is padded)
-    emit_rows(JF, 1, 0); JF += UNIT;
+    emit_rows(JF, 1, 0, [] {}); JF += UNIT;
   }
   return ok && carry == b0 && J == seg && JF >= seg;
 }
