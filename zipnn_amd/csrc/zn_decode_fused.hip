@@ -57,6 +57,17 @@
 #endif
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
+#ifndef ZN_F_ABLATE
+#define ZN_F_ABLATE 0                    // developer builds (scripts/ab_variants.py): repeat a phase (results unchanged) to price it on the device: 1 LUT fill, 2 sync run-in, 4 count pass, 8 write pass
+#endif
+#ifndef ZN_F_WMASK
+#define ZN_F_WMASK 0                     // write pass: idle lanes kept out of the atomics by the exec mask (one v_cndmask less per step)
+#endif
+#if !defined(ZN_SIMT_EMULATOR)
+#define ZN_OPAQUE32(x) asm volatile("" : "+v"(x))
+#else
+#define ZN_OPAQUE32(x) ((void)0)
+#endif
 #ifndef ZN_F_EARLY_STAGE
 #define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
 #endif
@@ -142,7 +153,13 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
   //  reads the same way was measured and does not pay)
   const bool act = FULL ? (c.pos > bound) : (c.pos > c.stop);
   uint32_t meta = lut32[idx], syms = (MODE == 2) ? lut32[idx + (1u << ZN_F_TLMAX)] : 0u;
+#if ZN_F_WMASK
+  // (the symbol word of a lane that takes nothing stays unmasked: a full step keeps such lanes out of the atomics
+  //  with the exec mask instead, the boundary step clears the word through its count of zero)
+  meta = act ? meta : 0u;
+#else
   meta = act ? meta : 0u; syms = act ? syms : 0u;
+#endif
   uint32_t nb, cnt;
   if (FULL) {
     nb = (meta >> 16) & 15u; cnt = meta >> 29;
@@ -162,8 +179,16 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
     const uint64_t pack = ((uint64_t)((meta >> 20) & 0xFFu) << 32) | syms;
     const uint64_t sp = pack << ((c.wpos & 3u) << 3);
     uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & ~3u));
+#if ZN_F_WMASK
+    uint32_t sp_lo = (uint32_t)sp, sp_hi = (uint32_t)(sp >> 32);
+    ZN_OPAQUE32(sp_hi);                                            // (else the test below becomes a 64-bit compare)
+    const bool on = FULL ? act : true;
+    if (on && sp_lo) atomicOr(d, sp_lo);
+    if (on && sp_hi) atomicOr(d + 1, sp_hi);
+#else
     if ((uint32_t)sp) atomicOr(d, (uint32_t)sp);
     if ((uint32_t)(sp >> 32)) atomicOr(d + 1, (uint32_t)(sp >> 32));
+#endif
     c.wpos += cnt;
   }
   { const uint64_t w = (((uint64_t)c.whi << 32) | c.wlo) << nb; c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w; }   // v_lshlrev_b64
@@ -413,16 +438,22 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
     // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it
     ZnChain A;
-    A.pos = (lane > 0 && active) ? hi_k + delta : hi_k; A.stop = hi_k; A.n = 0; A.wpos = 0; A.whi = 0; A.wlo = 0;
-    if (delta <= 21) {
-      // short run-in: one refill feeds one whole group (≤ TL bits) and the boundary step (≤ TL bits)
-      zn_chain_refill(A, in, base_bit);
-      zn_chain_step<0, true>(A, lut32, 32u - TL, A.stop + (int32_t)TL - 1, nullptr);
-      zn_chain_step<0, false>(A, lut32, 32u - TL, A.stop, nullptr);
-      while (__any(A.pos > A.stop)) { zn_chain_refill(A, in, base_bit); zn_chain_step<0, false>(A, lut32, 32u - TL, A.stop, nullptr); }
-    } else {
-      zn_fused_run<0>(lut32, in, base_bit, TL, A, nullptr);
-    }
+    auto sync_run = [&](ZnChain& c) {
+      c.pos = (lane > 0 && active) ? hi_k + delta : hi_k; c.stop = hi_k; c.n = 0; c.wpos = 0; c.whi = 0; c.wlo = 0;
+      if (delta <= 21) {
+        // short run-in: one refill feeds one whole group (≤ TL bits) and the boundary step (≤ TL bits)
+        zn_chain_refill(c, in, base_bit);
+        zn_chain_step<0, true>(c, lut32, 32u - TL, c.stop + (int32_t)TL - 1, nullptr);
+        zn_chain_step<0, false>(c, lut32, 32u - TL, c.stop, nullptr);
+        while (__any(c.pos > c.stop)) { zn_chain_refill(c, in, base_bit); zn_chain_step<0, false>(c, lut32, 32u - TL, c.stop, nullptr); }
+      } else {
+        zn_fused_run<0>(lut32, in, base_bit, TL, c, nullptr);
+      }
+    };
+    sync_run(A);
+#if ZN_F_ABLATE & 2
+    { ZnChain B; sync_run(B); uint32_t t_ = (uint32_t)B.pos; ZN_OPAQUE32(t_); }
+#endif
     int32_t s = (lane > 0) ? A.pos : carry;
     ZN_PT(5);   // sync run-in
 
@@ -430,6 +461,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     uint32_t n = 0; int32_t e = s; bool need = active, chained = false;
     for (int it = 0; it < 66; it++) {
       A.pos = need ? s : stop; A.stop = stop; A.n = 0;
+#if ZN_F_ABLATE & 4
+      { ZnChain B = A; zn_fused_run<1>(lut32, in, base_bit, TL, B, nullptr); uint32_t t_ = B.n + (uint32_t)B.pos; ZN_OPAQUE32(t_); }
+#endif
       zn_fused_run<1>(lut32, in, base_bit, TL, A, nullptr);
       if (need) { e = A.pos; n = A.n; }
       const int32_t e_prev = __shfl_up(e, 1u);
@@ -473,6 +507,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
       const bool mine = active && lane >= lane_lo && lane < lane_hi;
       A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
+#if ZN_F_ABLATE & 8
+      { ZnChain B = A; zn_fused_run<2>(lut32, in, base_bit, TL, B, ring); }      // (OR-ing the same symbols twice changes nothing)
+#endif
       zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
       __builtin_amdgcn_wave_barrier();
       ZN_PT(9);   // write pass
@@ -726,6 +763,9 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       const ZnWaveStats st = L.st[j];
       const int hs = st.hs; TL = st.tl;
       zn_fused_fill_luts(L, tid, TL, j);
+#if ZN_F_ABLATE & 1
+      __syncthreads(); zn_fused_fill_luts(L, tid, TL, j);
+#endif
       // jump table → this wave's stream
       const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
       const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
