@@ -27,13 +27,18 @@ PKG = os.path.join(ROOT, "zipnn_amd")
 # name -> (commit or None, [flags])
 VARIANTS = {
     "r01z": ("5886209", []),                        # the kernels the round-1 profiles were taken from
+    "c1": ("HEAD", []),                             # the last commit
     "new": (None, []),
     "late": (None, ["-DZN_F_EARLY_STAGE=0"]),       # tile staging back at the top of the loop
-    "wmask": (None, ["-DZN_F_WMASK=1"]),
     "x2lut": (None, ["-DZN_F_ABLATE=1"]),
     "x2sync": (None, ["-DZN_F_ABLATE=2"]),
     "x2count": (None, ["-DZN_F_ABLATE=4"]),
     "x2write": (None, ["-DZN_F_ABLATE=8"]),
+    "x2tree": (None, ["-DZN_F_ABLATE=256"]),
+    "nostore": (None, ["-DZN_F_ABLATE=16"]),
+    "noraw": (None, ["-DZN_F_ABLATE=32"]),
+    "nowrite": (None, ["-DZN_F_ABLATE=64"]),
+    "nomem": (None, ["-DZN_F_ABLATE=48"]),
     "d12": (None, ["-DZN_F_DELTA0=12"]),
     "d20": (None, ["-DZN_F_DELTA0=20"]),
 }
@@ -80,11 +85,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01z", "new", "late", "wmask")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01z", "new", "late", "wmask")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01z", "new", "late", "wmask"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01z", "c1", "new", "late")),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01z", "c1", "new", "late")),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01z", "c1", "new", "late"))]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01z", "new", "late", "wmask")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01z", "c1", "new", "late")))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:

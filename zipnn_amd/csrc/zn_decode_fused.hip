@@ -58,15 +58,21 @@
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
 #ifndef ZN_F_ABLATE
-#define ZN_F_ABLATE 0                    // developer builds (scripts/ab_variants.py): repeat a phase (results unchanged) to price it on the device: 1 LUT fill, 2 sync run-in, 4 count pass, 8 write pass
-#endif
-#ifndef ZN_F_WMASK
-#define ZN_F_WMASK 0                     // write pass: idle lanes kept out of the atomics by the exec mask (one v_cndmask less per step)
+#define ZN_F_ABLATE 0                    // developer builds (scripts/ab_variants.py): repeat a phase (results unchanged) to price it on the device: 1 LUT fill, 2 sync run-in, 4 count pass, 8 write pass, 256 tree description; or drop one (timing only, wrong output): 16 output stores, 32 raw-plane loads, 64 write pass
 #endif
 #if !defined(ZN_SIMT_EMULATOR)
 #define ZN_OPAQUE32(x) asm volatile("" : "+v"(x))
+// (a & mask) | (b & ~mask) as ONE v_bfi_b32: left to itself the compiler simplifies the masked shift first and
+// then needs and + and + or for the second of the two (seen in the ISA of the un-rotate: 8 VALU per dword pair)
+__device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t b) {
+  uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b)); return d;
+}
+#define ZN_BFI(mask, a, b) zn_bfi_((mask), (a), (b))
+#define ZN_NO_IFCVT asm volatile("")     // keeps a rarely-taken block a real (scalar) branch
 #else
+#define ZN_NO_IFCVT ((void)0)
 #define ZN_OPAQUE32(x) ((void)0)
+#define ZN_BFI(mask, a, b) ((((uint32_t)(a)) & (uint32_t)(mask)) | (((uint32_t)(b)) & ~(uint32_t)(mask)))
 #endif
 #ifndef ZN_F_EARLY_STAGE
 #define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
@@ -153,13 +159,7 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
   //  reads the same way was measured and does not pay)
   const bool act = FULL ? (c.pos > bound) : (c.pos > c.stop);
   uint32_t meta = lut32[idx], syms = (MODE == 2) ? lut32[idx + (1u << ZN_F_TLMAX)] : 0u;
-#if ZN_F_WMASK
-  // (the symbol word of a lane that takes nothing stays unmasked: a full step keeps such lanes out of the atomics
-  //  with the exec mask instead, the boundary step clears the word through its count of zero)
-  meta = act ? meta : 0u;
-#else
   meta = act ? meta : 0u; syms = act ? syms : 0u;
-#endif
   uint32_t nb, cnt;
   if (FULL) {
     nb = (meta >> 16) & 15u; cnt = meta >> 29;
@@ -179,16 +179,8 @@ __device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32,
     const uint64_t pack = ((uint64_t)((meta >> 20) & 0xFFu) << 32) | syms;
     const uint64_t sp = pack << ((c.wpos & 3u) << 3);
     uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & ~3u));
-#if ZN_F_WMASK
-    uint32_t sp_lo = (uint32_t)sp, sp_hi = (uint32_t)(sp >> 32);
-    ZN_OPAQUE32(sp_hi);                                            // (else the test below becomes a 64-bit compare)
-    const bool on = FULL ? act : true;
-    if (on && sp_lo) atomicOr(d, sp_lo);
-    if (on && sp_hi) atomicOr(d + 1, sp_hi);
-#else
     if ((uint32_t)sp) atomicOr(d, (uint32_t)sp);
     if ((uint32_t)(sp >> 32)) atomicOr(d + 1, (uint32_t)(sp >> 32));
-#endif
     c.wpos += cnt;
   }
   { const uint64_t w = (((uint64_t)c.whi << 32) | c.wlo) << nb; c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w; }   // v_lshlrev_b64
@@ -281,6 +273,10 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     for (int r = 0; r < RB; r++) if (r < nrows)
       for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
         const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+#if ZN_F_ABLATE & 32
+        for (int k = 0; k < EW; k++) pre[r][p][k] = (uint32_t)(uint64_t)a;                                 // (timing only: no raw-plane loads)
+        continue;
+#endif
         for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
       }
   };
@@ -312,7 +308,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     for (int r = 0; r < RB; r++) if (r < nrows) {
       for (int p = 0; p < P; p++) {
         if (p == H) { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
-        else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) pre[r][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
+        else if (pl[p].kind == ZN_KIND_RLE) { ZN_NO_IFCVT; for (int k = 0; k < EW; k++) pre[r][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }   // (a branch: as selects this cost every row two VALU ops)
       }
     }
     // undo the sign-bit rotate on the two top planes BEFORE the interleave (4 elements per dword):
@@ -321,8 +317,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       for (int r = 0; r < RB; r++) if (r < nrows)
         for (int k = 0; k < EW; k++) {
           const uint32_t hi = pre[r][P - 1][k], lo = pre[r][(P >= 2) ? P - 2 : 0][k];
-          pre[r][P - 1][k] = (lo & 0x80808080u) | ((hi >> 1) & ~0x80808080u);
-          pre[r][(P >= 2) ? P - 2 : 0][k] = (lo & 0x7F7F7F7Fu) | ((hi << 7) & ~0x7F7F7F7Fu);
+          pre[r][P - 1][k] = ZN_BFI(0x80808080u, lo, hi >> 1);
+          pre[r][(P >= 2) ? P - 2 : 0][k] = ZN_BFI(0x7F7F7F7Fu, lo, hi << 7);
         }
     }
     for (int r = 0; r < RB; r++) if (r < nrows) {
@@ -338,7 +334,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
         x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
         if (X) for (int k = 0; k < 4; k++) x[k] ^= xr_[k % XW];
+#if ZN_F_ABLATE & 16
+        ZN_OPAQUE32(x[0]); ZN_OPAQUE32(x[1]); ZN_OPAQUE32(x[2]); ZN_OPAQUE32(x[3]); (void)o;   // (timing only: no output)
+#else
         ZN_ST128(o, x[0], x[1], x[2], x[3]);
+#endif
       } else {
         for (int half = 0; half < 2; half++) {
           const int k = half % EW;
@@ -510,7 +510,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #if ZN_F_ABLATE & 8
       { ZnChain B = A; zn_fused_run<2>(lut32, in, base_bit, TL, B, ring); }      // (OR-ing the same symbols twice changes nothing)
 #endif
+#if !(ZN_F_ABLATE & 64)                                          // (64: timing only, the staging buffer stays empty)
       zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
+#endif
       __builtin_amdgcn_wave_barrier();
       ZN_PT(9);   // write pass
       J += nsub; wdone = wend; lane_lo = lane_hi;
@@ -731,6 +733,10 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       uint8_t* scratch = (uint8_t*)&L.ring[wave][0];          // weights + FSE cells; the ring is idle until the decode
       st = zn_wave_read_stats(body + L.plane[wave][h].off, csize, body_end, lane, scratch, L.symlist[wave], L.rank_start[wave],
                               L.sym_start[wave], scratch + 512);
+#if ZN_F_ABLATE & 256
+      st = zn_wave_read_stats(body + L.plane[wave][h].off, csize, body_end, lane, scratch, L.symlist[wave], L.rank_start[wave],
+                              L.sym_start[wave], scratch + 512);
+#endif
       if (st.hs < 0 || st.tl > ZN_F_TLMAX || (uint32_t)st.hs >= csize || csize - (uint32_t)st.hs < 10u) elig = false;
     }
     if (lane == 0) { L.st[wave] = st; L.what[wave] = elig ? (uint32_t)(h + 2) : 0u; }   // 0: not ours, 1: no Huffman plane, 2+h
