@@ -121,9 +121,25 @@ def run(names):
                 for _ in range(10):
                     L.zn_decompress_dev(body.data_ptr(), ln.value, P, rot, bm, chunk, n, out.data_ptr(), st, 0)
                 torch.cuda.synchronize(); best[k] = min(best[k], (time.perf_counter() - t0) / 10)
+        # compress: same frame body as the first variant's, then interleaved timing (one length read-back per call)
+        bestc = {k: 1e9 for k, _ in use}; okc = {}
+        body2 = torch.empty(cap, dtype=torch.uint8, device="cuda"); ln2 = ctypes.c_size_t(0)
+        for k, L in use:
+            body2.zero_()
+            rc = L.zn_compress_dev(flat.data_ptr(), n, P, rot, bm, chunk, 0.95, body2.data_ptr(), cap, ctypes.byref(ln2), st)
+            okc[k] = (rc == 0) and ln2.value == ln.value and bool(torch.equal(body2[:ln.value], body[:ln.value]))
+        for rnd in range(4):
+            for k, L in use:
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(5):
+                    L.zn_compress_dev(flat.data_ptr(), n, P, rot, bm, chunk, 0.95, body2.data_ptr(), cap, ctypes.byref(ln2), st)
+                torch.cuda.synchronize(); bestc[k] = min(bestc[k], (time.perf_counter() - t0) / 5)
         for k, _ in use:
-            print(f"{name:12s} {k:10s} exact={ok[k]}  decode {best[k] * 1e3:7.3f} ms {n / best[k] / 1e9:7.0f} GB/s  ratio {ln.value / n:.4f}", flush=True)
-            results[f"{name}/{k}"] = {"ms": best[k] * 1e3, "GBps": n / best[k] / 1e9, "exact": ok[k]}
+            print(f"{name:12s} {k:10s} exact={ok[k]}  decode {best[k] * 1e3:7.3f} ms {n / best[k] / 1e9:7.0f} GB/s  ratio {ln.value / n:.4f}"
+                  f"   compress same={okc[k]} {bestc[k] * 1e3:7.3f} ms {n / bestc[k] / 1e9:6.0f} GB/s", flush=True)
+            results[f"{name}/{k}"] = {"ms": best[k] * 1e3, "GBps": n / best[k] / 1e9, "exact": ok[k],
+                                      "compress_ms": bestc[k] * 1e3, "compress_same": okc[k]}
+        del body2
         del x, flat, body, out
         torch.cuda.empty_cache()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -121,3 +121,23 @@ def test_streaming_compress_batched_equals_per_frame_loop(use_simt):
     blob2 = zd.compress(raw, delta_second_data=other)
     back2 = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 16, delta_compressed_type="byte").decompress(blob2, delta_second_data=other)
     assert bytes(back2) == raw
+
+
+def test_host_buffer_entry_points_through_the_pinned_pipe(simt_lib, monkeypatch):
+    """zn_compress / zn_decompress with host buffers above the pipe's threshold: the sliced, multi-threaded
+    transfer (zn_host_pipe.hpp — plain memcpy under the emulator, same slicing / barriers / stripes) must hand the
+    kernels exactly the caller's bytes and return exactly theirs.  Sizes straddle slice and stripe boundaries."""
+    import numpy as np
+    import oracle_lib as O
+    rng = np.random.default_rng(7)
+    for n, threads in ((2 * 1024 * 1024 + 2, "3"), (5 * 1024 * 1024 + 4098, "8"), (17 * 1024 * 1024 + 6, "5")):
+        monkeypatch.setenv("ZN_HOST_THREADS", threads)
+        x = (rng.standard_normal(n // 2) * 0.02).astype(np.float32)
+        raw = (x.view(np.uint32) >> 16).astype(np.uint16).tobytes()          # bf16 bit patterns
+        assert len(raw) == n
+        hdr = bytes(32)
+        frame = simt_lib.compress(hdr, raw, 2, 1, 10, 256 * 1024, 0.95)
+        want = O.compress_frame(hdr, raw, 2, 1, 10, 256 * 1024)
+        assert bytes(frame[32:]) == want[32:]
+        back = simt_lib.decompress(memoryview(frame)[32:], 2, 1, 10, 256 * 1024, n)
+        assert bytes(back) == raw

@@ -4,6 +4,7 @@
 // the one 8-byte read-back of the compressed length.  All data work is in the kernels.
 #include "../../include/zipnn_hip.h"
 #include "zn_internal.hpp"
+#include "zn_host_pipe.hpp"
 
 #include <mutex>
 #include <string>
@@ -36,6 +37,7 @@ struct Workspace {
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
+  ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
 static_assert(WS_COUNT == 12, "Workspace::buf size");
@@ -395,13 +397,15 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
   }
   int rc = ZN_OK; size_t body_len = 0;
   do {
-    if (n && hipMemcpy(d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
-    if (d_delta && hipMemcpy(d_delta, delta, n, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
+    // (pageable host memory through the pinned, multi-threaded pipe of zn_host_pipe.hpp; g_host_mu serialises its use)
+    ZnHostPipe& pipe = g_ws[dev].pipe;
+    if (n && zn_host_pipe_copy(pipe, d_src, const_cast<void*>(src), n, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
+    if (d_delta && zn_host_pipe_copy(pipe, d_delta, const_cast<void*>(delta), n, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
     rc = zn_compress_delta_dev(d_src, d_delta, n, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, bound ? bound : 16, &body_len, nullptr);
     if (rc) break;
     if (hdr_len + body_len > dst_cap) { rc = ZN_E_CAP; break; }
     if (hdr_len) memcpy(dst, hdr, hdr_len);
-    if (body_len && hipMemcpy((uint8_t*)dst + hdr_len, d_body, body_len, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy D2H"; break; }
+    if (body_len && zn_host_pipe_copy(pipe, d_body, (uint8_t*)dst + hdr_len, body_len, false) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe D2H"; break; }
     *dst_len = hdr_len + body_len;
     if (hdr_len >= 32) { const uint64_t total = *dst_len; memcpy((uint8_t*)dst + 24, &total, 8); }   // zipnn_core.c:121
   } while (0);
@@ -434,11 +438,12 @@ int zn_decompress_delta(const void* body, size_t body_len, const void* delta, in
   }
   int rc = ZN_OK;
   do {
-    if (body_len && hipMemcpy(d_body, body, body_len, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
-    if (d_delta && hipMemcpy(d_delta, delta, orig_size, hipMemcpyHostToDevice) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy H2D"; break; }
+    ZnHostPipe& pipe = g_ws[dev].pipe;
+    if (body_len && zn_host_pipe_copy(pipe, d_body, const_cast<void*>(body), body_len, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
+    if (d_delta && zn_host_pipe_copy(pipe, d_delta, const_cast<void*>(delta), orig_size, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
     rc = zn_decompress_delta_dev(d_body, body_len, d_delta, num_buf, bits_mode, bytes_mode, chunk, orig_size, d_dst, nullptr, 1);
     if (rc) break;
-    if (orig_size && hipMemcpy(dst, d_dst, orig_size, hipMemcpyDeviceToHost) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "hipMemcpy D2H"; break; }
+    if (orig_size && zn_host_pipe_copy(pipe, d_dst, dst, orig_size, false) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe D2H"; break; }
   } while (0);
   return rc;
 }
@@ -486,7 +491,7 @@ int zn_release_workspace(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 64; d++) {
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -494,6 +499,7 @@ int zn_release_workspace(void) {
     if (w.h_segs) { (void)hipHostFree(w.h_segs); w.h_segs = nullptr; w.h_segs_cap = 0; }
     if (w.h_totals) { (void)hipHostFree(w.h_totals); w.h_totals = nullptr; w.h_totals_cap = 0; }
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
+    zn_host_pipe_release(w.pipe);
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
   }
   return ZN_OK;

@@ -799,10 +799,11 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     bool ok;
 #define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
+    // (one instance per Huffman plane index that exists for this P — nothing is instantiated twice)
     if (h < 0) ok = zn_fused_wave<P, -1, 0, X>(ZN_WAVE_ARGS);
-    else if (h == 0) ZN_WAVE_CASE(0);
-    else if (P >= 2 && h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
-    else if (P >= 4 && h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
+    else if (P == 1 || h == 0) ZN_WAVE_CASE(0);
+    else if (P == 2 || h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
+    else if (h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
     else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
 #undef ZN_WAVE_CASE
 #undef ZN_WAVE_ARGS

@@ -80,8 +80,7 @@ struct ZnStatsLds {
   // plane, so the low half never carries into the high one.  (P = 1: one plane, plain 32-bit counters.)
   static constexpr int COLS = (P == 4) ? 16 : 32;
   static constexpr int PAIRS = (P + 1) / 2;
-  uint32_t hist[PAIRS][256 * COLS];
-  uint32_t red_mx[P][4], red_hi[P][4];
+  uint32_t hist[PAIRS][256 * COLS];      // 32 KiB for P = 2: five workgroups per CU — the cross-wave reduction below reuses its head
 };
 
 // The chunk is histogrammed quarter by quarter (a quarter = the symbols of one huff0 stream); after each
@@ -145,15 +144,19 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
   ZN_PT(0);   // zero + histograms
 
   // ---- per plane: largest count, highest symbol, and the cheap exits of HUF_compress ----
+  // (the histogram is dead from here on — the last column sum ended with a barrier —: its first 8·P dwords hold the
+  //  per-wave maxima, which keeps the structure at 32 KiB)
+  uint32_t (*red_mx)[4] = (uint32_t (*)[4])&L.hist[0][0];
+  uint32_t (*red_hi)[4] = red_mx + P;
   for (int p = 0; p < P; p++) {
     uint32_t mx = tot[p], hi = tot[p] ? tid : 0u;
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d), h2 = __shfl_xor(hi, d); if (m2 > mx) mx = m2; if (h2 > hi) hi = h2; }
-    if (lane == 0) { L.red_mx[p][wave] = mx; L.red_hi[p][wave] = hi; }
+    if (lane == 0) { red_mx[p][wave] = mx; red_hi[p][wave] = hi; }
   }
   __syncthreads();
   for (int p = 0; p < P; p++) {
     uint32_t mx = 0, hi = 0;
-    for (int w = 0; w < 4; w++) { if (L.red_mx[p][w] > mx) mx = L.red_mx[p][w]; if (L.red_hi[p][w] > hi) hi = L.red_hi[p][w]; }
+    for (int w = 0; w < 4; w++) { if (red_mx[p][w] > mx) mx = red_mx[p][w]; if (red_hi[p][w] > hi) hi = red_hi[p][w]; }
     const uint64_t pc = (uint64_t)p * g.K + c;
     if (mx == n) {                               // RLE: HUF_compress returns 1; threshold rule of compression_worker (zipnn_core.c:371-385)
       const bool keep = 1.0 < (double)n * (double)threshold;
