@@ -140,6 +140,13 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
 int zn_decompress_delta(const void* body, size_t body_len, const void* delta, int num_buf, int bits_mode,
                         int bytes_mode, size_t chunk, size_t orig_size, int device, void* dst);
 
+/* Plumbing for callers that keep the tensors in HBM but hold pageable host buffers (files, Python bytes): the same
+ * pinned, multi-threaded transfer the host-buffer entry points above use internally (zipnn_amd/csrc/zn_host_pipe.hpp),
+ * on the current device; returns when the n bytes have arrived.  No reference counterpart — the reference's buffers
+ * never leave the host (zipnn/zipnn.py:714-725, 1143-1151 hand host pointers straight to the C core). */
+int zn_copy_to_device(void* d_dst, const void* src, size_t n);
+int zn_copy_to_host(void* dst, const void* d_src, size_t n);
+
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);
 

@@ -20,12 +20,16 @@ for name, fn in (("compress", lambda: lib.compress(hdr, x, 2, 1, 10, 262144, 0.9
     print(f"host-buffer {name}: 1 GiB bf16 in {best * 1e3:.1f} ms = {n / best / 1e9:.1f} GB/s (pageable host memory, PCIe both ways; "
           f"{best_free * 1e3:.1f} ms with the result buffer freed again)")
 
-# streaming `.znn` blob (1 MiB frames): per-frame compress loop, batched decompress
+# streaming `.znn` blob (1 MiB frames): batched compress and decompress, best of 3 (the first call of a process also
+# pays for the pinned bounce buffers and the allocator's first 256 MiB blocks)
 from zipnn_amd import ZipNN
 raw = x[: 256 << 20].tobytes()
-zs = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20)
-t0 = time.perf_counter(); blob = zs.compress(raw); t1 = time.perf_counter()
-back = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20).decompress(blob); t2 = time.perf_counter()
-assert bytes(back) == raw
-print(f"streaming 256 MiB in 1 MiB frames: compress {(t1 - t0) * 1e3:.0f} ms = {len(raw) / (t1 - t0) / 1e9:.2f} GB/s (per-frame calls), "
-      f"decompress {(t2 - t1) * 1e3:.0f} ms = {len(raw) / (t2 - t1) / 1e9:.2f} GB/s (one batched launch)")
+bc = bd = 1e9
+for _ in range(3):
+    t0 = time.perf_counter(); blob = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20).compress(raw); t1 = time.perf_counter()
+    back = ZipNN(bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=1 << 20).decompress(blob); t2 = time.perf_counter()
+    bc = min(bc, t1 - t0); bd = min(bd, t2 - t1)
+    assert bytes(back) == raw
+    del back
+print(f"streaming 256 MiB in 1 MiB frames (one batched call each way): compress {bc * 1e3:.0f} ms = {len(raw) / bc / 1e9:.2f} GB/s, "
+      f"decompress {bd * 1e3:.0f} ms = {len(raw) / bd / 1e9:.2f} GB/s")

@@ -78,6 +78,8 @@ class ZnLib:
         L.zn_compress_batch_dev.argtypes = [ctypes.POINTER(ZnCBatchItem), sz, vp]
         L.zn_decompress_batch_dev.restype = ci
         L.zn_decompress_batch_dev.argtypes = [ctypes.POINTER(ZnBatchItem), sz, vp, ci]
+        L.zn_copy_to_device.restype = ci; L.zn_copy_to_device.argtypes = [vp, vp, sz]
+        L.zn_copy_to_host.restype = ci; L.zn_copy_to_host.argtypes = [vp, vp, sz]
         L.zn_release_workspace.restype = ci
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
         L.zn_last_tail_planes.restype = ctypes.c_longlong
@@ -198,6 +200,16 @@ class ZnLib:
         if n < 0:
             self._check(int(n))
         return int(n)
+
+    # -- pageable host buffer <-> device pointer, through the library's pinned multi-threaded pipe --------------
+    def copy_to_device(self, dst_ptr, buf):
+        cb = _as_c_buffer(memoryview(buf).cast("B"))
+        self._check(self._L.zn_copy_to_device(dst_ptr, cb.addr, memoryview(buf).nbytes))
+
+    def copy_to_host(self, buf, src_ptr, n=None):
+        mv = memoryview(buf).cast("B")
+        cb = _as_c_buffer(mv)
+        self._check(self._L.zn_copy_to_host(cb.addr, src_ptr, mv.nbytes if n is None else n))
 
     def release_workspace(self):
         self._check(self._L.zn_release_workspace())

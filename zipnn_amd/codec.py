@@ -19,6 +19,55 @@ def flat_bytes(t):
     return t.reshape(-1).view(torch.uint8)
 
 
+def to_device(lib, buf, dev):
+    """bytes-like (pageable host memory) -> uint8 tensor on `dev`, through the library's pinned, multi-threaded
+    transfer (zn_copy_to_device) instead of a pageable torch copy.  The copy runs on the library's own stream and
+    is complete on return; torch's stream is drained first because the allocator may hand out a block that kernels
+    queued earlier are still using."""
+    mv = memoryview(buf).cast("B")
+    t = torch.empty(mv.nbytes, dtype=torch.uint8, device=dev)
+    if mv.nbytes:
+        if t.is_cuda:
+            with torch.cuda.device(t.device):
+                torch.cuda.current_stream().synchronize()
+                lib.copy_to_device(t.data_ptr(), mv)
+        else:
+            lib.copy_to_device(t.data_ptr(), mv)
+    return t
+
+
+def new_bytearray(n):
+    """bytearray of n bytes WITHOUT the zero fill of bytearray(n) (128 ms for 256 MiB: every page touched by one
+    thread before the data arrives) — the transfer that fills it touches the pages from several threads."""
+    import ctypes
+    try:
+        f = ctypes.pythonapi.PyByteArray_FromStringAndSize
+        f.restype = ctypes.py_object
+        f.argtypes = [ctypes.c_char_p, ctypes.c_ssize_t]
+        ba = f(None, n)
+        if isinstance(ba, bytearray) and len(ba) == n:
+            return ba
+    except Exception:
+        pass
+    return bytearray(n)
+
+
+def to_host(lib, t, out=None):
+    """uint8 tensor (device) -> writable host buffer (a new bytearray unless `out` is given), the same way back."""
+    t = t.contiguous()
+    n = t.numel()
+    if out is None:
+        out = new_bytearray(n)
+    if n:
+        if t.is_cuda:
+            with torch.cuda.device(t.device):
+                torch.cuda.current_stream().synchronize()      # the kernels that produced `t` ran on torch's stream
+                lib.copy_to_host(memoryview(out).cast("B")[:n], t.data_ptr())
+        else:
+            lib.copy_to_host(memoryview(out).cast("B")[:n], t.data_ptr())
+    return out
+
+
 def _stream_handle(t):
     return torch.cuda.current_stream(t.device).cuda_stream if t.is_cuda else 0
 
@@ -51,11 +100,12 @@ def compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold,
 def compress_device_to_frame(lib, header, flat, num_buf, bits_mode, bytes_mode, chunk, threshold):
     """Device tensor -> host frame bytes (header ‖ body); only compressed bytes cross PCIe."""
     body = compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold)
-    frame = bytearray(header)
-    total = len(frame) + body.numel()
-    if len(frame) >= 32:
-        frame[24:32] = total.to_bytes(8, "little")   # what the reference core writes at zipnn_core.c:121
-    frame += body.cpu().numpy().tobytes()
+    hl = len(header)
+    frame = new_bytearray(hl + body.numel())
+    frame[:hl] = header
+    if hl >= 32:
+        frame[24:32] = len(frame).to_bytes(8, "little")   # what the reference core writes at zipnn_core.c:121
+    to_host(lib, body, memoryview(frame)[hl:])
     return frame
 
 

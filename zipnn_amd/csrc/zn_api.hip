@@ -487,6 +487,22 @@ long long zn_last_tail_planes(void) {
   } catch (...) { return ZN_E_ALLOC; }
 }
 
+static int zn_copy_host(void* d, void* h, size_t n, bool to_device) {
+  if (n == 0) return ZN_OK;
+  if (!d || !h) return ZN_E_ARG;
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> hk(g_host_mu[dev]);        // one user of the device's bounce buffers at a time
+  try {
+    if (zn_host_pipe_copy(g_ws[dev].pipe, d, h, n, to_device) != hipSuccess) { t_hip_err = to_device ? "host pipe H2D" : "host pipe D2H"; (void)hipGetLastError(); return ZN_E_HIP; }
+  } catch (...) { return ZN_E_ALLOC; }
+  return ZN_OK;
+}
+int zn_copy_to_device(void* d_dst, const void* src, size_t n) { return zn_copy_host(d_dst, const_cast<void*>(src), n, true); }
+int zn_copy_to_host(void* dst, const void* d_src, size_t n) { return zn_copy_host(const_cast<void*>(d_src), dst, n, false); }
+
 int zn_release_workspace(void) {
   std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 64; d++) {

@@ -50,9 +50,10 @@ def compress_safetensors_file(filename, out_path=None, device="cpu", method=None
             if total >= t.element_size() * t.nelement():
                 tensors[name] = t.cpu()
                 continue
-            frame = bytearray(hdr)
+            frame = codec.new_bytearray(total)
+            frame[:len(hdr)] = hdr
             frame[24:32] = total.to_bytes(8, "little")     # what the core writes at zipnn_core.c:121
-            frame += body.cpu().numpy().tobytes()
+            codec.to_host(_capi.lib(), body, memoryview(frame)[len(hdr):])
             tensors[name] = torch.frombuffer(frame, dtype=COMPRESSED_DTYPE)
             infos[name] = build_compressed_tensor_info(t)
     if not metadata:
@@ -101,7 +102,10 @@ def load_file(filename, device="cuda:0"):
                 continue
             znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
             fp = znn.frame_params(t)
-            body = t.reshape(-1).view(torch.uint8)[fp["body_off"]:].to(dev, non_blocking=True)
+            host_body = t.reshape(-1).view(torch.uint8)[fp["body_off"]:]
+            # (large bodies through the library's pinned multi-threaded transfer; small ones are not worth its threads)
+            body = codec.to_device(_capi.lib(), host_body.numpy(), dev) if host_body.numel() >= (2 << 20) and dev.type == "cuda" \
+                else host_body.to(dev, non_blocking=True)
             items.append((body, fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"]))
             meta.append((name, fp["torch_dtype"], fp["shape"]))
     flats = codec.decompress_device_batch(_capi.lib(), items)

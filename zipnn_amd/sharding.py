@@ -96,7 +96,7 @@ def decompress_replicated(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig
     lo, hi = ranges[rank]
     if hi > lo:
         sub, off, length = split_body(body, num_buf, chunk, orig_size, world, ranges)[rank]
-        sub_t = torch.frombuffer(bytearray(sub), dtype=torch.uint8).to(device, non_blocking=True)
+        sub_t = codec.to_device(lib, sub, device)          # (the library's pinned multi-threaded transfer)
         codec.decompress_device(lib, sub_t, num_buf, bits_mode, bytes_mode, chunk, length, out=full[off:off + length])
     if world > 1:
         mine = full[rank * shard:(rank + 1) * shard].clone()            # (gloo does not take an aliasing input)

@@ -221,26 +221,25 @@ class ZipNN:
         h[5], h[6], h[15] = dt.byte_mode, dt.rotate, dt.code
         chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
         dev = torch.device("cuda", codec.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")      # (read-only input buffers: we only read them)
-            flat = torch.frombuffer(mv, dtype=torch.uint8).to(dev, non_blocking=True)
-            base = torch.frombuffer(mvd[:mv.nbytes], dtype=torch.uint8).to(dev, non_blocking=True) if mvd is not None else None
+        flat = codec.to_device(_capi.lib(), mv, dev)
+        base = codec.to_device(_capi.lib(), mvd[:mv.nbytes], dev) if mvd is not None else None
         offs = range(0, mv.nbytes, self.streaming_chunk)
         pieces = [flat[off:off + self.streaming_chunk] for off in offs]
         bases = [base[off:off + self.streaming_chunk] if base is not None else None for off in offs]   # XOR fused on the device
         bodies = codec.compress_device_batch(_capi.lib(), [(p, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold, b)
                                                            for p, b in zip(pieces, bases)])
-        payload = (torch.cat(bodies) if len(bodies) > 1 else bodies[0]).cpu().numpy()
-        out = bytearray()
-        o = 0
-        for p, b in zip(pieces, bodies):
+        # frames assembled on the device (header ‖ body, back to back), one transfer back
+        sizes = [b.numel() for b in bodies]
+        total = sum(sizes) + HEADER_LEN * len(bodies)
+        heads = bytearray()
+        for p, nb in zip(pieces, sizes):
             h[16:24] = p.numel().to_bytes(8, "little")
-            h[24:32] = (HEADER_LEN + b.numel()).to_bytes(8, "little")     # what the core writes at zipnn_core.c:121
-            out += bytes(h)
-            out += payload[o:o + b.numel()].tobytes()
-            o += b.numel()
-        return out
+            h[24:32] = (HEADER_LEN + nb).to_bytes(8, "little")           # what the core writes at zipnn_core.c:121
+            heads += h
+        heads_t = codec.to_device(_capi.lib(), heads, dev).view(len(bodies), HEADER_LEN)
+        blob = torch.cat([x for i, b in enumerate(bodies) for x in (heads_t[i], b)])
+        assert blob.numel() == total
+        return codec.to_host(_capi.lib(), blob)
 
     def torch_frame_plan(self, t):
         """Header and core parameters for compressing torch tensor `t` (no data work): (header bytes incl. the shape
@@ -388,16 +387,13 @@ class ZipNN:
             return None
         n_out = sum(fp["orig_size"] for (_, _, fp) in frames)
         dev = torch.device("cuda", codec.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")      # (read-only input buffers: we only read them)
-            blob = torch.frombuffer(mv, dtype=torch.uint8).to(dev, non_blocking=True)
-            base = None
-            if delta_second_data:
-                mvd = memoryview(delta_second_data).cast("B")
-                if mvd.nbytes != n_out:
-                    raise ValueError("Length of delta file has to match the length of the decompressed file.")
-                base = torch.frombuffer(mvd, dtype=torch.uint8).to(dev, non_blocking=True) if n_out else None
+        blob = codec.to_device(_capi.lib(), mv, dev)
+        base = None
+        if delta_second_data:
+            mvd = memoryview(delta_second_data).cast("B")
+            if mvd.nbytes != n_out:
+                raise ValueError("Length of delta file has to match the length of the decompressed file.")
+            base = codec.to_device(_capi.lib(), mvd, dev) if n_out else None
         flat = torch.empty(n_out, dtype=torch.uint8, device=dev)
         items, o = [], 0
         for (b0, b1, fp) in frames:                  # frame i's slice of the second buffer: XOR fused on the device
@@ -406,10 +402,7 @@ class ZipNN:
                           base[o:o + n] if base is not None else None))
             o += n
         codec.decompress_device_batch(_capi.lib(), items, into=flat)
-        out = bytearray(n_out)
-        if n_out:
-            torch.frombuffer(out, dtype=torch.uint8).copy_(flat)
-        return out
+        return codec.to_host(_capi.lib(), flat)
 
     def frame_params(self, frame):
         """Parse one frame's header -> what the C ABI needs to decode its body (no data work):
@@ -440,8 +433,7 @@ class ZipNN:
             if isinstance(frame, torch.Tensor):
                 body = frame.reshape(-1).view(torch.uint8)[body_off:].to(dev, non_blocking=True)
             else:
-                body = torch.frombuffer(bytearray(memoryview(frame)[body_off:]), dtype=torch.uint8).to(dev) \
-                    if len(frame) > body_off else torch.empty(0, dtype=torch.uint8, device=dev)
+                body = codec.to_device(lib, memoryview(frame)[body_off:], dev)
             flat = codec.decompress_device(lib, body, dt.planes, self._bit_reorder, self._byte_reorder, chunk,
                                            self.original_len)
             return flat.view(dt.torch).reshape(self.shape_bytes)
