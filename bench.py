@@ -87,8 +87,10 @@ def cpu_baseline(sample_u8, want_body):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: the clocks need ~12 launches (≈25 ms) of this kernel to settle after anything else has run
+    # (profiles/r01z2_launch_time_ramp.txt: 2.2 → 1.76 ms per launch), so the default warm-up covers that
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gib", type=float, default=4.0, help="uncompressed tensor size per GPU (GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)

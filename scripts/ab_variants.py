@@ -39,6 +39,8 @@ VARIANTS = {
     "noraw": (None, ["-DZN_F_ABLATE=32"]),
     "nowrite": (None, ["-DZN_F_ABLATE=64"]),
     "nomem": (None, ["-DZN_F_ABLATE=48"]),
+    "r3k": (None, ["-DZN_F_RING_BYTES=3072u", "-DZN_F_DCONST=3"]),          # odd sub-block stride: conflict-free stream-tile reads
+    "r3k5": (None, ["-DZN_F_RING_BYTES=3584u", "-DZN_F_DCONST=3"]),
     "d12": (None, ["-DZN_F_DELTA0=12"]),
     "d20": (None, ["-DZN_F_DELTA0=20"]),
 }

@@ -431,7 +431,11 @@ class ZipNN:
             # device-resident result: only compressed bytes cross PCIe
             dev = target if target is not None else frame.device
             if isinstance(frame, torch.Tensor):
-                body = frame.reshape(-1).view(torch.uint8)[body_off:].to(dev, non_blocking=True)
+                body = frame.reshape(-1).view(torch.uint8)[body_off:]
+                if not body.is_cuda and torch.device(dev).type == "cuda" and body.numel() >= (2 << 20):
+                    body = codec.to_device(lib, body.contiguous().numpy(), dev)     # (pinned multi-threaded transfer)
+                else:
+                    body = body.to(dev, non_blocking=True)
             else:
                 body = codec.to_device(lib, memoryview(frame)[body_off:], dev)
             flat = codec.decompress_device(lib, body, dt.planes, self._bit_reorder, self._byte_reorder, chunk,
