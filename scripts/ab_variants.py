@@ -29,7 +29,8 @@ VARIANTS = {
     "r01z": ("5886209", []),                        # the kernels the round-1 profiles were taken from
     "c1": ("HEAD", []),                             # the last commit
     "new": (None, []),
-    "late": (None, ["-DZN_F_EARLY_STAGE=0"]),       # tile staging back at the top of the loop
+    "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
+    "nopad16": (None, ["-DZN_F_L16_PAD=0"]),       # tile staging back at the top of the loop
     "x2lut": (None, ["-DZN_F_ABLATE=1"]),
     "x2sync": (None, ["-DZN_F_ABLATE=2"]),
     "x2count": (None, ["-DZN_F_ABLATE=4"]),

@@ -445,3 +445,29 @@ def test_replicated_decode_single_rank(lib):
     body = O.compress_frame(b"", d, 2, 1, 10, C, threads=4)
     out = sharding.decompress_replicated(lib, body, 2, 1, 10, C, nb, torch.device("cuda:0"))
     assert out.cpu().numpy().tobytes() == d
+
+
+@pytest.mark.gpu
+def test_pinned_host_pipe_copies_and_host_entry_points(lib, monkeypatch):
+    """zn_copy_to_device / zn_copy_to_host (the pinned, multi-threaded transfer of zn_host_pipe.hpp) move pageable
+    buffers bit-exactly for sizes around its slice and stripe boundaries, with several thread counts; the
+    host-buffer entry points built on it return the oracle's frame and the original bytes."""
+    from zipnn_amd import codec
+    rng = np.random.default_rng(11)
+    for n, threads, slice_mb in ((1, "8", None), (3 * 1024 * 1024 + 5, "3", None), (70 * 1024 * 1024 + 123, "8", None),
+                                 (33 * 1024 * 1024 + 64, "16", None)):
+        monkeypatch.setenv("ZN_HOST_THREADS", threads)
+        host = rng.integers(0, 256, n, dtype=np.uint8)
+        t = codec.to_device(lib, host, torch.device("cuda:0"))
+        assert t.is_cuda and t.numel() == n and np.array_equal(t.cpu().numpy(), host)
+        t2 = (t ^ 0x5A).contiguous()
+        back = codec.to_host(lib, t2)
+        assert isinstance(back, bytearray) and np.array_equal(np.frombuffer(back, dtype=np.uint8), host ^ 0x5A)
+    # host-buffer entry points, 40 MiB + a ragged tail (several slices each way)
+    n = 40 * 1024 * 1024 + 4098
+    x = (torch.randn(n // 2, generator=torch.Generator().manual_seed(3)) * 0.02).to(torch.bfloat16)
+    raw = x.view(torch.uint8).numpy().tobytes()
+    frame = lib.compress(bytes(32), raw, 2, 1, 10, 256 * 1024, 0.95)
+    want = O.compress_frame(bytes(32), raw, 2, 1, 10, 256 * 1024)
+    assert bytes(frame[32:]) == want[32:]
+    assert bytes(lib.decompress(memoryview(frame)[32:], 2, 1, 10, 256 * 1024, n)) == raw

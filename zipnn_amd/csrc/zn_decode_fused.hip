@@ -57,6 +57,17 @@
 #endif
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #define ZN_F_TLMAX 11u
+// the 16-bit single-symbol table (scratch of the LUT build, aliased into the idle staging buffers 0 and 1): one
+// dword of padding per 32 — the build reads it at (u << pos) & mask, power-of-two strides across the lanes that
+// would otherwise pile 16 or 32 lanes onto one bank
+#ifndef ZN_F_L16_PAD
+#define ZN_F_L16_PAD 1
+#endif
+#if ZN_F_L16_PAD
+#define ZN_L16(i) ((i) + (((i) >> 6) << 1))
+#else
+#define ZN_L16(i) (i)
+#endif
 #ifndef ZN_F_ABLATE
 #define ZN_F_ABLATE 0                    // developer builds (scripts/ab_variants.py): repeat a phase (results unchanged) to price it on the device: 1 LUT fill, 2 sync run-in, 4 count pass, 8 write pass, 256 tree description; or drop one (timing only, wrong output): 16 output stores, 32 raw-plane loads, 64 write pass
 #endif
@@ -216,7 +227,7 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
   uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
   {
     const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
-    for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[u] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
+    for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[ZN_L16(u)] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
   }
   __syncthreads();
   {
@@ -228,7 +239,7 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
       for (int k = 0; k < 8; k++) {
         const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
         if (u <= mask && cnt[k] == (uint32_t)step) {
-          const uint32_t e = lut16[(u << pos[k]) & mask]; const uint32_t len = e >> 8;
+          const uint32_t e = lut16[ZN_L16((u << pos[k]) & mask)]; const uint32_t len = e >> 8;
           if (pos[k] + len <= TL) {             // the window holds this code completely
             if (step > 0) ef[k] |= pos[k] << (4 * (step - 1));          // E_step = where this symbol starts
             if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
