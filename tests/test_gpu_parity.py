@@ -471,3 +471,31 @@ def test_pinned_host_pipe_copies_and_host_entry_points(lib, monkeypatch):
     want = O.compress_frame(bytes(32), raw, 2, 1, 10, 256 * 1024)
     assert bytes(frame[32:]) == want[32:]
     assert bytes(lib.decompress(memoryview(frame)[32:], 2, 1, 10, 256 * 1024, n)) == raw
+
+
+@pytest.mark.gpu
+def test_host_entry_points_from_concurrent_threads(lib):
+    """Two Python threads call the host-buffer entry points at once (ctypes releases the GIL): the calls serialise on
+    the device's staging buffers and both return the right bytes."""
+    import threading
+    n = 24 * 1024 * 1024
+    raws, frames, errs = [], [None, None], []
+    for seed in (1, 2):
+        x = (torch.randn(n // 2, generator=torch.Generator().manual_seed(seed)) * 0.02).to(torch.bfloat16)
+        raws.append(x.view(torch.uint8).numpy().tobytes())
+
+    def work(i):
+        try:
+            for _ in range(3):
+                f = lib.compress(bytes(32), raws[i], 2, 1, 10, 256 * 1024, 0.95)
+                back = lib.decompress(memoryview(f)[32:], 2, 1, 10, 256 * 1024, n)
+                assert bytes(back) == raws[i]
+            frames[i] = bytes(f)
+        except Exception as e:          # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    for i in range(2):
+        assert frames[i][32:] == O.compress_frame(bytes(32), raws[i], 2, 1, 10, 256 * 1024)[32:]

@@ -504,8 +504,10 @@ int zn_copy_to_device(void* d_dst, const void* src, size_t n) { return zn_copy_h
 int zn_copy_to_host(void* dst, const void* d_src, size_t n) { return zn_copy_host(const_cast<void*>(d_src), dst, n, false); }
 
 int zn_release_workspace(void) {
-  std::lock_guard<std::mutex> lk(g_mu);
   for (int d = 0; d < 64; d++) {
+    // same order as the host-buffer entry points: the device's host lock (its bounce buffers may be in use), then the table
+    std::lock_guard<std::mutex> hk(g_host_mu[d]);
+    std::lock_guard<std::mutex> lk(g_mu);
     Workspace& w = g_ws[d];
     bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
