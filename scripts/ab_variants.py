@@ -30,7 +30,8 @@ VARIANTS = {
     "c1": ("HEAD", []),                             # the last commit
     "new": (None, []),
     "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
-    "nopad16": (None, ["-DZN_F_L16_PAD=0"]),       # tile staging back at the top of the loop
+    "nopad16": (None, ["-DZN_F_L16_PAD=0"]),
+    "prio0": (None, ["-DZN_F_PRIO_PASS=0"]),
     "x2lut": (None, ["-DZN_F_ABLATE=1"]),
     "x2sync": (None, ["-DZN_F_ABLATE=2"]),
     "x2count": (None, ["-DZN_F_ABLATE=4"]),
