@@ -68,16 +68,23 @@
 #else
 #define ZN_L16(i) (i)
 #endif
-// wave priority (s_setprio) of the sync / count / write passes; everything else runs at 0.  The passes are chains of
-// dependent LDS look-ups: issuing their next instruction first, ahead of the flush / table-build code of the other
-// waves on the SIMD, measured +1.6 % (raising the flush or the table build instead: less or nothing)
-#ifndef ZN_F_PRIO_PASS
-#define ZN_F_PRIO_PASS 3
+// wave priority (s_setprio) by phase: it rises with the progress through a tile — sync run-in 1, count pass 2, write
+// pass 3, everything else (flush, staging, table build) 0.  The passes are chains of dependent LDS look-ups: their next
+// instruction issues ahead of the other waves' flush / table-build code, and a wave that is further along goes first.
+// Measured: all three passes at 3: +1.6 % over no priorities; graded like this: another +1 % (bf16; fp16 +3 %).
+#ifndef ZN_F_PRIO_SYNC
+#define ZN_F_PRIO_SYNC 1
 #endif
-#if ZN_F_PRIO_PASS && !defined(ZN_SIMT_EMULATOR)
-#define ZN_PRIO_PASS(on) __builtin_amdgcn_s_setprio((on) ? ZN_F_PRIO_PASS : 0)
+#ifndef ZN_F_PRIO_COUNT
+#define ZN_F_PRIO_COUNT 2
+#endif
+#ifndef ZN_F_PRIO_WRITE
+#define ZN_F_PRIO_WRITE 3
+#endif
+#if (ZN_F_PRIO_SYNC || ZN_F_PRIO_COUNT || ZN_F_PRIO_WRITE) && !defined(ZN_SIMT_EMULATOR)
+#define ZN_PRIO(v) __builtin_amdgcn_s_setprio(v)
 #else
-#define ZN_PRIO_PASS(on) do { } while (0)
+#define ZN_PRIO(v) do { } while (0)
 #endif
 #ifndef ZN_F_ABLATE
 #define ZN_F_ABLATE 0                    // developer builds (scripts/ab_variants.py): repeat a phase (results unchanged) to price it on the device: 1 LUT fill, 2 sync run-in, 4 count pass, 8 write pass, 256 tree description; or drop one (timing only, wrong output): 16 output stores, 32 raw-plane loads, 64 write pass
@@ -472,12 +479,13 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         zn_fused_run<0>(lut32, in, base_bit, TL, c, nullptr);
       }
     };
-    ZN_PRIO_PASS(1);
+    ZN_PRIO(ZN_F_PRIO_SYNC);
     sync_run(A);
 #if ZN_F_ABLATE & 2
     { ZnChain B; sync_run(B); uint32_t t_ = (uint32_t)B.pos; ZN_OPAQUE32(t_); }
 #endif
     int32_t s = (lane > 0) ? A.pos : carry;
+    ZN_PRIO(ZN_F_PRIO_COUNT);
     ZN_PT(5);   // sync run-in
 
     // count, and verify that the 64 sub-blocks form one consistent chain below the true start of the first
@@ -528,7 +536,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       fetch_rows(JF, first);
       ZN_PT(8);   // scans / shuffles / issue loads
 
-      ZN_PRIO_PASS(1);
+      ZN_PRIO(ZN_F_PRIO_WRITE);
       const bool mine = active && lane >= lane_lo && lane < lane_hi;
       A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
 #if ZN_F_ABLATE & 8
@@ -538,7 +546,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
 #endif
       __builtin_amdgcn_wave_barrier();
-      ZN_PRIO_PASS(0);
+      ZN_PRIO(0);
       ZN_PT(9);   // write pass
       J += nsub; wdone = wend; lane_lo = lane_hi;
 
@@ -566,7 +574,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     if (!ok) break;
     ZN_PT(3);   // flush rows
   }
-  ZN_PRIO_PASS(0);                            // (an error exit leaves the loop from inside a pass)
+  ZN_PRIO(0);                                 // (an error exit leaves the loop from inside a pass)
   if (ragged && ok && carry == b0 && J == seg && JF < seg) {
     // a stream of a partial chunk: the last row is incomplete — store it whole (the destination is padded)
     emit_rows(JF, 1, 0, [] {}); JF += UNIT;
