@@ -58,20 +58,6 @@ inline void stripe(size_t len, unsigned w, unsigned t, size_t* lo, size_t* hi) {
 
 }  // namespace zn_host_pipe_detail
 
-inline hipError_t zn_host_pipe_init(ZnHostPipe& p) {
-  if (p.pin[0]) return hipSuccess;
-  size_t slice = 32u << 20;
-  if (const char* e_ = getenv("ZN_HOST_SLICE_MB")) { const int v = atoi(e_); if (v >= 1 && v <= 256) slice = (size_t)v << 20; }   // tuning knob
-  hipError_t e;
-  for (int i = 0; i < 2; i++) {
-    if ((e = hipHostMalloc(&p.pin[i], slice, hipHostMallocDefault)) != hipSuccess) return e;
-    if ((e = hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming)) != hipSuccess) return e;
-  }
-  if ((e = hipStreamCreateWithFlags(&p.stream, 0)) != hipSuccess) return e;     // blocking: ordered against the null stream
-  p.slice = slice;
-  return hipSuccess;
-}
-
 inline void zn_host_pipe_release(ZnHostPipe& p) {
   for (int i = 0; i < 2; i++) {
     if (p.pin[i]) { (void)hipHostFree(p.pin[i]); p.pin[i] = nullptr; }
@@ -81,13 +67,29 @@ inline void zn_host_pipe_release(ZnHostPipe& p) {
   p.slice = 0;
 }
 
+inline hipError_t zn_host_pipe_init(ZnHostPipe& p) {
+  if (p.pin[0]) return hipSuccess;
+  size_t slice = 32u << 20;
+  if (const char* e_ = getenv("ZN_HOST_SLICE_MB")) { const int v = atoi(e_); if (v >= 1 && v <= 256) slice = (size_t)v << 20; }   // tuning knob
+  hipError_t e = hipSuccess;
+  for (int i = 0; i < 2 && e == hipSuccess; i++) {
+    e = hipHostMalloc(&p.pin[i], slice, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming);
+  }
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, 0);     // blocking: ordered against the null stream
+  if (e != hipSuccess) { zn_host_pipe_release(p); (void)hipGetLastError(); return e; }   // all or nothing
+  p.slice = slice;
+  return hipSuccess;
+}
+
 // to_device: host `h` -> device `d`; else device `d` -> host `h`.  Returns when the transfer is complete.
 inline hipError_t zn_host_pipe_copy(ZnHostPipe& p, void* d, void* h, size_t n, bool to_device) {
   using namespace zn_host_pipe_detail;
   if (n == 0) return hipSuccess;
   if (n < (2u << 20)) return to_device ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
   hipError_t e = zn_host_pipe_init(p);
-  if (e != hipSuccess) return e;
+  if (e != hipSuccess)                          // no pinned memory to be had: the plain, slower way
+    return to_device ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
   const size_t S = p.slice, slices = (n + S - 1) / S;
   const unsigned T = worker_count(n);
   Barrier go(T + 1), done(T + 1);
