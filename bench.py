@@ -3,6 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
+Before the W warm-up steps the decode is launched `--settle-launches` times (default 16, untimed, reported on the
+JSON line): after idle or other kernels the clocks need ~12 launches (25 ms) of this kernel to settle
+(profiles/r01z2_launch_time_ramp.txt); every timed step is a full step either way.
+
 One "step" = one pass of the decompress hot path over one batch: a 4 GiB synthetic bf16
 tensor (BASELINE.json configs[1]; N(0, 0.02) like model weights, generated on the device,
 2 147 483 648 elements, 16 384 chunks of 256 KiB), compressed body already resident in HBM
@@ -91,6 +95,9 @@ def main():
     # (profiles/r01z2_launch_time_ramp.txt: 2.2 → 1.76 ms per launch), so the default warm-up covers that
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-launches", type=int, default=16,
+                    help="untimed decode launches before the W warm-up steps: the GPU's clocks take ~12 launches (25 ms) of this "
+                         "kernel to settle after idle or other kernels; reported on the JSON line (0 = off)")
     ap.add_argument("--gib", type=float, default=4.0, help="uncompressed tensor size per GPU (GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
@@ -126,7 +133,9 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    # ---- decompress: W warm-up + exactly K timed steps --------------------------------
+    # ---- decompress: clock settle + W warm-up + exactly K timed steps ------------------
+    for _ in range(max(0, args.settle_launches)):
+        codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n_bytes, out=out, check=False)
     for _ in range(args.warmup):
         codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n_bytes, out=out, check=False)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -175,6 +184,7 @@ def main():
         line = {
             "metric": "bf16 decompress GB/s (uncompressed bytes / s; compress GB/s beside it)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "settle_launches": max(0, args.settle_launches),
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{n_bytes / (1 << 30):g} GiB synthetic bf16 N(0,0.02) tensor per GPU, 256 KiB chunks, "
