@@ -24,7 +24,11 @@
 //      exactly those rows are requested from HBM before the write pass and consumed after it: staging
 //      bytes + raw bytes get the sign-bit rotate undone at plane level, are byte-interleaved with
 //      v_perm_b32 and go out as coalesced 16-byte stores.  The next tile of the stream is prefetched
-//      into registers the same way.  Decoded symbols never touch HBM; the float stream is written once.
+//      into registers the same way and copied into its LDS buffer inside this flush — behind the flush's one
+//      wait, ahead of its stores — so that no wave ever waits for a store to be acknowledged (gfx9 counts loads
+//      and stores on one in-order counter).  Decoded symbols never touch HBM; the float stream is written once.
+//   4. wave priorities (s_setprio) rise with the progress through a tile: sync 1, count 2, write 3, the rest 0 —
+//      the passes are chains of dependent LDS look-ups and should issue ahead of the other waves' flush code.
 //
 // A launch decodes one tensor or a batch (segment table, zn_internal.hpp); the Huffman planes of partial
 // last chunks are decoded by extra workgroups at the front of the same grid (zn_decode_tail_wg).
