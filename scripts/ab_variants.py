@@ -31,6 +31,8 @@ VARIANTS = {
     "new": (None, []),
     "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
     "nopad16": (None, ["-DZN_F_L16_PAD=0"]),
+    "rb4_3": (None, ["-DZN_F_RB4=3"]),              # fp32: rows per flush batch (default 2)
+    "rb4_4": (None, ["-DZN_F_RB4=4"]),
     "prio0": (None, ["-DZN_F_PRIO_SYNC=0", "-DZN_F_PRIO_COUNT=0", "-DZN_F_PRIO_WRITE=0"]),
     "prio333": (None, ["-DZN_F_PRIO_SYNC=3", "-DZN_F_PRIO_COUNT=3", "-DZN_F_PRIO_WRITE=3"]),
     "x2lut": (None, ["-DZN_F_ABLATE=1"]),
@@ -90,11 +92,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01z", "c1", "new", "late", "prio0")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01z", "c1", "new", "late", "prio0")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01z", "c1", "new", "late", "prio0"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4")),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4")),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4"))]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01z", "c1", "new", "late", "prio0")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4")))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:
