@@ -26,28 +26,29 @@ PKG = os.path.join(ROOT, "zipnn_amd")
 
 # name -> (commit or None, [flags])
 VARIANTS = {
-    "r01z": ("5886209", []),                        # the kernels the round-1 profiles were taken from
+    "r01": ("fb215d2", []),                         # the kernels of the round-1 final state
     "c1": ("HEAD", []),                             # the last commit
     "new": (None, []),
     "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
-    "nopad16": (None, ["-DZN_F_L16_PAD=0"]),
-    "rb4_3": (None, ["-DZN_F_RB4=3"]),              # fp32: rows per flush batch (default 2)
-    "rb4_4": (None, ["-DZN_F_RB4=4"]),
     "prio0": (None, ["-DZN_F_PRIO_SYNC=0", "-DZN_F_PRIO_COUNT=0", "-DZN_F_PRIO_WRITE=0"]),
-    "prio333": (None, ["-DZN_F_PRIO_SYNC=3", "-DZN_F_PRIO_COUNT=3", "-DZN_F_PRIO_WRITE=3"]),
-    "x2lut": (None, ["-DZN_F_ABLATE=1"]),
-    "x2sync": (None, ["-DZN_F_ABLATE=2"]),
-    "x2count": (None, ["-DZN_F_ABLATE=4"]),
-    "x2write": (None, ["-DZN_F_ABLATE=8"]),
-    "x2tree": (None, ["-DZN_F_ABLATE=256"]),
-    "nostore": (None, ["-DZN_F_ABLATE=16"]),
-    "noraw": (None, ["-DZN_F_ABLATE=32"]),
-    "nowrite": (None, ["-DZN_F_ABLATE=64"]),
-    "nomem": (None, ["-DZN_F_ABLATE=48"]),
-    "r3k": (None, ["-DZN_F_RING_BYTES=3072u", "-DZN_F_DCONST=3"]),          # odd sub-block stride: conflict-free stream-tile reads
-    "r3k5": (None, ["-DZN_F_RING_BYTES=3584u", "-DZN_F_DCONST=3"]),
-    "d12": (None, ["-DZN_F_DELTA0=12"]),
-    "d20": (None, ["-DZN_F_DELTA0=20"]),
+    "fip2": (None, ["-DZN_F_FETCH_IN_PASS2=1"]),
+    "nopass2": (None, ["-DZN_F_ABL=1"]),
+    "noraw": (None, ["-DZN_F_ABL=2"]),
+    "nostore": (None, ["-DZN_F_ABL=4"]),
+    "nomem": (None, ["-DZN_F_ABL=6"]),
+    "nofix": (None, ["-DZN_F_ABL=8"]),
+    "nolut": (None, ["-DZN_F_ABL=16"]),
+    "nop2mem": (None, ["-DZN_F_ABL=7"]),
+    "noall": (None, ["-DZN_F_ABL=31"]),
+    "nofence": (None, ["-DZN_F_NO_SCHED_FENCE"]),
+    "w3": (None, ["-DZN_F_WAVES_PER_SIMD=3"]),      # 3 waves per SIMD: 168 VGPRs
+    "w2": (None, ["-DZN_F_WAVES_PER_SIMD=2"]),
+    "tf15": (None, ["-DZN_F_TF(D)=((D)*4-1)"]),     # record slots for whole-group steps (default 4 D + 1)
+    "tf19": (None, ["-DZN_F_TF(D)=((D)*4+3)"]),
+    "d21": (None, ["-DZN_F_DELTA0=21"]),
+    "d32": (None, ["-DZN_F_DELTA0=32"]),
+    "p2m1": (None, ["-DZN_F_P2_MASK=1"]),
+    "p2m2": (None, ["-DZN_F_P2_MASK=2"]),
 }
 
 
@@ -92,11 +93,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "new")),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "new")),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "new"))]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01z", "c1", "new", "late", "prio0", "rb4_3", "rb4_4")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "new")))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:

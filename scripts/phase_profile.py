@@ -16,7 +16,7 @@ from zipnn_amd import _capi, codec   # noqa: E402
 from zipnn_amd.build import hipcc_path, sources   # noqa: E402
 
 NAMES = {0: "metadata", 1: "tree description (serial)", 2: "LUT fill", 3: "flush rows", 4: "stage tile", 5: "sync run-in",
-         6: "count pass", 7: "fix-up passes", 8: "scan/shuffles", 9: "write pass"}
+         6: "decode pass", 7: "fix-up passes", 8: "scan/shuffles", 9: "compaction / write pass"}
 
 
 def main():
@@ -53,7 +53,7 @@ def main():
     print(f"  (in flush) wait for fetched rows {acc[10] / chunks:10.0f} cyc/chunk")
     print(f"  wait for slowest wave at chunk start {acc[21] / chunks:10.0f} cyc/chunk")
     print(f"  tiles/chunk(wave0) {acc[18] / chunks:.2f}  fix-up iterations/tile {acc[16] / max(acc[18], 1):.3f}  "
-          f"mismatching lanes/tile {acc[17] / max(acc[18], 1):.3f}")
+          f"mismatching lanes/tile {acc[17] / max(acc[18], 1):.3f}  tiles in the looping form {acc[22] / max(acc[18], 1):.3f}")
     # encoder statistics kernel
     raw.zn_debug_phase_read_enc(acc, 1)
     codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)

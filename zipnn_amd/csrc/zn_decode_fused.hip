@@ -60,6 +60,9 @@
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
+#ifndef ZN_F_TF
+#define ZN_F_TF(D) ((D) * 4 + 1)         // whole-group step slots of the register-resident decode for a sub-block of D dwords
+#endif
 #define ZN_F_TLMAX 11u
 // the 16-bit single-symbol table (scratch of the LUT build, aliased into the idle staging buffers 0 and 1): one
 // dword of padding per 32 — the build reads it at (u << pos) & mask, power-of-two strides across the lanes that
@@ -90,9 +93,6 @@
 #else
 #define ZN_PRIO(v) do { } while (0)
 #endif
-#ifndef ZN_F_ABLATE
-#define ZN_F_ABLATE 0                    // developer builds (scripts/ab_variants.py): repeat a phase (results unchanged) to price it on the device: 1 LUT fill, 2 sync run-in, 4 count pass, 8 write pass, 256 tree description; or drop one (timing only, wrong output): 16 output stores, 32 raw-plane loads, 64 write pass
-#endif
 #if !defined(ZN_SIMT_EMULATOR)
 #define ZN_OPAQUE32(x) asm volatile("" : "+v"(x))
 // (a & mask) | (b & ~mask) as ONE v_bfi_b32: left to itself the compiler simplifies the masked shift first and
@@ -102,16 +102,31 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
 }
 #define ZN_BFI(mask, a, b) zn_bfi_((mask), (a), (b))
 #define ZN_NO_IFCVT asm volatile("")     // keeps a rarely-taken block a real (scalar) branch
+#define ZN_ASM_MARK(txt) asm volatile("; " txt)   // a comment in the ISA listing (scripts/hot_spills.py looks for spills between the marks)
 #else
 #define ZN_NO_IFCVT ((void)0)
+#define ZN_ASM_MARK(txt) ((void)0)
 #define ZN_OPAQUE32(x) ((void)0)
 #define ZN_BFI(mask, a, b) ((((uint32_t)(a)) & (uint32_t)(mask)) | (((uint32_t)(b)) & ~(uint32_t)(mask)))
+#endif
+#ifndef ZN_F_ABL
+#define ZN_F_ABL 0                       // developer builds (scripts/ab_variants.py), timing only, WRONG output: drop a phase to price it on the device — 1 compaction, 2 raw-plane loads, 4 output stores, 8 fix-up iterations, 16 LUT fill (after a group's first chunk)
 #endif
 #ifndef ZN_F_EARLY_STAGE
 #define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
 #endif
 #ifndef ZN_F_DELTA0
-#define ZN_F_DELTA0 16                   // initial sync run-in (bits); doubles after a mismatch
+#define ZN_F_DELTA0 22                   // initial sync run-in (bits): the most one window refill can feed; doubles after a mismatch
+#endif
+
+// path counters of the emulated build (tests/simt): which form decoded how many tiles — [0] tiles, [1] looping form,
+// [2] fix-up iterations, [3] tiles written in several lane groups.  The device build has none of this.
+#if defined(ZN_SIMT_EMULATOR)
+static unsigned long long zn_dbg_tiles[8];
+extern "C" void zn_debug_tile_counters(unsigned long long* out, int reset) { for (int i = 0; i < 8; i++) { out[i] = zn_dbg_tiles[i]; if (reset) zn_dbg_tiles[i] = 0; } }
+#define ZN_DBG_COUNT(i) do { if (lane == 0) zn_dbg_tiles[i]++; } while (0)
+#else
+#define ZN_DBG_COUNT(i) do { } while (0)
 #endif
 
 // stream-tile dword i lives at in[ZN_IN_IDX(i)] (a padded layout against bank conflicts of the strided walk
@@ -126,13 +141,18 @@ typedef uint32_t zn_v4u __attribute__((ext_vector_type(4)));
 #define ZN_ST128(p, a, b, c, d) (*(uint4*)(p) = make_uint4((a), (b), (c), (d)))
 #endif
 
+// wave-uniform values the compiler cannot see as such (v_readfirstlane → scalar registers)
+__device__ __forceinline__ uint32_t zn_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t zn_uniform64(uint64_t v) { return ((uint64_t)zn_uniform((uint32_t)(v >> 32)) << 32) | zn_uniform((uint32_t)v); }
+template <typename T> __device__ __forceinline__ T* zn_uniform_ptr(T* p) { return ZN_GLOBAL_PTR(T, zn_uniform64((uint64_t)p)); }
+
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 
 struct ZnFusedPlane { uint64_t off; uint32_t kind; uint32_t csize; };   // off: body offset (RAW/HUF) or byte value (RLE)
 
-struct ZnFusedLds {
-  uint32_t lut[2u << ZN_F_TLMAX];          // multi-symbol decode table: [0, 2^TL) meta words, [2^TLMAX, …) symbol words
+struct __attribute__((aligned(16))) ZnFusedLds {
+  uint2 lut[1u << ZN_F_TLMAX];             // multi-symbol decode table: {symbols, meta} per TL-bit window (ZN_E_META)
   uint32_t ring[4][ZN_F_RING_DW];          // per-wave output ring; ring[0] holds the 16-bit LUT while tables are built
   uint32_t in[4][ZN_F_IN_DW];              // per-wave staged stream tile
   uint8_t symlist[4][256];                 // per chunk of the group: symbols in canonical order
@@ -142,105 +162,7 @@ struct ZnFusedLds {
   uint32_t what[4];
 };
 
-// multi-symbol LUT entry = up to 5 symbols of one 11-bit window.  Symbol word: symbols 0-3 (unused bytes 0).
-// Meta word: E1..E5 in bits 0-19 (4 bits each), symbol 4 in 20-27, count in 29-31, where E_j = bits consumed
-// when exactly j symbols are taken = start offset of symbol j (j < count), the total length for j ≥ count.
-#define ZN_E_META(cnt, efields, sym4) ((efields) | ((sym4) << 20) | ((cnt) << 29))
-
-// wave-wide exclusive prefix sum on the DPP network (6 v_add_u32 with a dpp modifier, no LDS traffic):
-// row_shr 1/2/4/8 scan each row of 16 lanes, row_bcast15 / row_bcast31 carry the row totals forward.
-__device__ __forceinline__ uint32_t zn_wave_excl_scan(uint32_t v, uint32_t lane, uint32_t* total) {
-  int x = (int)v;
-  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
-  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
-  *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
-  (void)lane;
-  return (uint32_t)x - v;
-}
-
-// One decode chain = the sub-block of the tile walked by one lane.  The unread bits sit MSB-aligned in
-// (whi:wlo) and are consumed with one 64-bit shift per step.  The loops are BRANCH-FREE per
-// step (lanes that are done keep executing with a zero-length step) and unrolled as "refill + 3 steps":
-// a refill leaves ≥ 33 valid bits and a step consumes ≤ TL ≤ 11, so no per-step refill test is needed.
-struct ZnChain {
-  int32_t pos, stop;          // next unread bit / boundary: symbols starting in (stop, pos] belong to this chain
-  uint32_t whi, wlo;
-  uint32_t n;                 // MODE 1: symbols counted
-  uint32_t wpos;              // MODE 2: byte offset in the staging buffer of the next symbol
-};
-
-__device__ __forceinline__ void zn_chain_refill(ZnChain& c, const uint32_t* in, int32_t base_bit) {
-  int32_t q = c.pos - 1 - base_bit;
-  q = q < 32 ? 32 : q;                                     // (only lanes that are done can be below; keeps in[j-1] in range)
-  const int32_t j = q >> 5; const uint32_t sh = 31u - (uint32_t)(q & 31);
-  const uint32_t d1 = in[ZN_IN_IDX(j)], d0 = in[ZN_IN_IDX(j - 1)];
-  const uint64_t w = (((uint64_t)d1 << 32) | d0) << sh;    // one v_lshlrev_b64
-  c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w;
-}
-// One step.  FULL: the whole group of the LUT entry, for lanes that are still more than a window above
-// their boundary (pos > bound = stop + TL - 1), nothing for the others.  !FULL: the boundary step — exactly
-// the symbols of the group that START above `stop` (symbol j starts E_j bits below pos).
-// A lane that takes nothing leaves its window undefined; every loop iteration begins with a refill.
-template <int MODE, bool FULL>
-__device__ __forceinline__ void zn_chain_step(ZnChain& c, const uint32_t* lut32, uint32_t sh, int32_t bound, uint32_t* stage) {
-  const uint32_t idx = c.whi >> sh;
-  // (LDS is a bottleneck of these passes: lanes with nothing to add stay out of the atomics; masking the table
-  //  reads the same way was measured and does not pay)
-  const bool act = FULL ? (c.pos > bound) : (c.pos > c.stop);
-  uint32_t meta = lut32[idx], syms = (MODE == 2) ? lut32[idx + (1u << ZN_F_TLMAX)] : 0u;
-  meta = act ? meta : 0u; syms = act ? syms : 0u;
-  uint32_t nb, cnt;
-  if (FULL) {
-    nb = (meta >> 16) & 15u; cnt = meta >> 29;
-  } else {
-    const int32_t rem = c.pos - c.stop;                             // ≤ 0: this lane is done (meta == 0)
-    const uint32_t k = (uint32_t)(rem > 0) + (uint32_t)((int32_t)(meta & 15u) < rem) + (uint32_t)((int32_t)((meta >> 4) & 15u) < rem) +
-                       (uint32_t)((int32_t)((meta >> 8) & 15u) < rem) + (uint32_t)((int32_t)((meta >> 12) & 15u) < rem);
-    const uint32_t have = meta >> 29;
-    cnt = k < have ? k : have;
-    nb = k ? ((meta >> (4u * k - 4u)) & 15u) : 0u;
-    syms &= cnt >= 4u ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8u * cnt));   // the symbols 0-3 taken
-    if (cnt < 5u) meta &= ~(0xFFu << 20);                           // symbol 4 only with all five
-  }
-  if (MODE == 2) {
-    // the ≤ 5 symbol bytes as one 40-bit value, moved to the byte position inside the dword with one 64-bit
-    // shift: low dword → d[0], high dword = the bytes that spill into d[1] (0 when none)
-    const uint64_t pack = ((uint64_t)((meta >> 20) & 0xFFu) << 32) | syms;
-    const uint64_t sp = pack << ((c.wpos & 3u) << 3);
-    uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & ~3u));
-    if ((uint32_t)sp) atomicOr(d, (uint32_t)sp);
-    if ((uint32_t)(sp >> 32)) atomicOr(d + 1, (uint32_t)(sp >> 32));
-    c.wpos += cnt;
-  }
-  { const uint64_t w = (((uint64_t)c.whi << 32) | c.wlo) << nb; c.whi = (uint32_t)(w >> 32); c.wlo = (uint32_t)w; }   // v_lshlrev_b64
-  c.pos -= (int32_t)nb;
-  if (MODE == 1) c.n += cnt;
-}
-
-// Decode every symbol that starts in (stop, pos]: whole groups of up to 5 symbols while the group provably
-// starts above `stop`, then the boundary step(s).  MODE 0: advance only (sync run-in); 1: count symbols;
-// 2: OR the symbols into the staging buffer (ds_or_b32: neighbouring lanes share dwords).
-// base_bit = absolute bit position of bit 0 of in[0].  All 64 lanes call this together.
-template <int MODE>
-__device__ __forceinline__ void zn_fused_run(const uint32_t* lut32, const uint32_t* in, int32_t base_bit, uint32_t TL,
-                                             ZnChain& c, uint32_t* stage) {
-  const uint32_t sh = 32u - TL;
-  const int32_t mb = c.stop + (int32_t)TL - 1;
-  while (__any(c.pos > mb)) {
-    zn_chain_refill(c, in, base_bit);
-    zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
-    zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
-    zn_chain_step<MODE, true>(c, lut32, sh, mb, stage);
-  }
-  while (__any(c.pos > c.stop)) {            // one iteration unless > 5 symbols start in the last TL - 1 bits
-    zn_chain_refill(c, in, base_bit);
-    zn_chain_step<MODE, false>(c, lut32, sh, c.stop, stage);
-  }
-}
+#include "zn_decode_chain.hpp"
 
 // Decode tables of one huff0 block, by the whole workgroup: the canonical single-symbol LUT (u16, aliased into
 // staging buffer 0, idle at this point), then the multi-symbol LUT.  j = which of the group's symbol orders.
@@ -255,16 +177,16 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
   {
     // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
     const uint32_t mask = (1u << TL) - 1u;
-    uint32_t pos[8], cnt[8], syms[8], ef[8], sym4[8];
-    for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; sym4[k] = 0; }
-    for (int step = 0; step < 5; step++) {
+    uint32_t pos[8], cnt[8], syms[8], ef[8];
+    for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; }
+    for (int step = 0; step < 4; step++) {
       for (int k = 0; k < 8; k++) {
         const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
         if (u <= mask && cnt[k] == (uint32_t)step) {
           const uint32_t e = lut16[ZN_L16((u << pos[k]) & mask)]; const uint32_t len = e >> 8;
           if (pos[k] + len <= TL) {             // the window holds this code completely
-            if (step > 0) ef[k] |= pos[k] << (4 * (step - 1));          // E_step = where this symbol starts
-            if (step < 4) syms[k] |= (e & 0xFFu) << (8 * step); else sym4[k] = e & 0xFFu;
+            if (step > 0) ef[k] |= pos[k] << (16 + 4 * (step - 1));     // E_step = where this symbol starts
+            syms[k] |= (e & 0xFFu) << (8 * step);
             pos[k] += len; cnt[k]++;
           }
         }
@@ -272,8 +194,8 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
     }
     for (int k = 0; k < 8; k++) {
       const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
-      for (uint32_t j = 1; j <= 5u; j++) if (j >= cnt[k]) ef[k] |= pos[k] << (4u * (j - 1u));   // E_j = total for j ≥ count
-      if (u <= mask) { L.lut[u] = ZN_E_META(cnt[k], ef[k], sym4[k]); L.lut[u + (1u << ZN_F_TLMAX)] = syms[k]; }
+      for (uint32_t i = 1; i <= 3u; i++) if (i >= cnt[k]) ef[k] |= pos[k] << (16u + 4u * (i - 1u));   // E_i = total for a symbol that does not exist
+      if (u <= mask) L.lut[u] = make_uint2(syms[k], ZN_E_META(cnt[k], pos[k], ef[k]));
     }
   }
 }
@@ -286,9 +208,20 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
 // xq == outq accumulates into rows already written (every row is loaded before it is stored, once).
 template <int P, int H, int DC, bool X = false>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
-                                              uint8_t* outq, const uint8_t* xq, const ZnFusedPlane (&pl)[P], const uint8_t* const (&rawq)[P],
-                                              const uint32_t* lut32, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg,
-                                              uint32_t TL, uint32_t Du, const uint8_t* stream, uint32_t slen, bool ragged ZN_PT_PARAM) {
+                                              uint8_t* outq_, const uint8_t* xq_, const ZnFusedPlane (&pl_)[P], const uint8_t* const (&rawq_)[P],
+                                              const uint2* lut, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg_,
+                                              uint32_t TL_, uint32_t Du, const uint8_t* stream_, uint32_t slen_, bool ragged ZN_PT_PARAM) {
+  // Everything the caller hands over is the same in all 64 lanes, but most of it came through LDS or was derived from
+  // threadIdx, which makes it per-lane data to the compiler: vector registers, and exec-masked control flow around every
+  // branch that depends on it (the tile loop, the choice of the decode form).  Say that it is uniform.
+  uint8_t* const outq = zn_uniform_ptr(outq_); const uint8_t* const xq = zn_uniform_ptr(xq_);
+  const uint8_t* const stream = zn_uniform_ptr(stream_);
+  const uint32_t seg = zn_uniform(seg_), TL = zn_uniform(TL_), slen = zn_uniform(slen_);
+  ZnFusedPlane pl[P]; const uint8_t* rawq[P];
+  for (int p = 0; p < P; p++) {
+    pl[p].off = zn_uniform64(pl_[p].off); pl[p].kind = zn_uniform(pl_[p].kind); pl[p].csize = zn_uniform(pl_[p].csize);
+    rawq[p] = zn_uniform_ptr(rawq_[p]);
+  }
   constexpr int EPL = (P == 1) ? 16 : 8;      // bytes per plane per lane in one flushed row
   constexpr int EW = EPL / 4;                 // … in dwords
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
@@ -297,21 +230,31 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #ifndef ZN_F_RB4
 #define ZN_F_RB4 2
 #endif
-  constexpr int RB = (P == 2) ? (int)(ZN_F_RING_BYTES / 512u) : (P == 4) ? ZN_F_RB4 : (int)(ZN_F_RING_BYTES / 1024u);
+#ifndef ZN_F_RB2
+#define ZN_F_RB2 (ZN_F_RING_BYTES / 512u)
+#endif
+  constexpr int RB = (P == 2) ? (int)ZN_F_RB2 : (P == 4) ? ZN_F_RB4 : (int)(ZN_F_RING_BYTES / 1024u);
+  // register-resident decode (zn_pass1 / zn_pass2): slots for whole-group steps / boundary steps, unchecked head.
+  // A sub-block of D dwords needs about 32 D / 9.6 steps (a step consumes 9-10 of its ≤ 11 window bits on every
+  // dtype's data, or 4 symbols when the codes are short); lanes that need more send the tile to the looping form.
+  constexpr int TF = DC ? ZN_F_TF(DC) : 0, TB = 3;      // (the run-time-D instance only has the looping form)
+  constexpr int UF = DC ? (32 * DC - 31) / 11 : 0;
   ZN_PT_SHARED;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
   uint32_t pre[RB][P][EW];
-  auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
-    for (int r = 0; r < RB; r++) if (r < nrows)
-      for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
-        const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
-#if ZN_F_ABLATE & 32
-        for (int k = 0; k < EW; k++) pre[r][p][k] = (uint32_t)(uint64_t)a;                                 // (timing only: no raw-plane loads)
-        continue;
+  auto fetch_row = [&](uint32_t first_row_sym, int r) {
+    for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
+      const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+#if ZN_F_ABL & 2
+      for (int k = 0; k < EW; k++) pre[r][p][k] = (uint32_t)(uint64_t)a;
+      continue;
 #endif
-        for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
-      }
+      for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
+    }
+  };
+  auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
+    for (int r = 0; r < RB; r++) if (r < nrows) fetch_row(first_row_sym, r);
   };
   // interleave rows (ring bytes for the Huffman plane, fetched bytes for raw planes) and store them.
   // All loads are complete before the first store is issued, so no store latency is ever waited on.
@@ -367,8 +310,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
         x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
         if (X) for (int k = 0; k < 4; k++) x[k] ^= xr_[k % XW];
-#if ZN_F_ABLATE & 16
-        ZN_OPAQUE32(x[0]); ZN_OPAQUE32(x[1]); ZN_OPAQUE32(x[2]); ZN_OPAQUE32(x[3]); (void)o;   // (timing only: no output)
+#if ZN_F_ABL & 4
+        { uint32_t t_ = x[0] ^ x[1] ^ x[2] ^ x[3]; asm volatile("" : "+v"(t_)); (void)o; }
 #else
         ZN_ST128(o, x[0], x[1], x[2], x[3]);
 #endif
@@ -409,10 +352,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const uint32_t mis = (uint32_t)((uint64_t)stream & 3u);
   const uint32_t* gdw = (const uint32_t*)(stream - mis);
   const int32_t b0 = (int32_t)(8u * mis);
-  int32_t carry = b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last);
+  int32_t carry = __builtin_amdgcn_readfirstlane(b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last));   // (wave-uniform)
   int32_t hi_dw = (carry + 31) >> 5;
   const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
   int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
+  int nmis = 0;                               // tiles of this stream that needed a fix-up since the run-in was last lengthened
 
   // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D-1, and (lane 0) the
   // tile's last dword, in a register of its own so that nothing selects on a loaded value before the staging
@@ -455,8 +399,44 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   stage_tile();
 #endif
 
+  // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it; returns the
+  // position the lane's own decode starts from (lane 0: the true position carried over from the previous tile)
+  auto sync_run = [&](int32_t base_bit, int32_t hi_k, bool active) -> int32_t {
+    ZnChain c;
+    c.pos = (lane > 0 && active) ? hi_k + delta : hi_k; c.stop = hi_k; c.n = 0; c.wpos = 0;
+    if (delta <= 22) {
+      // short run-in: one refill (≥ 33 valid bits) feeds two whole groups (≤ TL bits each) and the boundary step (a
+      // TL-bit look-up) — 22 bits almost always synchronise (a fix-up re-decodes the whole tile: 14 steps against this one)
+      const uint32_t sh = 32u - TL;
+      uint64_t w = zn_window(in, c.pos - 1 - base_bit);
+      for (int i = 0; i < 2; i++) { uint2 e = lut[(uint32_t)(w >> 32) >> sh]; if (!(c.pos > c.stop + (int32_t)TL - 1)) { e.x = 0; e.y = 0; } w <<= (e.y & 63u); c.pos -= (int32_t)ZN_M_NB(e.y); }
+      { uint2 e = lut[(uint32_t)(w >> 32) >> sh]; if (!(c.pos > c.stop)) { e.x = 0; e.y = 0; } c.pos -= (int32_t)ZN_M_NB(zn_trim_group(e, c.pos - c.stop).y); }
+      while (__any(c.pos > c.stop)) {
+        w = zn_window(in, c.pos - 1 - base_bit);
+        uint2 e = lut[(uint32_t)(w >> 32) >> sh]; if (!(c.pos > c.stop)) { e.x = 0; e.y = 0; }
+        c.pos -= (int32_t)ZN_M_NB(zn_trim_group(e, c.pos - c.stop).y);
+      }
+    } else {
+      zn_fused_run<0>(lut, in, base_bit, TL, c, nullptr);
+    }
+    return (lane > 0) ? c.pos : carry;
+  };
+  // a longer run-in for the rest of the stream once mismatches keep coming (the third tile that needs a fix-up): beyond
+  // 22 bits the run-in takes the looping form, which costs every later tile of the stream several steps
+  auto note_mismatch = [&]() { if (++nmis >= 3) { nmis = 0; delta = (delta < 22) ? 22 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; } };
+  // the incomplete last row (< UNIT symbols, at staging row `total_rows`) moves to the start of the staging buffer
+  auto keep_remainder = [&](uint32_t total_rows) {
+    const uint32_t i = (total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
+    uint32_t t[EW];
+    for (int k = 0; k < EW; k++) { t[k] = ring[i + k]; ring[i + k] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 0; k < EW; k++) ring[((uint32_t)EPL * lane >> 2) + k] = t[k];
+    __builtin_amdgcn_wave_barrier();
+  };
+
   bool ok = true;
   while (32 * hi_dw > b0) {
+    if (DC) ZN_ASM_MARK("ZN_HOT_TILE_BEGIN");
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
 #if !ZN_F_EARLY_STAGE
@@ -468,115 +448,140 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     const int32_t hi_k = 32 * (hi_dw - (int32_t)lane * Di), lo_k = hi_k - 32 * Di;
     const int32_t stop = lo_k > b0 ? lo_k : b0;
     const bool active = hi_k > b0;
-
-    // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it
-    ZnChain A;
-    auto sync_run = [&](ZnChain& c) {
-      c.pos = (lane > 0 && active) ? hi_k + delta : hi_k; c.stop = hi_k; c.n = 0; c.wpos = 0; c.whi = 0; c.wlo = 0;
-      if (delta <= 21) {
-        // short run-in: one refill feeds one whole group (≤ TL bits) and the boundary step (≤ TL bits)
-        zn_chain_refill(c, in, base_bit);
-        zn_chain_step<0, true>(c, lut32, 32u - TL, c.stop + (int32_t)TL - 1, nullptr);
-        zn_chain_step<0, false>(c, lut32, 32u - TL, c.stop, nullptr);
-        while (__any(c.pos > c.stop)) { zn_chain_refill(c, in, base_bit); zn_chain_step<0, false>(c, lut32, 32u - TL, c.stop, nullptr); }
-      } else {
-        zn_fused_run<0>(lut32, in, base_bit, TL, c, nullptr);
-      }
-    };
-    ZN_PRIO(ZN_F_PRIO_SYNC);
-    sync_run(A);
-#if ZN_F_ABLATE & 2
-    { ZnChain B; sync_run(B); uint32_t t_ = (uint32_t)B.pos; ZN_OPAQUE32(t_); }
-#endif
-    int32_t s = (lane > 0) ? A.pos : carry;
-    ZN_PRIO(ZN_F_PRIO_COUNT);
-    ZN_PT(5);   // sync run-in
-
-    // count, and verify that the 64 sub-blocks form one consistent chain below the true start of the first
-    uint32_t n = 0; int32_t e = s; bool need = active, chained = false;
-    for (int it = 0; it < 66; it++) {
-      A.pos = need ? s : stop; A.stop = stop; A.n = 0;
-#if ZN_F_ABLATE & 4
-      { ZnChain B = A; zn_fused_run<1>(lut32, in, base_bit, TL, B, nullptr); uint32_t t_ = B.n + (uint32_t)B.pos; ZN_OPAQUE32(t_); }
-#endif
-      zn_fused_run<1>(lut32, in, base_bit, TL, A, nullptr);
-      if (need) { e = A.pos; n = A.n; }
-      const int32_t e_prev = __shfl_up(e, 1u);
-      const bool mism = active && lane > 0 && e_prev != s;
-      if (it == 0) ZN_PT(6); else ZN_PT(7);   // first count pass / fix-up passes
-      if (!__any(mism)) { chained = true; break; }
-      ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
-      ZN_PT_COUNT(17, __popcll(__ballot(mism)));
-      // a longer run-in for the rest of the stream: first to 21 bits (still one refill: the short sync path), then doubling
-      if (it == 0) { delta = (delta < 21) ? 21 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; }
-      need = mism;
-      if (mism) s = e_prev;
-    }
+    const bool regular = (32 * lo_dw >= b0);             // every lane owns a whole sub-block (stop == lo_k, all active)
     ZN_PT_COUNT(18, 1);                      // tiles
-    if (!active) n = 0;
-    uint32_t N = 0;
-    const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
-    const uint32_t nact = (uint32_t)__popcll(__ballot(active));
-    const int32_t e_last = __shfl(e, (int)(nact ? nact - 1u : 0u));
-    if (!chained || J + N > seg) { ok = false; break; }
-    carry = e_last; hi_dw = lo_dw;
+    ZN_DBG_COUNT(0);
 
-    // write: second decode of the same sub-blocks, symbols OR-ed into the staging buffer.  The buffer is
-    // linear: its byte 0 holds symbol JF (the unflushed remainder of the previous tile sits at its start).
-    // The sub-block size is chosen from the stream's average code length, so a tile normally fits in one
-    // go; a tile that is denser than that is written in several lane groups with a flush after each.
-    uint32_t lane_lo = 0, wdone = 0;
-    do {
-      const uint32_t base = J - JF;                            // < UNIT
-      const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - 4u - base);   // monotone in the lane index
-      const uint32_t lane_hi = (uint32_t)__popcll(__ballot(fits));
-      if (lane_hi <= lane_lo) { ok = false; break; }           // cannot happen: one sub-block always fits
-      const uint32_t wend = (lane_hi >= 64u) ? N : (uint32_t)__shfl((int)o_k, (int)(lane_hi & 63u));
-      const uint32_t nsub = wend - wdone;
-
-      // rows that will be complete after this group: request their raw bytes now, use them after the write pass
-      int rows = (int)((base + nsub) / UNIT);
-      const int first = rows < RB ? rows : RB;
-      fetch_rows(JF, first);
-      ZN_PT(8);   // scans / shuffles / issue loads
-
-      ZN_PRIO(ZN_F_PRIO_WRITE);
-      const bool mine = active && lane >= lane_lo && lane < lane_hi;
-      A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
-#if ZN_F_ABLATE & 8
-      { ZnChain B = A; zn_fused_run<2>(lut32, in, base_bit, TL, B, ring); }      // (OR-ing the same symbols twice changes nothing)
-#endif
-#if !(ZN_F_ABLATE & 64)                                          // (64: timing only, the staging buffer stays empty)
-      zn_fused_run<2>(lut32, in, base_bit, TL, A, ring);
-#endif
-      __builtin_amdgcn_wave_barrier();
-      ZN_PRIO(0);
-      ZN_PT(9);   // write pass
-      J += nsub; wdone = wend; lane_lo = lane_hi;
-
-      const int total_rows = rows;
-      uint32_t srow = 0;
-      // (the write pass of the tile's last lane group is over: the stream-tile buffer is free for the next tile)
-      emit_rows(JF, first, srow, [&] {
-#if ZN_F_EARLY_STAGE
-        if (lane_hi >= 64u && 32 * hi_dw > b0) stage_tile();
-#endif
-      });
-      JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
-      while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
-      if (total_rows > 0 && J > JF) {
-        // move the incomplete last row (< UNIT symbols) to the start of the staging buffer
-        const uint32_t i = ((uint32_t)total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
-        uint32_t t[EW];
-        for (int k = 0; k < EW; k++) { t[k] = ring[i + k]; ring[i + k] = 0; }
-        __builtin_amdgcn_wave_barrier();
-        for (int k = 0; k < EW; k++) ring[((uint32_t)EPL * lane >> 2) + k] = t[k];
-        __builtin_amdgcn_wave_barrier();
+    // ---- the register-resident form (zn_decode_chain.hpp): decode once, verify the chain, compact, flush.  It commits
+    // nothing before it knows that the tile is its own; what it does not take — more than TF whole-group steps in some
+    // lane, a chain that a few fix-up iterations do not close, a tile denser than one staging buffer — is left, untouched,
+    // to the looping form below, whose state (and registers) it shares nothing with but the stream position.
+    bool done = false;
+    if (TF > 0) {
+      ZN_PRIO(ZN_F_PRIO_SYNC);
+      int32_t s = sync_run(base_bit, hi_k, active);
+      ZN_PRIO(ZN_F_PRIO_COUNT);
+      ZN_PT(5);   // sync run-in
+      ZnRec rec;
+      int nfull = 0, nbnd = 0;
+      uint32_t acc = 0, n = 0; int32_t e = s;
+      bool took = true, chained = false;
+      for (int it = 0; it < 4; it++) {
+        // (one call site per instance: the unchecked-head one for regular tiles, the checked one for a stream's last tile)
+        if (regular) took = zn_pass1<TF, TB, UF>(lut, in, base_bit, TL, s, stop, true, rec, acc, nfull, nbnd);
+        else took = zn_pass1<TF, TB, 0>(lut, in, base_bit, TL, s, stop, active, rec, acc, nfull, nbnd);
+        if (!took) break;
+        e = s - (int32_t)(acc & 0xFFu); n = (acc >> 8) & 0xFFu;
+        const int32_t e_prev = __shfl_up(e, 1u);
+        const bool mism = active && lane > 0 && e_prev != s;
+        if (it == 0) ZN_PT(6); else ZN_PT(7);   // first decode pass / fix-up passes
+        if (__builtin_expect(!__any(mism), 1) || (ZN_F_ABL & 8)) { chained = true; break; }
+        ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
+        ZN_PT_COUNT(17, __popcll(__ballot(mism)));
+        ZN_DBG_COUNT(2);
+        if (it == 0) note_mismatch();
+        if (mism) s = e_prev;                  // (every lane decodes again: the lanes run in lock-step anyway)
       }
-      ZN_PT_COUNT(20, 1);                    // write groups (== tiles when nothing overflowed)
-    } while (lane_lo < 64u);
-    if (!ok) break;
+      if (took && chained) {
+        if (!active) n = 0;
+        uint32_t N = 0;
+        const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
+        const uint32_t base = J - JF;                            // < UNIT
+        if (J + N <= seg && base + N <= ZN_F_RING_BYTES - 4u) {
+          const uint32_t nact = (uint32_t)__popcll(__ballot(active));
+          carry = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u)); hi_dw = lo_dw;
+          // rows that will be complete after this tile: request their raw bytes now, use them after the compaction
+          int rows = (int)((base + N) / UNIT);
+          const uint32_t total_rows = (uint32_t)rows;
+          const int first = rows < RB ? rows : RB;
+          fetch_rows(JF, first);
+          ZN_PT(8);   // scans / shuffles / issue loads
+          ZN_PRIO(ZN_F_PRIO_WRITE);
+          if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB>(ring, base + o_k, rec, nfull, nbnd, [](auto) {});   // (lanes without a sub-block hold zero records)
+          __builtin_amdgcn_wave_barrier();
+          ZN_PRIO(0);
+          ZN_PT(9);   // compaction
+          J += N;
+          // (the compaction is over: the stream-tile buffer is free for the next tile, staged behind the flush's wait)
+          emit_rows(JF, first, 0, [&] {
+#if ZN_F_EARLY_STAGE
+            if (32 * hi_dw > b0) stage_tile();
+#endif
+          });
+          uint32_t srow = (uint32_t)first;
+          JF += (uint32_t)first * UNIT; rows -= first;
+          while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
+          if (total_rows > 0 && J > JF) keep_remainder(total_rows);
+          ZN_PT_COUNT(20, 1);                    // write groups (== tiles when nothing overflowed)
+          done = true;
+        }
+      }
+    }
+
+    // ---- the looping form: count pass (with fix-up iterations), then a second decode that ORs the symbols into the
+    // staging buffer, in several lane groups with a flush after each when the tile is denser than the buffer
+    if (!done) {
+      ZN_NO_IFCVT;
+      ZN_PT_COUNT(22, 1);                    // tiles that took the looping form
+      ZN_DBG_COUNT(1);
+      ZN_PRIO(ZN_F_PRIO_SYNC);
+      int32_t s = sync_run(base_bit, hi_k, active);
+      ZN_PRIO(ZN_F_PRIO_COUNT);
+      ZnChain A; A.wpos = 0;
+      int32_t e = s; uint32_t n = 0; bool need = active, chained = false;
+      for (int it = 0; it < 66; it++) {
+        A.pos = need ? s : stop; A.stop = stop; A.n = 0;
+        zn_fused_run<1>(lut, in, base_bit, TL, A, nullptr);
+        if (need) { e = A.pos; n = A.n; }
+        const int32_t e_prev = __shfl_up(e, 1u);
+        const bool mism = active && lane > 0 && e_prev != s;
+        if (!__any(mism)) { chained = true; break; }
+        if (it == 0) note_mismatch();
+        need = mism;
+        if (mism) s = e_prev;
+      }
+      if (!active) n = 0;
+      uint32_t N = 0;
+      const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
+      const uint32_t nact = (uint32_t)__popcll(__ballot(active));
+      const int32_t e_last = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u));
+      if (!chained || J + N > seg) { ok = false; break; }
+      carry = e_last; hi_dw = lo_dw;
+      uint32_t lane_lo = 0, wdone = 0;
+      do {
+        const uint32_t base = J - JF;                            // < UNIT
+        const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - 4u - base);   // monotone in the lane index
+        const uint32_t lane_hi = (uint32_t)__popcll(__ballot(fits));
+        if (lane_hi <= lane_lo) { ok = false; break; }           // cannot happen: one sub-block always fits
+        if (lane_hi < 64u) ZN_DBG_COUNT(3);
+        const uint32_t wend = (lane_hi >= 64u) ? N : (uint32_t)__shfl((int)o_k, (int)(lane_hi & 63u));
+        const uint32_t nsub = wend - wdone;
+        int rows = (int)((base + nsub) / UNIT);
+        const int first = rows < RB ? rows : RB;
+        fetch_rows(JF, first);
+        ZN_PRIO(ZN_F_PRIO_WRITE);
+        const bool mine = active && lane >= lane_lo && lane < lane_hi;
+        A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
+        zn_fused_run<2>(lut, in, base_bit, TL, A, ring);
+        __builtin_amdgcn_wave_barrier();
+        ZN_PRIO(0);
+        J += nsub; wdone = wend; lane_lo = lane_hi;
+        const uint32_t total_rows = (uint32_t)rows;
+        uint32_t srow = 0;
+        emit_rows(JF, first, srow, [&] {
+#if ZN_F_EARLY_STAGE
+          if (lane_hi >= 64u && 32 * hi_dw > b0) stage_tile();
+#endif
+        });
+        JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
+        while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
+        if (total_rows > 0 && J > JF) keep_remainder(total_rows);
+        ZN_PT_COUNT(20, 1);
+      } while (lane_lo < 64u);
+      if (!ok) break;
+    }
     ZN_PT(3);   // flush rows
+    if (DC) ZN_ASM_MARK("ZN_HOT_TILE_END");
   }
   ZN_PRIO(0);                                 // (an error exit leaves the loop from inside a pass)
   if (ragged && ok && carry == b0 && J == seg && JF < seg) {
@@ -595,7 +600,7 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg*
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
   const uint8_t* body_end = body + body_len;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // (wave-uniform, and the compiler should know: everything derived from it lives in scalar registers)
   const uint32_t p = b - S.tail0;
   const uint64_t c = g.K - 1u;
   ZN_PT_DECL;
@@ -656,9 +661,10 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
                                                     uint8_t* outq, uint32_t j, uint32_t more, uint32_t seg ZN_PT_PARAM) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // (wave-uniform, and the compiler should know: everything derived from it lives in scalar registers)
   uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
   bool ok = true;
+  ZN_PT_SHARED;
   for (int p2 = 1; p2 < P; p2++) {
     if (!((more >> p2) & 1u)) continue;
     __syncthreads();                         // every wave is done with the tables and rings of the previous pass
@@ -730,7 +736,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 #define ZN_SET_DONE(c_, v_) do { if (tid == 0) { done[c_] = (v_); if (!(v_)) atomicAdd(status + 1 + (P == 1 ? 0 : P == 2 ? 1 : 2), 1u); } if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;
 
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // (wave-uniform, and the compiler should know: everything derived from it lives in scalar registers)
   const uint64_t c0 = (uint64_t)(wg - S.wg0) * ncg;
   const uint32_t nc = (g.K - c0 < (uint64_t)ncg) ? (uint32_t)(g.K - c0) : ncg;
   const uint32_t plen = (uint32_t)(g.chunk / P);
@@ -771,10 +777,6 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       uint8_t* scratch = (uint8_t*)&L.ring[wave][0];          // weights + FSE cells; the ring is idle until the decode
       st = zn_wave_read_stats(body + L.plane[wave][h].off, csize, body_end, lane, scratch, L.symlist[wave], L.rank_start[wave],
                               L.sym_start[wave], scratch + 512);
-#if ZN_F_ABLATE & 256
-      st = zn_wave_read_stats(body + L.plane[wave][h].off, csize, body_end, lane, scratch, L.symlist[wave], L.rank_start[wave],
-                              L.sym_start[wave], scratch + 512);
-#endif
       if (st.hs < 0 || st.tl > ZN_F_TLMAX || (uint32_t)st.hs >= csize || csize - (uint32_t)st.hs < 10u) elig = false;
     }
     if (lane == 0) { L.st[wave] = st; L.what[wave] = elig ? (uint32_t)(h + 2) : 0u; }   // 0: not ours, 1: no Huffman plane, 2+h
@@ -786,13 +788,13 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     const uint64_t c = c0 + j;
     if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
     ZN_PT(21);  // wait for the slowest wave of the previous chunk
-    const uint32_t what = L.what[j];
+    const uint32_t what = zn_uniform(L.what[j]);          // (what comes out of LDS or HBM below is wave-uniform: scalar registers, scalar branches)
     if (what == 0u) { ZN_SET_DONE(c, 0); continue; }
     const int h = (int)what - 2;
     ZnFusedPlane pl[P];
     uint32_t more = 0;                          // further Huffman planes (bit p): decoded by extra passes, zero bytes in this one
     for (int p = 0; p < P; p++) {
-      pl[p] = L.plane[j][p];
+      pl[p].off = zn_uniform64(L.plane[j][p].off); pl[p].kind = zn_uniform(L.plane[j][p].kind); pl[p].csize = zn_uniform(L.plane[j][p].csize);
       if (p > h && h >= 0 && pl[p].kind == ZN_KIND_HUF) { more |= 1u << p; pl[p].kind = ZN_KIND_RLE; pl[p].off = 0; }
     }
 
@@ -805,14 +807,12 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       for (int p = 0; p < P; p++) if (p == h) { h_off = pl[p].off; csize = pl[p].csize; }
       const uint8_t* src = body + h_off;
       const ZnWaveStats st = L.st[j];
-      const int hs = st.hs; TL = st.tl;
+      const int hs = (int)zn_uniform((uint32_t)st.hs); TL = zn_uniform(st.tl);
+      if (!((ZN_F_ABL & 16) && j > 0))
       zn_fused_fill_luts(L, tid, TL, j);
-#if ZN_F_ABLATE & 1
-      __syncthreads(); zn_fused_fill_luts(L, tid, TL, j);
-#endif
       // jump table → this wave's stream
       const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
-      const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+      const uint32_t l1 = zn_uniform(zn_ld16(js)), l2 = zn_uniform(zn_ld16(js + 2)), l3 = zn_uniform(zn_ld16(js + 4));
       uint32_t l4 = 0;
       if (l1 + l2 + l3 + 6u > rem) bad = true; else l4 = rem - 6u - l1 - l2 - l3;
       if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) bad = true;
@@ -838,6 +838,9 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 #define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
     // (one instance per Huffman plane index that exists for this P — nothing is instantiated twice)
+#ifdef ZN_F_ONLY_HOT      // (developer probe: the common instance alone, to read its register use off the compiler's remarks)
+    if (P == 2) ok = zn_fused_wave<P, (P >= 2 ? 1 : 0), ZN_F_DCONST, X>(ZN_WAVE_ARGS); else
+#endif
     if (h < 0) ok = zn_fused_wave<P, -1, 0, X>(ZN_WAVE_ARGS);
     else if (P == 1 || h == 0) ZN_WAVE_CASE(0);
     else if (P == 2 || h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
@@ -846,11 +849,13 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 #undef ZN_WAVE_CASE
 #undef ZN_WAVE_ARGS
     // ---- further Huffman planes (deltas, sparse tensors: every plane compresses): one more pass per plane
+#ifndef ZN_F_ONLY_HOT
     if (P >= 2 && __builtin_expect(more != 0u, 0)) {
       const int r2 = zn_fused_more_passes<P>(L, g, body, body_end, outq, j, more, seg ZN_PT_PASS);
       if (r2 < 0) { ZN_SET_DONE(c, 0); continue; }   // a later plane this kernel does not take: the generic path redoes the chunk
       ok = ok && r2 > 0;
     }
+#endif
     if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
     ZN_SET_DONE(c, 1);
     ZN_PT_COUNT(19, 1);                        // chunks
