@@ -28,7 +28,7 @@
 #define __global__
 #define __device__
 #define __host__
-#define __shared__ static
+#define __shared__ static thread_local      /* (one "LDS" per host thread: two threads may drive two emulated devices) */
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 
@@ -71,7 +71,7 @@ struct Engine {
   uint64_t wave_live[64];      // live-lane mask at release time
 };
 
-inline Engine& E() { static Engine e; return e; }
+inline Engine& E() { static thread_local Engine e; return e; }   // one engine per host thread
 
 inline void trampoline() {
   Engine& e = E();
@@ -266,11 +266,14 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuc
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+// two "devices" (nothing but an ordinal that is current per host thread, as in HIP): lets the CPU suite check the
+// per-device locking of the C-ABI with two threads
+inline int& zn_simt_current_device() { static thread_local int d = 0; return d; }
+static inline hipError_t hipGetDeviceCount(int* n) { *n = 2; return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = zn_simt_current_device(); return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
 static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= 2) return hipErrorInvalidValue; zn_simt_current_device() = d; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "zn_simt"; }
 static inline hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p, 256, n ? n : 256) ? hipErrorOutOfMemory : hipSuccess; }

@@ -499,3 +499,131 @@ def test_host_entry_points_from_concurrent_threads(lib):
     assert not errs, errs
     for i in range(2):
         assert frames[i][32:] == O.compress_frame(bytes(32), raws[i], 2, 1, 10, 256 * 1024)[32:]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 2: the plugin surface on a real device, the reference-produced checkpoint, whole-frame pins per dtype
+# ---------------------------------------------------------------------------------------------------------------
+GOLD_ST = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden", "gpt2_small_ref.znn.safetensors")
+
+
+def _tensor_sha(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("device", ["cuda:0", 0, "cuda", "torch.device"], ids=["str-cuda0", "int-0", "str-cuda", "torch-device"])
+def test_plugin_safe_open_decodes_in_hbm(lib, tmp_path, device):
+    """SURVEY §8 a16 on hardware (reference zipnn.py:1592-1643, util_patch.py:11-47): after zipnn_safetensors(), both
+    `safetensors.torch.safe_open` (what the reference patches) and top-level `safetensors.safe_open` (what transformers
+    ≥ 5 imports) opened with a device return every compressed tensor decoded ON that device by the HIP kernels, equal
+    to the original bit for bit; uncompressed tensors pass through; `device` may be a string, an ordinal or a torch.device."""
+    import os
+    import safetensors
+    import safetensors.torch
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    dev = torch.device("cuda", 0) if device == "torch.device" else device
+    g = torch.Generator().manual_seed(31)
+    tensors = {"w_bf16": (torch.randn(1100, 513, generator=g) * 0.02).to(torch.bfloat16),          # 2 full chunks + a tail
+               "w_fp16": (torch.randn(700, 300, generator=g) * 0.02).to(torch.float16),
+               "w_fp32": torch.randn(513, 257, generator=g) * 0.02,
+               "w_fp8": (torch.randn(900, 400, generator=g) * 0.02).to(torch.float8_e4m3fn),
+               "ids": torch.arange(5000, dtype=torch.int64), "tiny": torch.randn(3, generator=g).to(torch.bfloat16)}
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    znn = safetensors_io.compress_safetensors_file(src)
+    orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
+    try:
+        zipnn_safetensors()
+        for opener in (safetensors.torch.safe_open, safetensors.safe_open):
+            with opener(znn, framework="pt", device=dev) as f:
+                assert set(f.keys()) == set(tensors)
+                for k, v in tensors.items():
+                    got = f.get_tensor(k)
+                    assert got.is_cuda and got.dtype == v.dtype and got.shape == v.shape, k
+                    assert _tensor_sha(got) == _tensor_sha(v), k
+                    if k.startswith("w_"):
+                        assert "zn_k_decode" in lib.last_kernels(), (k, lib.last_kernels())      # decoded by the HIP kernels, in HBM
+        f = safetensors.safe_open(znn, framework="pt", device=dev)      # without `with`: still works, and closes its host handle
+        assert _tensor_sha(f.get_tensor("w_bf16")) == _tensor_sha(tensors["w_bf16"])
+        del f
+    finally:
+        safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+        from zipnn_amd import zipnn as _Z
+        _Z._patches_applied.pop(_Z._zipnn_safetensors, None)      # (the patcher applies a patch once per process, like the reference's: let the next test apply it again)
+
+
+def test_reference_produced_checkpoint_loads_through_the_plugin_and_load_file(lib):
+    """BASELINE.json configs[3] / SURVEY §8d-4: a GPT-2-shaped checkpoint compressed by the REFERENCE's own
+    scripts/zipnn_compress_safetensors.py (tests/golden/make_golden_safetensors.py, over oracle/_ref) is consumed
+    here: plugin + safe_open(device="cuda:0"), and safetensors_io.load_file (one batched decode).  Every tensor must
+    hash to what the generator recorded."""
+    import json
+    import safetensors
+    import safetensors.torch
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    info = json.load(open(GOLD_ST + ".json"))
+    assert hashlib.sha256(open(GOLD_ST, "rb").read()).hexdigest() == info["file_sha256"]
+    loaded = safetensors_io.load_file(GOLD_ST, device="cuda:0")
+    assert set(loaded) == set(info["tensors"])
+    for k, meta in info["tensors"].items():
+        assert loaded[k].is_cuda and str(loaded[k].dtype) == meta["dtype"] and list(loaded[k].shape) == meta["shape"], k
+        assert _tensor_sha(loaded[k]) == meta["sha256"], k
+    orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
+    try:
+        zipnn_safetensors()
+        with safetensors.torch.safe_open(GOLD_ST, "pt", device="cuda:0") as f:
+            n_compressed = 0
+            for k, meta in info["tensors"].items():
+                got = f.get_tensor(k)
+                assert got.is_cuda and _tensor_sha(got) == meta["sha256"], k
+                n_compressed += k in f.compressed_tensors_metadata
+            assert n_compressed >= 10                      # the reference really compressed the weight matrices
+        with safetensors.safe_open(GOLD_ST, framework="pt", device="cpu") as f:          # and the host route
+            for k, meta in info["tensors"].items():
+                assert _tensor_sha(f.get_tensor(k)) == meta["sha256"], k
+    finally:
+        safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+        from zipnn_amd import zipnn as _Z
+        _Z._patches_applied.pop(_Z._zipnn_safetensors, None)      # (the patcher applies a patch once per process, like the reference's: let the next test apply it again)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32", "fp8"])
+def test_256MiB_other_dtypes_whole_frame_vs_oracle(lib, dtype):
+    """BASELINE.json configs[2] (+ fp8): the WHOLE frame body of a 256 MiB tensor equals the oracle's (sha256), not a
+    sample of its chunks, and decodes back; every chunk through the fused kernels."""
+    from zipnn_amd import codec
+    g = torch.Generator().manual_seed(77)
+    n = 256 * KB * KB
+    if dtype == "fp16":
+        x = (torch.randn(n // 2, generator=g) * 0.02).half(); P, rot, bm, chunk = 2, 0, 10, C
+    elif dtype == "fp32":
+        x = torch.randn(n // 4, generator=g) * 0.02; P, rot, bm, chunk = 4, 1, 220, C
+    else:
+        x = (torch.randn(n, generator=g) * 0.02).to(torch.float8_e4m3fn); P, rot, bm, chunk = 1, 0, 10, 128 * KB
+    raw = x.view(torch.uint8).reshape(-1).numpy()
+    want = O.compress_frame(bytes(32), raw, P, rot, bm, chunk, threads=8)
+    body = codec.compress_device(lib, codec.flat_bytes(x.cuda()), P, rot, bm, chunk, 0.95)
+    assert hashlib.sha256(body.cpu().numpy().tobytes()).hexdigest() == hashlib.sha256(want[32:]).hexdigest()
+    obody = torch.from_numpy(np.frombuffer(want, dtype=np.uint8)[32:].copy()).cuda()
+    out = codec.decompress_device(lib, obody, P, rot, bm, chunk, raw.size)       # the ORACLE's frame, decoded on the GPU
+    assert torch.equal(out.cpu(), torch.from_numpy(raw))
+    assert lib.last_fused_chunks() == raw.size // chunk
+
+
+def test_plain_host_entry_points_the_reference_binding_calls(lib):
+    """zn_compress / zn_decompress (no delta) are what the reference-side stub binds (INTEGRATION.md §1,
+    tests/ref_binding/zipnn_core.py): called directly here, next to their *_delta siblings."""
+    import ctypes
+    L = lib._L
+    d = gen_bytes("bf16", 3 * C + 1000, 4)
+    want = O.compress_frame(HDR, d, 2, 1, 10, C)
+    cap = L.zn_compress_bound(len(d), 2, C, 32)
+    out = np.empty(cap, dtype=np.uint8); n_out = ctypes.c_size_t(0)
+    src = np.frombuffer(d, dtype=np.uint8); hdr = np.frombuffer(HDR, dtype=np.uint8)
+    assert L.zn_compress(hdr.ctypes.data, 32, src.ctypes.data, len(d), 2, 1, 10, C, 0.95, 0, out.ctypes.data, cap, ctypes.byref(n_out)) == 0
+    assert out[:n_out.value].tobytes() == want
+    back = np.empty(len(d), dtype=np.uint8)
+    assert L.zn_decompress(out[32:].ctypes.data, n_out.value - 32, 2, 1, 10, C, len(d), 0, back.ctypes.data) == 0
+    assert back.tobytes() == d
+    assert torch.cuda.current_device() == 0                  # the host entry points leave the caller's device as it was

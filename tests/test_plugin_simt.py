@@ -69,6 +69,8 @@ def test_safetensors_file_roundtrip_and_plugin(use_simt, tmp_path):
             assert torch.equal(f.get_tensor("w_fp32"), tensors["w_fp32"])
     finally:
         safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+        from zipnn_amd import zipnn as _Z
+        _Z._patches_applied.pop(_Z._zipnn_safetensors, None)      # (the patcher applies a patch once per process, like the reference's: let the next test apply it again)
 
 
 def test_zipnn_api_errors_and_types(use_simt):
@@ -141,3 +143,87 @@ def test_host_buffer_entry_points_through_the_pinned_pipe(simt_lib, monkeypatch)
         assert bytes(frame[32:]) == want[32:]
         back = simt_lib.decompress(memoryview(frame)[32:], 2, 1, 10, 256 * 1024, n)
         assert bytes(back) == raw
+
+
+def test_tensor_frames_with_delta_streaming_and_many_dims(use_simt):
+    """a frame handed to decompress() as a torch.Tensor used to work only for the plain one-frame case —
+    with a delta buffer it raised an opaque TypeError, a streaming BYTE blob decoded its first frame only, and a shape
+    of more than ~9 dimensions did not fit the fixed 80-byte header window."""
+    import numpy as np
+    import torch
+    from zipnn_amd import ZipNN
+    r = np.random.default_rng(2)
+    a = r.integers(0, 256, 300_000, dtype=np.uint8).tobytes()
+    b = bytes(x ^ (1 if i % 50 == 0 else 0) for i, x in enumerate(a))
+    z = ZipNN(input_format="byte", bytearray_dtype="bfloat16", delta_compressed_type="byte")
+    f = bytes(z.compress(a, delta_second_data=b))
+    ft = torch.frombuffer(bytearray(f), dtype=torch.uint8)
+    assert bytes(ZipNN(input_format="byte", bytearray_dtype="bfloat16", delta_compressed_type="byte").decompress(ft, delta_second_data=b)) == a
+    # a streaming blob of several frames, as a tensor
+    zs = ZipNN(input_format="byte", bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=65536)
+    blob = bytes(zs.compress(a))
+    bt = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+    assert bytes(ZipNN(input_format="byte", bytearray_dtype="bfloat16", is_streaming=True, streaming_chunk=65536).decompress(bt)) == a
+    # 12 dimensions: the shape extension is 1 + 12 * 2 bytes here, up to 1 + 9 * ndim in general
+    t = torch.randn(2, 1, 3, 1, 2, 1, 2, 1, 5, 1, 2, 3).to(torch.bfloat16)
+    fr = ZipNN(input_format="torch").compress(t)
+    back = ZipNN(input_format="torch").decompress(torch.frombuffer(bytearray(bytes(fr)), dtype=torch.uint8))
+    assert back.shape == t.shape and torch.equal(back, t)
+    big = torch.zeros((1,) * 20 + (4,), dtype=torch.float32)
+    fb = ZipNN(input_format="torch").compress(big)
+    assert ZipNN(input_format="torch").decompress(fb).shape == big.shape
+
+
+def test_safe_open_without_with_closes_its_host_handle(use_simt, tmp_path):
+    """SafeOpen opens a second, host-side handle for device reads; used without `with` it was never closed."""
+    import gc
+    import torch
+    from safetensors.torch import save_file
+    from zipnn_amd import zipnn as Z
+    from zipnn_amd.safetensors_io import compress_safetensors_file
+    src = tmp_path / "m.safetensors"
+    save_file({"w": (torch.randn(70_000) * 0.02).to(torch.bfloat16)}, str(src))
+    out = compress_safetensors_file(str(src))
+    f = Z.SafeOpen(out, framework="pt", device="cpu")
+    f._device = "meta-not-cpu"          # force the second handle the way device="cuda:0" would (no GPU here)
+    h = f._host_reader()
+    assert f._host is h and h is not f._f
+    closed = []
+    real_exit = h.__exit__
+    class Spy:
+        def __init__(self, inner): self.inner = inner
+        def __exit__(self, *a): closed.append(1); return real_exit(*a)
+        def __getattr__(self, n): return getattr(self.inner, n)
+    f._host = Spy(h)
+    del f
+    gc.collect()
+    assert closed == [1]
+
+
+def test_reference_produced_checkpoint_through_emulated_kernels(use_simt):
+    """The reference-produced GPT-2-shaped checkpoint (tests/golden/make_golden_safetensors.py) through the plugin and
+    load_file on the emulated kernels — the CPU half of tests/test_gpu_parity.py's hardware test of the same file."""
+    import hashlib
+    import json
+    import safetensors
+    import safetensors.torch
+    import torch
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gpt2_small_ref.znn.safetensors")
+    info = json.load(open(path + ".json"))
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == info["file_sha256"]
+    sha = lambda t: hashlib.sha256(t.contiguous().view(torch.uint8).numpy().tobytes()).hexdigest()   # noqa: E731
+    loaded = safetensors_io.load_file(path, device="cpu")
+    assert {k: sha(v) for k, v in loaded.items()} == {k: m["sha256"] for k, m in info["tensors"].items()}
+    orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
+    try:
+        zipnn_safetensors()
+        with safetensors.safe_open(path, framework="pt", device="cpu") as f:
+            assert len(f.compressed_tensors_metadata) >= 10
+            for k, m in info["tensors"].items():
+                t = f.get_tensor(k)
+                assert str(t.dtype) == m["dtype"] and list(t.shape) == m["shape"] and sha(t) == m["sha256"], k
+    finally:
+        safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+        from zipnn_amd import zipnn as _Z
+        _Z._patches_applied.pop(_Z._zipnn_safetensors, None)      # (the patcher applies a patch once per process, like the reference's: let the next test apply it again)

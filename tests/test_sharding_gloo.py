@@ -1,7 +1,7 @@
 """CPU tests (-m "not gpu") of the N>1 path: chunk ranges shard across ranks with no data-path
-collective.  world_size-2 gloo processes each code their own chunk range (the oracle stands in for the
-GPU codec here — this test is about the sharding arithmetic and the process plumbing); the merged
-frame must be byte-identical to the single-rank frame, and split bodies must decode independently."""
+collective.  world_size-2 gloo processes each code their own chunk range with the PRODUCT's kernels and C ABI
+(the SIMT-emulated build, tests/simt/libzipnn_simt.so — there is no GPU here); the oracle is only the checker: the
+merged frame must be byte-identical to the single-rank oracle frame, and split bodies must decode independently."""
 import os
 import sys
 
@@ -27,7 +27,11 @@ def _worker(rank, world, port, case, q):
     K = (nb + C - 1) // C
     lo, hi = sharding.chunk_ranges(K, world)[rank]
     mine = data[lo * C: min(hi * C, nb)]
-    body = O.compress_frame(b"", mine, P, rot, bm, C) if hi > lo else b""
+    from zipnn_amd._capi import ZnLib
+    lib = ZnLib(os.path.join(os.path.dirname(os.path.abspath(__file__)), "simt", "libzipnn_simt.so"))   # the product's kernels, emulated
+    body = bytes(lib.compress(b"", mine, P, rot, bm, C, 0.95)) if hi > lo else b""
+    if hi > lo:                                   # and the rank's own body decodes back with the same library
+        assert bytes(lib.decompress(body, P, rot, bm, C, len(mine))) == mine
     # metadata-only exchange: every rank learns every body length (no payload collective on the data path)
     lens = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(lens, torch.tensor([len(body)], dtype=torch.int64))
@@ -37,8 +41,8 @@ def _worker(rank, world, port, case, q):
 
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[0]}-{c[1]}")
-def test_two_ranks_merge_to_single_rank_frame(case):
-    kind, nb, P, rot, bm = case
+def test_two_ranks_merge_to_single_rank_frame(case, simt_lib):
+    kind, nb, P, rot, bm = case          # (simt_lib: builds the emulated library before the ranks start)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() + nb) % 2000

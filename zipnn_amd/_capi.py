@@ -129,8 +129,12 @@ class ZnLib:
         dl = _as_c_buffer(memoryview(delta).cast("B")) if delta is not None else None
         if dl is not None and memoryview(delta).nbytes != n:
             raise ValueError("delta buffer and data differ in length")
-        rc = self._L.zn_compress_delta(ctypes.addressof(hb), hv.nbytes, src.addr, dl.addr if dl else None, n, num_buf, bits_mode,
-                                       bytes_mode, chunk, threshold, device, out.ctypes.data, cap, ctypes.byref(out_len))
+        if dl is None:      # the entry point the reference-side binding binds
+            rc = self._L.zn_compress(ctypes.addressof(hb), hv.nbytes, src.addr, n, num_buf, bits_mode, bytes_mode, chunk,
+                                     threshold, device, out.ctypes.data, cap, ctypes.byref(out_len))
+        else:
+            rc = self._L.zn_compress_delta(ctypes.addressof(hb), hv.nbytes, src.addr, dl.addr, n, num_buf, bits_mode,
+                                           bytes_mode, chunk, threshold, device, out.ctypes.data, cap, ctypes.byref(out_len))
         self._check(rc)
         return memoryview(out)[:out_len.value]
 
@@ -143,8 +147,11 @@ class ZnLib:
         dl = _as_c_buffer(memoryview(delta).cast("B")) if delta is not None else None
         if dl is not None and memoryview(delta).nbytes != orig_size:
             raise ValueError("delta buffer and original size differ")
-        rc = self._L.zn_decompress_delta(src.addr, bv.nbytes, dl.addr if dl else None, num_buf, bits_mode, bytes_mode, chunk,
-                                         orig_size, device, out.ctypes.data)
+        if dl is None:
+            rc = self._L.zn_decompress(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, device, out.ctypes.data)
+        else:
+            rc = self._L.zn_decompress_delta(src.addr, bv.nbytes, dl.addr, num_buf, bits_mode, bytes_mode, chunk,
+                                             orig_size, device, out.ctypes.data)
         self._check(rc)
         return memoryview(out)[:orig_size]
 

@@ -82,15 +82,20 @@ def _delta_ptr(delta, like):
     return delta, (delta.data_ptr() if delta.numel() else None)
 
 
-def compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold, delta=None):
+def compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold, delta=None, body=None):
     """flat: uint8 tensor in HBM -> uint8 tensor (same device) holding the frame BODY
     (types ‖ cumSizes ‖ payload).  One 8-byte read-back for the length.
     delta: optional uint8 tensor of the same length — the body then encodes flat ^ delta, the XOR being fused
-    into the kernels that read the tensor (the reference's delta step, zipnn/zipnn.py:625-640)."""
+    into the kernels that read the tensor (the reference's delta step, zipnn/zipnn.py:625-640).
+    body: optional preallocated uint8 buffer on the same device (>= zn_compress_bound bytes) the body is written into —
+    a caller that compresses repeatedly (a checkpoint writer, bench.py) allocates it once; the result is a slice of it."""
     n = flat.numel()
     delta, dptr = _delta_ptr(delta, flat)
     cap = lib.compress_bound(n, num_buf, chunk, 0)
-    body = torch.empty(max(cap, 16), dtype=torch.uint8, device=flat.device)
+    if body is None:
+        body = torch.empty(max(cap, 16), dtype=torch.uint8, device=flat.device)
+    elif body.dtype != torch.uint8 or body.device != flat.device or body.numel() < max(cap, 16) or not body.is_contiguous():
+        raise ValueError("body must be a contiguous uint8 tensor on the same device with at least zn_compress_bound bytes")
     with torch.cuda.device(flat.device) if flat.is_cuda else _nullctx():
         used = lib.compress_dev(flat.data_ptr() if n else 0, n, num_buf, bits_mode, bytes_mode, chunk, threshold,
                                 body.data_ptr(), body.numel(), _stream_handle(flat), delta_ptr=dptr)

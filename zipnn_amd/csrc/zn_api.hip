@@ -7,6 +7,8 @@
 #include "zn_host_pipe.hpp"
 
 #include <mutex>
+#include <thread>
+#include <chrono>
 #include <string>
 #include <vector>
 #include <string.h>
@@ -42,8 +44,20 @@ struct Workspace {
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
 static_assert(WS_COUNT == 12, "Workspace::buf size");
 
-std::mutex g_mu;
+// One lock PER DEVICE (the workspace tables of different devices share nothing): threads that drive different GPUs of a
+// node from one process — north_star's "independent HIP streams" — do not serialise each other.
+std::mutex g_dev_mu[64];
 Workspace g_ws[64];
+
+// the host entry points take a device ordinal: switch to it for the call and leave the caller's current device as it was
+struct DeviceScope {
+  int prev = -1; bool ok = true;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 std::mutex g_host_mu[64];     // serialises the host-buffer entry points of a device (they share two staging buffers)
 
 int ws_reserve(Workspace& w, int slot, size_t bytes) {
@@ -164,7 +178,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   t_kernels.clear();
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
   Workspace& w = g_ws[dev];
   int rc;
   const size_t nseg_all = segs[0].size() + segs[1].size() + segs[2].size();
@@ -292,7 +306,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   t_kernels.clear();
-  std::lock_guard<std::mutex> lk(g_mu);
+  std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
   Workspace& w = g_ws[dev];
   int rc;
   const size_t nseg_all = segs[0].size() + segs[1].size() + segs[2].size();
@@ -378,7 +392,8 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
                       int bytes_mode, size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
   if (!dst_len || (hdr_len && !hdr) || (n && !src) || !dst) return ZN_E_ARG;
   if (zn_device_count() <= 0) return ZN_E_NODEV;
-  ZN_HIP(hipSetDevice(device));
+  DeviceScope scope(device);              // (restored on every return path)
+  if (!scope.ok) { t_hip_err = "hipSetDevice"; return ZN_E_HIP; }
   const size_t bound = zn_compress_bound(n, num_buf, chunk, 0);
   // device staging for host buffers: cached with the workspace (grow-only), one host-path call at a time per device
   int dev = 0;
@@ -387,7 +402,7 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
   std::lock_guard<std::mutex> hk(g_host_mu[dev]);
   void* d_src = nullptr; void* d_body = nullptr; void* d_delta = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
     int rc0;
     if (delta && n) { if ((rc0 = ws_reserve(w, WS_HOST_DELTA, n))) return rc0; d_delta = w.buf[WS_HOST_DELTA]; }
@@ -421,14 +436,15 @@ int zn_decompress_delta(const void* body, size_t body_len, const void* delta, in
                         size_t orig_size, int device, void* dst) {
   if ((body_len && !body) || (orig_size && !dst)) return ZN_E_ARG;
   if (zn_device_count() <= 0) return ZN_E_NODEV;
-  ZN_HIP(hipSetDevice(device));
+  DeviceScope scope(device);              // (restored on every return path)
+  if (!scope.ok) { t_hip_err = "hipSetDevice"; return ZN_E_HIP; }
   int dev = 0;
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   std::lock_guard<std::mutex> hk(g_host_mu[dev]);
   void* d_body = nullptr; void* d_dst = nullptr; void* d_delta = nullptr;
   {
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
     int rc0;
     if (delta && orig_size) { if ((rc0 = ws_reserve(w, WS_HOST_DELTA, orig_size))) return rc0; d_delta = w.buf[WS_HOST_DELTA]; }
@@ -458,7 +474,7 @@ long long zn_last_fused_chunks(void) {
     int dev = 0;
     ZN_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return ZN_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
     if (!w.last_K || !w.buf[WS_META_B]) return 0;
     std::string flags(w.last_K, '\0');
@@ -475,7 +491,7 @@ long long zn_last_tail_planes(void) {
     int dev = 0;
     ZN_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return ZN_E_ARG;
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
     if (!w.last_tails || !w.buf[WS_META_A]) return 0;
     std::string flags(w.last_tails, '\0');
@@ -503,11 +519,24 @@ static int zn_copy_host(void* d, void* h, size_t n, bool to_device) {
 int zn_copy_to_device(void* d_dst, const void* src, size_t n) { return zn_copy_host(d_dst, const_cast<void*>(src), n, true); }
 int zn_copy_to_host(void* dst, const void* d_src, size_t n) { return zn_copy_host(const_cast<void*>(d_src), dst, n, false); }
 
+#if defined(ZN_SIMT_EMULATOR)
+// test hook of the emulated build (tests/test_kernels_simt.py): holds one device's workspace lock for `ms` milliseconds,
+// so that a test can show that calls on ANOTHER device do not wait for it and calls on the same one do
+int zn_debug_hold_device_lock(int dev, int ms) {
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+  std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+  return ZN_OK;
+}
+#endif
+
 int zn_release_workspace(void) {
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
   for (int d = 0; d < 64; d++) {
     // same order as the host-buffer entry points: the device's host lock (its bounce buffers may be in use), then the table
     std::lock_guard<std::mutex> hk(g_host_mu[d]);
-    std::lock_guard<std::mutex> lk(g_mu);
+    std::lock_guard<std::mutex> lk(g_dev_mu[d]);
     Workspace& w = g_ws[d];
     bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
@@ -520,6 +549,7 @@ int zn_release_workspace(void) {
     zn_host_pipe_release(w.pipe);
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
   }
+  if (prev >= 0) (void)hipSetDevice(prev);
   return ZN_OK;
 }
 

@@ -25,19 +25,30 @@ __device__ __forceinline__ ZnSeg zn_find_seg(const ZnSeg& one, const ZnSeg* __re
 // ---------------------------------------------------------------------------
 struct ZnPcMeta { uint64_t off; uint32_t csize; uint32_t plen; uint32_t type; uint32_t ok; };
 
+// Everything here comes out of an untrusted frame: every sum is checked against what is left of the body BEFORE it
+// is formed, so that no crafted cumSizes entry can wrap the 64-bit arithmetic and move `off` outside [0, body_len)
+// (a plane total of 2^64 - 9PK - 4096 used to give the next plane a base 4096 bytes before the body).
 __device__ inline ZnPcMeta zn_pc_meta(const ZnGeom& g, const uint8_t* body, uint64_t body_len, uint32_t p, uint64_t c) {
   ZnPcMeta m;
   const uint64_t PK = (uint64_t)g.P * g.K;
   const uint8_t* cum = body + PK;                       // u64 [P][K], inclusive, unaligned
+  bool ok = (PK <= body_len / 9u);                      // types + cumSizes fit
   uint64_t base = 9u * PK;                              // payload start
-  for (uint32_t q = 0; q < p; q++) base += zn_ld64(cum + 8u * ((uint64_t)q * g.K + g.K - 1));
-  const uint64_t hi = zn_ld64(cum + 8u * ((uint64_t)p * g.K + c));
-  const uint64_t lo = c ? zn_ld64(cum + 8u * ((uint64_t)p * g.K + c - 1)) : 0;
-  m.type = body[(uint64_t)p * g.K + c];
+  for (uint32_t q = 0; q < p && ok; q++) {
+    const uint64_t t = zn_ld64(cum + 8u * ((uint64_t)q * g.K + g.K - 1));   // total of plane q
+    if (t > body_len - base) ok = false; else base += t;
+  }
+  uint64_t hi = 0, lo = 0;
+  if (ok) {
+    hi = zn_ld64(cum + 8u * ((uint64_t)p * g.K + c));
+    lo = c ? zn_ld64(cum + 8u * ((uint64_t)p * g.K + c - 1)) : 0;
+    ok = (hi >= lo) && (hi - lo <= 0xFFFFFFFFull) && (hi <= body_len - base);
+  }
+  m.type = ok ? body[(uint64_t)p * g.K + c] : 0xFFu;
   m.plen = zn_plane_len(zn_chunk_len(g, c), g.P, p);
-  m.ok = (hi >= lo) && (hi - lo <= 0xFFFFFFFFull) && (base + hi <= body_len);
-  m.csize = (uint32_t)(hi - lo);
-  m.off = base + lo;
+  m.ok = ok ? 1u : 0u;
+  m.csize = ok ? (uint32_t)(hi - lo) : 0u;
+  m.off = ok ? base + lo : 0u;
   return m;
 }
 

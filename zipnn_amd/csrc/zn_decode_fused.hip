@@ -42,6 +42,7 @@
 // dtype16.c:145-216, data_manipulation_dtype32.c:275-294,391-456).
 #include "zn_internal.hpp"
 #include <cstdlib>
+#include <atomic>
 #include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
 
@@ -879,11 +880,15 @@ extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
 // chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
 // outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
 uint32_t zn_decode_fused_group(uint64_t K) {
-  static int slots = 0;
+  static std::atomic<int> slots_of[64];          // per device (a node may mix parts); 0 = not asked yet
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+  int slots = slots_of[dev].load(std::memory_order_relaxed);
   if (slots == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
     slots = cus * ZN_F_WAVES_PER_SIMD;
+    slots_of[dev].store(slots, std::memory_order_relaxed);     // (racing first calls store the same value)
   }
   uint32_t ncg = (uint32_t)(K / (uint64_t)slots);
   ncg = ncg > 4u ? 4u : (ncg < 1u ? 1u : ncg);

@@ -145,7 +145,7 @@ class ZipNN:
         """Header fields of a compressed file / buffer as a dict (reference zipnn.py:497-553)."""
         if isinstance(file, str):
             with open(file, "rb") as f:
-                mv = memoryview(f.read(HEADER_LEN + 80))
+                mv = memoryview(f.read(HEADER_LEN + 1 + 9 * 255))    # header + the largest possible shape extension
         else:
             mv = memoryview(file)
         h = mv[:HEADER_LEN]
@@ -319,6 +319,11 @@ class ZipNN:
         elif delta_second_data is not None:
             raise ValueError("ZipNN isn't set for delta compression, but delta_second_data is not null.")
 
+        if isinstance(data, torch.Tensor) and not (data.is_cuda and not delta_second_data and self.input_format != EnumFormat.BYTE.value):
+            # a frame handed over as a tensor: only the device-resident fast path (a CUDA frame, no second buffer, TORCH /
+            # NUMPY result) works on the tensor itself; every other case (delta, streaming blobs of BYTE frames) takes the
+            # host-bytes route — the reference only ever sees bytes here (zipnn.py:928-1005)
+            data = data.detach().cpu().contiguous().view(torch.uint8).reshape(-1).numpy()
         if isinstance(data, torch.Tensor):
             mv = None
             was_delta, stream_byte = int(data[9]), int(data[13])
@@ -407,7 +412,12 @@ class ZipNN:
     def frame_params(self, frame):
         """Parse one frame's header -> what the C ABI needs to decode its body (no data work):
         dict(body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape)."""
-        head = bytes(frame[:HEADER_LEN + 80].cpu().numpy()) if isinstance(frame, torch.Tensor) else bytes(memoryview(frame)[:HEADER_LEN + 80])
+        # header + shape extension: 1 byte ndim, then per dim a width byte and ≤ 8 bytes (header.pack_shape) — read what
+        # this frame's ndim needs, not a fixed window (a 12-dimensional shape does not fit 80 bytes)
+        def _take(a, b):
+            return bytes(frame[a:b].cpu().numpy()) if isinstance(frame, torch.Tensor) else bytes(memoryview(frame)[a:b])
+        nd = _take(HEADER_LEN, HEADER_LEN + 1)
+        head = _take(0, HEADER_LEN + 1 + 9 * (nd[0] if nd else 0))
         body_off = self._retrieve_header(head)
         dt = dtype_from_code(self.dtype)
         chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
@@ -418,7 +428,11 @@ class ZipNN:
         """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198).  delta (BYTE format): second buffer
         of the original length, XORed into the output on the device."""
         on_device = isinstance(frame, torch.Tensor) and frame.is_cuda
-        head = bytes(frame[:HEADER_LEN + 80].cpu().numpy()) if isinstance(frame, torch.Tensor) else frame
+        if isinstance(frame, torch.Tensor):       # (the header and a shape extension sized from its ndim byte: 1 + 9 per dim)
+            nd = int(frame[HEADER_LEN]) if frame.numel() > HEADER_LEN else 0
+            head = bytes(frame[:HEADER_LEN + 1 + 9 * nd].cpu().numpy())
+        else:
+            head = frame
         body_off = self._retrieve_header(head)
         dt = dtype_from_code(self.dtype)
         if self.input_format == EnumFormat.NUMPY.value and dt.numpy is None:
@@ -556,11 +570,20 @@ class SafeOpen:
         self._f.__enter__()
         return self
 
+    def _close_host(self, *exc):
+        host, self._host = getattr(self, "_host", None), None
+        if host is not None:
+            try:
+                host.__exit__(*(exc or (None, None, None)))
+            except Exception:
+                pass
+
     def __exit__(self, exc_type, exc_value, traceback):
-        if self._host is not None:
-            self._host.__exit__(exc_type, exc_value, traceback)
-            self._host = None
+        self._close_host(exc_type, exc_value, traceback)
         return self._f.__exit__(exc_type, exc_value, traceback)
+
+    def __del__(self):          # (used without `with`: the second, host-side handle must not outlive the object)
+        self._close_host()
 
     def __getattr__(self, name):
         return getattr(self._f, name)
