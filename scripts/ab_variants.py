@@ -31,7 +31,12 @@ VARIANTS = {
     "new": (None, []),
     "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
     "prio0": (None, ["-DZN_F_PRIO_SYNC=0", "-DZN_F_PRIO_COUNT=0", "-DZN_F_PRIO_WRITE=0"]),
-    "fip2": (None, ["-DZN_F_FETCH_IN_PASS2=1"]),
+    "early": (None, ["-DZN_F_EARLY_ROWS=1"]),
+    "plainld": (None, ["-DZN_F_NT_LOADS=0"]),
+    "pad": (None, ["-DZN_F_IN_PAD=1"]),
+    "p2m0": (None, ["-DZN_F_P2_MASK=0"]),
+    "m64": (None, ["-DZN_F_ROW_MARGIN=64u"]),
+    "m320": (None, ["-DZN_F_ROW_MARGIN=320u"]),
     "nopass2": (None, ["-DZN_F_ABL=1"]),
     "noraw": (None, ["-DZN_F_ABL=2"]),
     "nostore": (None, ["-DZN_F_ABL=4"]),

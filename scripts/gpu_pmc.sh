@@ -13,7 +13,7 @@ for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_INSTS_FLAT" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --kernel-trace --pmc $SET -d "$OUT/p$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --gib ${GIB:-1} > "$OUT/p$i.log" 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc $SET -d "$OUT/p$i" -o pmc -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-other-dtypes --gib ${GIB:-1} > "$OUT/p$i.log" 2>&1
   tail -2 "$OUT/p$i.log" | cut -c1-300
 done
 python "$R/scripts/pmc_summary.py" "$OUT" | tee "$OUT/summary.txt"

@@ -60,7 +60,12 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
-#define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
+#ifndef ZN_F_IN_PAD
+#define ZN_F_IN_PAD 0                    // 1: one dword of padding per 32 in the stream-tile buffer (see ZN_IN_IDX)
+#endif
+// dwords 0 (look-ahead below the tile) .. 64 D (its top): 64 D + 1 entries, padded index of the last one + 1, + 1 spare —
+// not a dword more: the structure is 40 944 bytes, four workgroups per CU need ≤ 40 960
+#define ZN_F_IN_DW (ZN_F_IN_PAD ? (64 * ZN_F_DMAX + (64 * ZN_F_DMAX) / 32 + 2) : (64 * ZN_F_DMAX + 4))
 #ifndef ZN_F_TF
 #define ZN_F_TF(D) ((D) * 4 + 1)         // whole-group step slots of the register-resident decode for a sub-block of D dwords
 #endif
@@ -96,6 +101,7 @@
 #endif
 #if !defined(ZN_SIMT_EMULATOR)
 #define ZN_OPAQUE32(x) asm volatile("" : "+v"(x))
+#define ZN_KEEP32(x) asm volatile("" :: "v"(x))        // a use the compiler cannot remove (keeps a loaded-and-ignored value's register until here)
 // (a & mask) | (b & ~mask) as ONE v_bfi_b32: left to itself the compiler simplifies the masked shift first and
 // then needs and + and + or for the second of the two (seen in the ISA of the un-rotate: 8 VALU per dword pair)
 __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t b) {
@@ -108,6 +114,7 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
 #define ZN_NO_IFCVT ((void)0)
 #define ZN_ASM_MARK(txt) ((void)0)
 #define ZN_OPAQUE32(x) ((void)0)
+#define ZN_KEEP32(x) ((void)(x))
 #define ZN_BFI(mask, a, b) ((((uint32_t)(a)) & (uint32_t)(mask)) | (((uint32_t)(b)) & ~(uint32_t)(mask)))
 #endif
 #ifndef ZN_F_ABL
@@ -130,9 +137,14 @@ extern "C" void zn_debug_tile_counters(unsigned long long* out, int reset) { for
 #define ZN_DBG_COUNT(i) do { } while (0)
 #endif
 
-// stream-tile dword i lives at in[ZN_IN_IDX(i)] (a padded layout against bank conflicts of the strided walk
-// was measured: no gain, the kernel is issue-bound — identity)
+// stream-tile dword i lives at in[ZN_IN_IDX(i)].  Lane k walks its sub-block of D dwords, so the 32 lanes of a half-wave read
+// with a stride of D dwords: D = 4 puts them on 8 banks, a 4-way conflict on every window refill (two dwords each) — as
+// much LDS time as all of a tile's LUT look-ups.  One dword of padding per 32 spreads a stride of 2, 4 or 8 over all banks.
+#if ZN_F_IN_PAD
+#define ZN_IN_IDX(i) ((i) + ((i) >> 5))
+#else
 #define ZN_IN_IDX(i) (i)
+#endif
 
 // 16-byte output store, non-temporal: the output is written once and never read back by this kernel
 #if !defined(ZN_SIMT_EMULATOR)
@@ -149,6 +161,17 @@ template <typename T> __device__ __forceinline__ T* zn_uniform_ptr(T* p) { retur
 
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
+// the payload is read once: streaming (non-temporal) loads for the raw planes and the stream tiles
+#ifndef ZN_F_NT_LOADS
+#define ZN_F_NT_LOADS 1
+#endif
+#if ZN_F_NT_LOADS && !defined(ZN_SIMT_EMULATOR)
+#define ZN_LD_RAW64(p) __builtin_nontemporal_load((const zn_u64u*)(p))
+#define ZN_LD_STREAM32(p) __builtin_nontemporal_load((const uint32_t*)(p))
+#else
+#define ZN_LD_RAW64(p) (*(const zn_u64u*)(p))
+#define ZN_LD_STREAM32(p) (*(const uint32_t*)(p))
+#endif
 
 struct ZnFusedPlane { uint64_t off; uint32_t kind; uint32_t csize; };   // off: body offset (RAW/HUF) or byte value (RLE)
 
@@ -251,7 +274,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       for (int k = 0; k < EW; k++) pre[r][p][k] = (uint32_t)(uint64_t)a;
       continue;
 #endif
-      for (int k = 0; k < EW / 2; k++) { const uint64_t t = *(const zn_u64u*)(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
+      for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
     }
   };
   auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
@@ -358,6 +381,10 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
   int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
   int nmis = 0;                               // tiles of this stream that needed a fix-up since the run-in was last lengthened
+  uint32_t n_prev = 0;                        // symbols the previous tile decoded to (predicts this tile's rows; 0: no early request)
+#ifndef ZN_F_ROW_MARGIN
+#define ZN_F_ROW_MARGIN 160u                // the prediction's safety margin, in symbols (a tile is ~3100 ± 2 %)
+#endif
 
   // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D-1, and (lane 0) the
   // tile's last dword, in a register of its own so that nothing selects on a loaded value before the staging
@@ -369,7 +396,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     const uint32_t* p = gdw + (lo_dw_ - 1) + (int32_t)lane;
     if (lo_dw_ >= 0 && !(top_guard && hi_dw_ - 1 == top_dw)) {
       // common case: every dword of the tile exists in the buffer
-      for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? p[64 * i] : 0u;
+      for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? ZN_LD_STREAM32(p + 64 * i) : 0u;
       nx_last = gdw[__builtin_amdgcn_readfirstlane(hi_dw_) - 1];   // (every lane, the same address: no select on the way into the register)
     } else {
       auto dword_at = [&](int32_t li) -> uint32_t {
@@ -444,6 +471,28 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     stage_tile();
 #endif
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
+#ifndef ZN_F_EARLY_ROWS
+#define ZN_F_EARLY_ROWS 0                // 1: request the raw-plane rows this tile will PROBABLY complete at the top of the tile (0: all of them after the decode pass)
+#endif
+    // The raw-plane rows of this tile's flush can only be counted once the tile is decoded, a compaction's length before
+    // they are needed: at 5 TB/s the HBM latency is several thousand cycles and most of it was exposed in the flush's wait
+    // (dropping the memory operations: -22 %, profiles/r02_decode_experiments.txt).  A stream's tiles decode to nearly the
+    // same number of symbols, so the rows this tile will complete are predicted from the previous tile's count (minus a
+    // margin) and requested NOW, a whole decode pass ahead; what the prediction misses is requested after the pass as
+    // before, a row it over-predicts is simply not used (and read again next tile).  Their registers are live through the
+    // decode pass, which does not raise the peak: that is the start of the compaction either way.
+    int rows_early = 0;
+    if (ZN_F_EARLY_ROWS && TF > 0 && H >= 0) {
+      const uint32_t base0 = zn_uniform(J - JF);
+      const uint32_t guess = n_prev > ZN_F_ROW_MARGIN ? n_prev - ZN_F_ROW_MARGIN : 0u;
+      uint32_t re = (base0 + guess) / UNIT;
+      const uint32_t room = (seg - zn_uniform(JF)) / UNIT;                 // rows left in this quarter
+      re = re > (uint32_t)RB ? (uint32_t)RB : re; re = re > room ? room : re;
+      rows_early = (int)zn_uniform(re);
+      fetch_rows(JF, rows_early);
+    }
+    // (tried, r02: touching the raw-plane lines this tile's flush will need — one dword per 128-byte line, at the top of
+    //  the tile, so that the loads proper hit the L2 — made the kernel 8 % SLOWER: profiles/r02_decode_experiments.txt)
     ZN_PT(4);   // stage tile
     const int32_t base_bit = 32 * (lo_dw - 1);
     const int32_t hi_k = 32 * (hi_dw - (int32_t)lane * Di), lo_k = hi_k - 32 * Di;
@@ -487,15 +536,19 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         if (!active) n = 0;
         uint32_t N = 0;
         const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
+        // (J, JF and everything derived from them are wave-uniform; the compiler loses that across the loop — as per-lane
+        //  values every `r < rows` below becomes an exec-mask dance of six scalar instructions instead of one compare-and-branch)
+        J = zn_uniform(J); JF = zn_uniform(JF);
         const uint32_t base = J - JF;                            // < UNIT
         if (J + N <= seg && base + N <= ZN_F_RING_BYTES - 4u) {
           const uint32_t nact = (uint32_t)__popcll(__ballot(active));
           carry = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u)); hi_dw = lo_dw;
           // rows that will be complete after this tile: request their raw bytes now, use them after the compaction
-          int rows = (int)((base + N) / UNIT);
+          int rows = (int)zn_uniform((base + N) / UNIT);
           const uint32_t total_rows = (uint32_t)rows;
           const int first = rows < RB ? rows : RB;
-          fetch_rows(JF, first);
+          for (int r = 0; r < RB; r++) if (r >= rows_early && r < first) fetch_row(JF, r);      // what the early request did not cover
+          n_prev = N;
           ZN_PT(8);   // scans / shuffles / issue loads
           ZN_PRIO(ZN_F_PRIO_WRITE);
           if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB>(ring, base + o_k, rec, nfull, nbnd, [](auto) {});   // (lanes without a sub-block hold zero records)
@@ -716,6 +769,7 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
 #ifndef ZN_F_XWAVES
 #define ZN_F_XWAVES ZN_F_WAVES_PER_SIMD
 #endif
+static_assert(sizeof(ZnFusedLds) * ZN_F_WAVES_PER_SIMD <= 160u * 1024u, "ZnFusedLds: the LDS budget of ZN_F_WAVES_PER_SIMD workgroups per CU");
 template <int P, bool X>
 __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
