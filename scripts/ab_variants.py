@@ -35,6 +35,9 @@ VARIANTS = {
     "plainld": (None, ["-DZN_F_NT_LOADS=0"]),
     "pad": (None, ["-DZN_F_IN_PAD=1"]),
     "p2m0": (None, ["-DZN_F_P2_MASK=0"]),
+    "nosplit": (None, ["-DZN_F_FETCH_SPLIT=0"]),
+    "rb8": (None, ["-DZN_F_RB2=8"]),
+    "rb6": (None, ["-DZN_F_RB2=6"]),
     "m64": (None, ["-DZN_F_ROW_MARGIN=64u"]),
     "m320": (None, ["-DZN_F_ROW_MARGIN=320u"]),
     "nopass2": (None, ["-DZN_F_ABL=1"]),

@@ -154,6 +154,11 @@ typedef uint32_t zn_v4u __attribute__((ext_vector_type(4)));
 #define ZN_ST128(p, a, b, c, d) (*(uint4*)(p) = make_uint4((a), (b), (c), (d)))
 #endif
 
+#if defined(ZN_SIMT_EMULATOR)
+__device__ __forceinline__ uint32_t zn_lane_id() { return threadIdx.x & 63u; }
+#else
+__device__ __forceinline__ uint32_t zn_lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+#endif
 // wave-uniform values the compiler cannot see as such (v_readfirstlane → scalar registers)
 __device__ __forceinline__ uint32_t zn_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t zn_uniform64(uint64_t v) { return ((uint64_t)zn_uniform((uint32_t)(v >> 32)) << 32) | zn_uniform((uint32_t)v); }
@@ -233,11 +238,12 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
 template <int P, int H, int DC, bool X = false>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* outq_, const uint8_t* xq_, const ZnFusedPlane (&pl_)[P], const uint8_t* const (&rawq_)[P],
-                                              const uint2* lut, uint32_t* ring, uint32_t* in, uint32_t lane, uint32_t seg_,
+                                              const uint2* lut, uint32_t* ring, uint32_t* in, uint32_t lane_, uint32_t seg_,
                                               uint32_t TL_, uint32_t Du, const uint8_t* stream_, uint32_t slen_, bool ragged ZN_PT_PARAM) {
   // Everything the caller hands over is the same in all 64 lanes, but most of it came through LDS or was derived from
   // threadIdx, which makes it per-lane data to the compiler: vector registers, and exec-masked control flow around every
   // branch that depends on it (the tile loop, the choice of the decode form).  Say that it is uniform.
+  uint32_t lane = lane_;                       // (recomputed at the top of every tile: two v_mbcnt instead of a register that lives — or is spilled — across the whole loop)
   uint8_t* const outq = zn_uniform_ptr(outq_); const uint8_t* const xq = zn_uniform_ptr(xq_);
   const uint8_t* const stream = zn_uniform_ptr(stream_);
   const uint32_t seg = zn_uniform(seg_), TL = zn_uniform(TL_), slen = zn_uniform(slen_);
@@ -254,8 +260,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #ifndef ZN_F_RB4
 #define ZN_F_RB4 2
 #endif
+  // (two planes: 4 rows per batch, a tile's ~6 rows in two batches.  8 rows — one batch — keeps 16 more registers in flight
+  //  through the compaction; every build of that variant spilled somewhere in the tile loop and ran between 1.61 and 2.2 ms
+  //  on the 4 GiB config depending on where, 4 rows ran 1.60 ms three builds in a row: profiles/r02_decode_experiments.txt)
 #ifndef ZN_F_RB2
-#define ZN_F_RB2 (ZN_F_RING_BYTES / 512u)
+#define ZN_F_RB2 4
 #endif
   constexpr int RB = (P == 2) ? (int)ZN_F_RB2 : (P == 4) ? ZN_F_RB4 : (int)(ZN_F_RING_BYTES / 1024u);
   // register-resident decode (zn_pass1 / zn_pass2): slots for whole-group steps / boundary steps, unchecked head.
@@ -267,9 +276,16 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
   uint32_t pre[RB][P][EW];
+  // the lane index as the HBM address computations see it: made opaque once per tile (below), so that the compiler cannot
+  // hoist `base pointer + lane` out of the tile loop as 64-bit per-lane pointers — loop-invariant, so it did, one pair of
+  // registers per stream / plane / output, and then spilled them and reloaded them behind an s_waitcnt vmcnt(0)
+  uint32_t lane_v = lane;
   auto fetch_row = [&](uint32_t first_row_sym, int r) {
     for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
-      const uint8_t* a = rawq[p] + first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
+      // (a wave-uniform base + a 32-bit lane offset: the compiler then addresses with a scalar base register and one vector
+      //  offset instead of keeping — and spilling — a 64-bit pointer per lane and row)
+      const uint8_t* au = rawq[p] + (first_row_sym + (uint32_t)r * UNIT);
+      const uint8_t* a = au + (uint32_t)EPL * lane_v;
 #if ZN_F_ABL & 2
       for (int k = 0; k < EW; k++) pre[r][p][k] = (uint32_t)(uint64_t)a;
       continue;
@@ -324,8 +340,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     for (int r = 0; r < RB; r++) if (r < nrows) {
       if (X && r % XG == 0 && r + XG < RB) load_delta(r / XG + 1);
       const uint32_t* xr_ = xd[(r / XG) & 1][r % XG];
-      const uint32_t si = first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane;
-      uint8_t* o = outq + (uint64_t)si * P;
+      uint8_t* o = (outq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT) * P) + (uint32_t)EPL * lane_v * (uint32_t)P;   // (uniform base + lane offset)
       if (P == 1) {
         if (X) ZN_ST128(o, pre[r][0][0] ^ xr_[0], pre[r][0][1 % EW] ^ xr_[1 % XW], pre[r][0][2 % EW] ^ xr_[2 % XW], pre[r][0][3 % EW] ^ xr_[3 % XW]);
         else ZN_ST128(o, pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
@@ -393,10 +408,10 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t top_dw = hi_dw - 1;
   const bool top_guard = ((const uint8_t*)(gdw + hi_dw) > body_end);
   auto fetch_tile = [&](int32_t lo_dw_, int32_t hi_dw_) {
-    const uint32_t* p = gdw + (lo_dw_ - 1) + (int32_t)lane;
+    const uint32_t* pu = gdw + (lo_dw_ - 1);               // wave-uniform (scalar registers); the lane index is the vector offset
     if (lo_dw_ >= 0 && !(top_guard && hi_dw_ - 1 == top_dw)) {
       // common case: every dword of the tile exists in the buffer
-      for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? ZN_LD_STREAM32(p + 64 * i) : 0u;
+      for (int i = 0; i < ZN_F_DMAX; i++) nx[i] = (i < Di) ? ZN_LD_STREAM32(pu + (lane_v + 64u * (uint32_t)i)) : 0u;
       nx_last = gdw[__builtin_amdgcn_readfirstlane(hi_dw_) - 1];   // (every lane, the same address: no select on the way into the register)
     } else {
       auto dword_at = [&](int32_t li) -> uint32_t {
@@ -465,6 +480,14 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   bool ok = true;
   while (32 * hi_dw > b0) {
     if (DC) ZN_ASM_MARK("ZN_HOT_TILE_BEGIN");
+    // the stream position and the counters are wave-uniform; said once per tile, because across the two tile forms and
+    // the fix-up loop the compiler takes them for per-lane values: vector registers (the 64-bit stream pointer among them,
+    // spilled), and an exec-mask region around every branch that depends on them
+    lane = zn_lane_id();
+    lane_v = lane; ZN_OPAQUE32(lane_v);
+    hi_dw = __builtin_amdgcn_readfirstlane(hi_dw); carry = __builtin_amdgcn_readfirstlane(carry);
+    delta = __builtin_amdgcn_readfirstlane(delta); nmis = __builtin_amdgcn_readfirstlane(nmis);
+    J = zn_uniform(J); JF = zn_uniform(JF); n_prev = zn_uniform(n_prev);
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
 #if !ZN_F_EARLY_STAGE
@@ -547,11 +570,24 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           int rows = (int)zn_uniform((base + N) / UNIT);
           const uint32_t total_rows = (uint32_t)rows;
           const int first = rows < RB ? rows : RB;
-          for (int r = 0; r < RB; r++) if (r >= rows_early && r < first) fetch_row(JF, r);      // what the early request did not cover
+#ifndef ZN_F_FETCH_SPLIT
+#define ZN_F_FETCH_SPLIT 1                // 1: request the second half of the flush's raw rows in the middle of the compaction, when half of the record registers are free again
+#endif
+          constexpr int RH = (ZN_F_FETCH_SPLIT && RB >= 4) ? RB / 2 : RB;         // rows requested before the compaction
+          for (int r = 0; r < RH; r++) if (r >= rows_early && r < first) fetch_row(JF, r);      // (what an early request did not cover)
           n_prev = N;
           ZN_PT(8);   // scans / shuffles / issue loads
           ZN_PRIO(ZN_F_PRIO_WRITE);
-          if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB>(ring, base + o_k, rec, nfull, nbnd, [](auto) {});   // (lanes without a sub-block hold zero records)
+          // (uniform — said again here, where they are used: through the fix-up loop the compiler takes the slot counts for
+          //  per-lane values and turns the compaction's `t < nfull` tests into a ten-deep nest of exec-mask regions)
+          const int nf = __builtin_amdgcn_readfirstlane(nfull), nb_ = __builtin_amdgcn_readfirstlane(nbnd);
+          // (lanes without a sub-block hold zero records.)  The raw rows RH.. are requested after step TF/2 - 1: the records of
+          // the steps before it are dead by then, so the rows' registers do not add to the peak at the start of the compaction.
+          bool late_rows = (RH < RB);
+          if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB>(ring, base + o_k, rec, nf, nb_, [&](auto I) {
+            if constexpr (RH < RB && decltype(I)::v == TF / 2 - 1) { for (int r = RH; r < RB; r++) if (r >= rows_early && r < first) fetch_row(JF, r); late_rows = false; }
+          });
+          if (late_rows) for (int r = RH; r < RB; r++) if (r >= rows_early && r < first) fetch_row(JF, r);     // (a tile of fewer steps than that)
           __builtin_amdgcn_wave_barrier();
           ZN_PRIO(0);
           ZN_PT(9);   // compaction

@@ -540,6 +540,12 @@ class SafeOpen:
     arguments newer safetensors releases pass (`backend=`)."""
 
     def __init__(self, filename, framework="pt", device="cpu", **kwargs):
+        self._host = None
+        # `device` as safetensors takes it — "cpu", "cuda:N", an ordinal — plus what torch users write: "cuda", torch.device
+        if isinstance(device, torch.device):
+            device = "cpu" if device.type == "cpu" else f"{device.type}:{device.index if device.index is not None else codec.current_device()}"
+        elif device == "cuda":
+            device = f"cuda:{codec.current_device()}"
         self._device = device
         # compressed tensors are read on the host and decoded on `device`
         self._f = _ORIGINAL_SAFE_OPEN(filename, framework=framework, device=device, **kwargs)
@@ -586,6 +592,8 @@ class SafeOpen:
         self._close_host()
 
     def __getattr__(self, name):
+        if name.startswith("_"):          # (never delegate private names: `_f` itself is looked up here when __init__ failed early)
+            raise AttributeError(name)
         return getattr(self._f, name)
 
 
