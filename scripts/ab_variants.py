@@ -37,6 +37,7 @@ VARIANTS = {
     "p2m0": (None, ["-DZN_F_P2_MASK=0"]),
     "nosplit": (None, ["-DZN_F_FETCH_SPLIT=0"]),
     "rb8": (None, ["-DZN_F_RB2=8"]),
+    "nod6": (None, ["-DZN_F_DCONST2=0"]),
     "rb6": (None, ["-DZN_F_RB2=6"]),
     "m64": (None, ["-DZN_F_ROW_MARGIN=64u"]),
     "m320": (None, ["-DZN_F_ROW_MARGIN=320u"]),
@@ -53,6 +54,7 @@ VARIANTS = {
     "w2": (None, ["-DZN_F_WAVES_PER_SIMD=2"]),
     "tf15": (None, ["-DZN_F_TF(D)=((D)*4-1)"]),     # record slots for whole-group steps (default 4 D + 1)
     "tf19": (None, ["-DZN_F_TF(D)=((D)*4+3)"]),
+    "d16": (None, ["-DZN_F_DELTA0=16"]),
     "d21": (None, ["-DZN_F_DELTA0=21"]),
     "d32": (None, ["-DZN_F_DELTA0=32"]),
     "p2m1": (None, ["-DZN_F_P2_MASK=1"]),

@@ -817,7 +817,15 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 
   if (blockIdx.x < ntail) { zn_decode_tail_wg(L, one, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return; }
   const uint32_t wg = blockIdx.x - ntail;      // workgroup index among the full-chunk groups
-  const ZnSeg S = zn_find_seg<0>(one, segs, nseg, wg);
+  // (the segment comes back through private memory — a kernel argument or a table entry, chosen at run time — which makes
+  //  every field per-lane data to the compiler: 64-bit pointers in vector registers, spilled and reloaded once per chunk,
+  //  0.17 GB of scratch reads per GiB decoded.  They are uniform: scalar registers.)
+  const ZnSeg S_ = zn_find_seg<0>(one, segs, nseg, wg);
+  ZnSeg S;
+  S.g.n = zn_uniform64(S_.g.n); S.g.chunk = zn_uniform64(S_.g.chunk); S.g.K = zn_uniform64(S_.g.K); S.g.P = zn_uniform(S_.g.P); S.g.rot = zn_uniform(S_.g.rot);
+  S.body = (const uint8_t*)zn_uniform64((uint64_t)S_.body); S.body_len = zn_uniform64(S_.body_len); S.dst = (uint8_t*)zn_uniform64((uint64_t)S_.dst);
+  S.chunk0 = zn_uniform64(S_.chunk0); S.desc0 = zn_uniform64(S_.desc0); S.wg0 = zn_uniform(S_.wg0); S.ncg = zn_uniform(S_.ncg);
+  S.tail0 = zn_uniform(S_.tail0); S.has_tail = zn_uniform(S_.has_tail); S.xr = (const uint8_t*)zn_uniform64((uint64_t)S_.xr);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
   uint8_t* __restrict__ dst = ZN_GLOBAL_PTR(uint8_t, S.dst); uint8_t* __restrict__ done = done_all + S.chunk0;
@@ -927,7 +935,12 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
 #define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
-#define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
+#ifndef ZN_F_DCONST2
+#define ZN_F_DCONST2 0                   // a second compile-time sub-block size (0 = none; 6 = what dense codes — fp8, fp16, ~5.4 bits a symbol — use).  Off: its 28 record slots spill in every instance of the kernel, and dense codes need a longer run-in than 22 bits to synchronise (fix-ups in 40-100 % of the tiles: profiles/r02_decode_experiments.txt)
+#endif
+#define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) \
+                            : (ZN_F_DCONST2 && !X && Du == ZN_F_DCONST2) ? zn_fused_wave<P, H_, (X ? 0 : ZN_F_DCONST2), X>(ZN_WAVE_ARGS) \
+                            : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
     // (one instance per Huffman plane index that exists for this P — nothing is instantiated twice)
 #ifdef ZN_F_ONLY_HOT      // (developer probe: the common instance alone, to read its register use off the compiler's remarks)
     if (P == 2) ok = zn_fused_wave<P, (P >= 2 ? 1 : 0), ZN_F_DCONST, X>(ZN_WAVE_ARGS); else
