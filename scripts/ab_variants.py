@@ -37,6 +37,12 @@ VARIANTS = {
     "p2m0": (None, ["-DZN_F_P2_MASK=0"]),
     "nosplit": (None, ["-DZN_F_FETCH_SPLIT=0"]),
     "rb8": (None, ["-DZN_F_RB2=8"]),
+    "nob2": (None, ["-DZN_F_BATCH2_AHEAD=0"]),
+    "rb3nob2": (None, ["-DZN_F_RB2=3", "-DZN_F_BATCH2_AHEAD=0"]),
+    "rb4nob2": (None, ["-DZN_F_RB2=4", "-DZN_F_BATCH2_AHEAD=0"]),
+    "rb2": (None, ["-DZN_F_RB2=2"]),
+    "rb3": (None, ["-DZN_F_RB2=3"]),
+    "rb5": (None, ["-DZN_F_RB2=5"]),
     "nod6": (None, ["-DZN_F_DCONST2=0"]),
     "rb6": (None, ["-DZN_F_RB2=6"]),
     "m64": (None, ["-DZN_F_ROW_MARGIN=64u"]),

@@ -262,9 +262,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #endif
   // (two planes: 4 rows per batch, a tile's ~6 rows in two batches.  8 rows — one batch — keeps 16 more registers in flight
   //  through the compaction; every build of that variant spilled somewhere in the tile loop and ran between 1.61 and 2.2 ms
-  //  on the 4 GiB config depending on where, 4 rows ran 1.60 ms three builds in a row: profiles/r02_decode_experiments.txt)
+  //  on the 4 GiB config depending on where, 4 rows ran 1.60 ms three builds in a row; with the tile loop spill-free 3 rows
+  //  — two even batches for the ~6 rows of a tile — run 1.545 against 1.568 (4), 1.588 (2), 1.581 (5), 1.82 (8):
+  //  profiles/r02_decode_experiments.txt)
 #ifndef ZN_F_RB2
-#define ZN_F_RB2 4
+#define ZN_F_RB2 3
 #endif
   constexpr int RB = (P == 2) ? (int)ZN_F_RB2 : (P == 4) ? ZN_F_RB4 : (int)(ZN_F_RING_BYTES / 1024u);
   // register-resident decode (zn_pass1 / zn_pass2): slots for whole-group steps / boundary steps, unchecked head.
@@ -275,12 +277,14 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   ZN_PT_SHARED;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
-  uint32_t pre[RB][P][EW];
+  // two sets: the second holds the rows of a tile's SECOND flush batch, requested behind the first batch's wait and ahead of
+  // its stores, so that waiting for them is not also a wait for those stores (one in-order counter for loads and stores)
+  uint32_t pre[RB][P][EW], preB[RB][P][EW];
   // the lane index as the HBM address computations see it: made opaque once per tile (below), so that the compiler cannot
   // hoist `base pointer + lane` out of the tile loop as 64-bit per-lane pointers — loop-invariant, so it did, one pair of
   // registers per stream / plane / output, and then spilled them and reloaded them behind an s_waitcnt vmcnt(0)
   uint32_t lane_v = lane;
-  auto fetch_row = [&](uint32_t first_row_sym, int r) {
+  auto fetch_row_to = [&](uint32_t (&pre)[RB][P][EW], uint32_t first_row_sym, int r) {
     for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
       // (a wave-uniform base + a 32-bit lane offset: the compiler then addresses with a scalar base register and one vector
       //  offset instead of keeping — and spilling — a 64-bit pointer per lane and row)
@@ -293,8 +297,12 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
     }
   };
+  auto fetch_row = [&](uint32_t first_row_sym, int r) { fetch_row_to(pre, first_row_sym, r); };
   auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
-    for (int r = 0; r < RB; r++) if (r < nrows) fetch_row(first_row_sym, r);
+    for (int r = 0; r < RB; r++) if (r < nrows) fetch_row_to(pre, first_row_sym, r);
+  };
+  auto fetch_rows_b = [&](uint32_t first_row_sym, int nrows) {
+    for (int r = 0; r < RB; r++) if (r < nrows) fetch_row_to(preB, first_row_sym, r);
   };
   // interleave rows (ring bytes for the Huffman plane, fetched bytes for raw planes) and store them.
   // All loads are complete before the first store is issued, so no store latency is ever waited on.
@@ -302,8 +310,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   // `after_wait` runs right behind the wait, before the first store is issued: whatever else has to consume
   // loaded registers (the staging of the next stream tile) does it there, so that nothing ever waits on a STORE
   // (gfx9 has one in-order counter for loads and stores: a wait for a load issued after stores waits for their acks)
-  auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0, auto&& after_wait) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
+  auto emit_rows_from = [&](uint32_t (&pre)[RB][P][EW], bool full_wait, uint32_t first_row_sym, int nrows, uint32_t stage_row0, auto&& after_wait) {
+    if (full_wait) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every fetched row (and the prefetched tile) has landed
     ZN_PT(10);  // wait for the fetched rows
     after_wait();
     // delta base of these rows, two rows at a time, double-buffered: the next pair is requested before the current
@@ -368,6 +376,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       }
     }
   };
+  auto emit_rows = [&](uint32_t first_row_sym, int nrows, uint32_t stage_row0, auto&& after_wait) { emit_rows_from(pre, true, first_row_sym, nrows, stage_row0, after_wait); };
 
   uint32_t JF = 0;                            // symbols flushed to HBM so far
   if (H < 0) {
@@ -532,9 +541,11 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     bool done = false;
     if (TF > 0) {
       ZN_PRIO(ZN_F_PRIO_SYNC);
+      if (DC) ZN_ASM_MARK("ZN_MARK sync");
       int32_t s = sync_run(base_bit, hi_k, active);
       ZN_PRIO(ZN_F_PRIO_COUNT);
       ZN_PT(5);   // sync run-in
+      if (DC) ZN_ASM_MARK("ZN_MARK pass1");
       ZnRec rec;
       int nfull = 0, nbnd = 0;
       uint32_t acc = 0, n = 0; int32_t e = s;
@@ -555,6 +566,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         if (it == 0) note_mismatch();
         if (mism) s = e_prev;                  // (every lane decodes again: the lanes run in lock-step anyway)
       }
+      if (DC) ZN_ASM_MARK("ZN_MARK scan");
       if (took && chained) {
         if (!active) n = 0;
         uint32_t N = 0;
@@ -578,6 +590,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           n_prev = N;
           ZN_PT(8);   // scans / shuffles / issue loads
           ZN_PRIO(ZN_F_PRIO_WRITE);
+          if (DC) ZN_ASM_MARK("ZN_MARK pass2");
           // (uniform — said again here, where they are used: through the fix-up loop the compiler takes the slot counts for
           //  per-lane values and turns the compaction's `t < nfull` tests into a ten-deep nest of exec-mask regions)
           const int nf = __builtin_amdgcn_readfirstlane(nfull), nb_ = __builtin_amdgcn_readfirstlane(nbnd);
@@ -591,18 +604,30 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           __builtin_amdgcn_wave_barrier();
           ZN_PRIO(0);
           ZN_PT(9);   // compaction
+          if (DC) ZN_ASM_MARK("ZN_MARK flush");
           J += N;
           // (the compaction is over: the stream-tile buffer is free for the next tile, staged behind the flush's wait)
+#ifndef ZN_F_BATCH2_AHEAD
+#define ZN_F_BATCH2_AHEAD 0               // 1: request the second flush batch's raw rows behind the first batch's wait, ahead of its stores
+#endif
+          const int second = (ZN_F_BATCH2_AHEAD && !X) ? ((rows - first) < RB ? (rows - first) : RB) : 0;
           emit_rows(JF, first, 0, [&] {
 #if ZN_F_EARLY_STAGE
             if (32 * hi_dw > b0) stage_tile();
 #endif
+            if (second > 0) fetch_rows_b(JF + (uint32_t)first * UNIT, second);
           });
           uint32_t srow = (uint32_t)first;
           JF += (uint32_t)first * UNIT; rows -= first;
+          if (second > 0) {
+            // (no full wait here: the compiler's own vmcnt(N) for these registers lets the first batch's stores stay in flight)
+            emit_rows_from(preB, false, JF, second, srow, [] {});
+            JF += (uint32_t)second * UNIT; srow += (uint32_t)second; rows -= second;
+          }
           while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
           if (total_rows > 0 && J > JF) keep_remainder(total_rows);
           ZN_PT_COUNT(20, 1);                    // write groups (== tiles when nothing overflowed)
+          if (DC) ZN_ASM_MARK("ZN_MARK fastend");
           done = true;
         }
       }
