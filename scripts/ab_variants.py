@@ -42,6 +42,12 @@ VARIANTS = {
     "rb4nob2": (None, ["-DZN_F_RB2=4", "-DZN_F_BATCH2_AHEAD=0"]),
     "rb2": (None, ["-DZN_F_RB2=2"]),
     "rb3": (None, ["-DZN_F_RB2=3"]),
+    "dcap4": (None, ["-DZN_F_DCAP=4"]),
+    "dcap3": (None, ["-DZN_F_DCAP=3", "-DZN_F_DCONST2=3"]),
+    "dcap5": (None, ["-DZN_F_DCAP=5", "-DZN_F_DCONST2=5"]),
+    "e_noahead": (None, ["-DZN_E_STATS_AHEAD=0"]),
+    "e_fwd": (None, ["-DZN_E_EMIT_REVERSE=0"]),
+    "e_old": (None, ["-DZN_E_STATS_AHEAD=0", "-DZN_E_EMIT_REVERSE=0"]),
     "rb5": (None, ["-DZN_F_RB2=5"]),
     "nod6": (None, ["-DZN_F_DCONST2=0"]),
     "rb6": (None, ["-DZN_F_RB2=6"]),
@@ -109,11 +115,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "new")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "new")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "new"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "prev", "new", "dcap4")),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "prev", "new", "dcap4")),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "prev", "new", "dcap4"))]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "new")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "prev", "new", "dcap4")))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:

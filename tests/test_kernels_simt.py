@@ -434,21 +434,25 @@ def _tile_counters(reset=True):
     return list(a)       # [tiles, tiles in the looping form, fix-up iterations, tiles written in several lane groups]
 
 
-@pytest.mark.parametrize("kind,P,rot,bm,chunk", [("bf16", 2, 1, 10, 256 * 1024), ("fp32", 4, 1, 220, 256 * 1024), ("bf16", 2, 1, 10, 128 * 1024)],
-                         ids=["bf16-256k", "fp32-256k", "bf16-128k"])
+@pytest.mark.parametrize("kind,P,rot,bm,chunk", [("bf16", 2, 1, 10, 256 * 1024), ("fp32", 4, 1, 220, 256 * 1024), ("bf16", 2, 1, 10, 128 * 1024),
+                                                    ("fp16", 2, 0, 10, 256 * 1024)],
+                         ids=["bf16-256k", "fp32-256k", "bf16-128k", "fp16-256k-dense-code-capped"])
 def test_register_resident_form_decodes_weights_like_tensors(simt_lib, kind, P, rot, bm, chunk):
     """The fast form of the fused decoder (decode once into registers, compact): weights-like tensors at the default
     chunk size must go through it tile for tile (counters of the emulated build), including its fix-up iterations,
     and decode to the input bit for bit."""
     g = torch.Generator().manual_seed(11)
     n = 3 * chunk
-    x = (torch.randn(n // (4 if kind == "fp32" else 2), generator=g) * 0.02).to(torch.float32 if kind == "fp32" else torch.bfloat16)
+    x = (torch.randn(n // (4 if kind == "fp32" else 2), generator=g) * 0.02).to({"fp32": torch.float32, "fp16": torch.float16}.get(kind, torch.bfloat16))
     d = x.view(torch.uint8).numpy().tobytes()
     ref = O.compress_frame(HDR, d, P, rot, bm, chunk)
     _tile_counters()
     assert bytes(simt_lib.decompress(ref[32:], P, rot, bm, chunk, len(d))) == d
     tiles, looping, fixups, groups = _tile_counters()[:4]
-    assert tiles > 20 and looping == 0 and groups == 0        # every tile took the register-resident form
+    if kind == "fp16":     # a dense code (5.5 bits a symbol): sub-blocks capped at the compile-time size; a few tiles overflow the step slots
+        assert tiles > 20 and looping * 20 <= tiles and groups == 0
+    else:
+        assert tiles > 20 and looping == 0 and groups == 0    # every tile took the register-resident form
     assert fixups > 0                                         # … and some of them needed a fix-up iteration (22-bit run-in)
 
 

@@ -57,6 +57,18 @@
 #ifndef ZN_F_DMAX
 #define ZN_F_DMAX 6                      // largest sub-block (dwords); sizes the stream-tile buffer and its prefetch registers (LDS: 40.8 KB, still 4 workgroups/CU; dense codes — fp8, fp16 — want long sub-blocks: +22 % on fp8)
 #endif
+// Dense codes (fp16's top byte, fp8: 5-6 bits a symbol) would get sub-blocks of 6 dwords from the density rule, which only
+// the looping form decodes.  Capped at the compile-time size they run the register-resident form: fp16 +14 %.  The
+// exception is a code that does not re-synchronise — most of its code space at ONE length (fp8 e4m3 weights: 72 % of the
+// symbols are 5 bits long, a mis-aligned decoder stays mis-aligned for a median of 35 bits, 12 % beyond 128): nearly every
+// tile then needs fix-up passes whatever the run-in, and the looping form with long sub-blocks is the faster one (−13 %
+// with the cap).  `dom` = the share of the code space held by the most populated code length (ZnWaveStats).
+#ifndef ZN_F_DCAP
+#define ZN_F_DCAP 4
+#endif
+#ifndef ZN_F_DOM_MAX
+#define ZN_F_DOM_MAX 154                 // (0.6 · 256)
+#endif
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
@@ -751,6 +763,7 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg*
   uint8_t* outq = scratch + (uint64_t)b * ZN_TAIL_SLOT + (uint64_t)wave * ZN_TAIL_SEGPAD;
   uint32_t Du = ((ZN_F_RING_BYTES - UNIT1 - 128u) * slen) / (256u * segw);
   Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+  if (ZN_F_DCAP && Du > ZN_F_DCAP && st.dom < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
   Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
   const bool ok = (Du == ZN_F_DCONST)
     ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
@@ -895,7 +908,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       if (kind == ZN_KIND_HUF) { if (h < 0) h = p; nhuf++; }     // h: the FIRST Huffman plane (further ones: extra passes below)
     }
     (void)nhuf;
-    ZnWaveStats st; st.hs = 0; st.nsym = 0; st.tl = 0; st.lmin = 1;
+    ZnWaveStats st; st.hs = 0; st.nsym = 0; st.tl = 0; st.lmin = 1; st.dom = 0;
     if (elig && h >= 0) {
       const uint32_t csize = L.plane[wave][h].csize;
       uint8_t* scratch = (uint8_t*)&L.ring[wave][0];          // weights + FSE cells; the ring is idle until the decode
@@ -957,6 +970,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     // carried remainder, at this stream's average code length (8 slen / seg bits per symbol)
     uint32_t Du = ((ZN_F_RING_BYTES - UNIT - 128u) * slen) / (256u * seg);
     Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+    if (ZN_F_DCAP && Du > ZN_F_DCAP && zn_uniform(L.st[j].dom) < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
 #define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS

@@ -42,6 +42,12 @@ __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { const zn_ev4u v = _
 __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { return *(const uint4*)p; }
 #endif
 #define ZN_LD_STATS(p) zn_ldnt128(p)
+#ifndef ZN_E_EMIT_REVERSE
+#define ZN_E_EMIT_REVERSE 1
+#endif
+#ifndef ZN_E_STATS_AHEAD
+#define ZN_E_STATS_AHEAD 1                 // the stats kernel requests step i + 1 before it counts step i
+#endif
 #define ZN_LD_EMIT(p) (*(const uint4*)(p))
 
 typedef uint64_t __attribute__((aligned(1))) zn_eu64u;
@@ -104,21 +110,39 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
 
   constexpr uint32_t COLS = ZnStatsLds<P>::COLS;
   constexpr uint32_t PAIRS = ZnStatsLds<P>::PAIRS;
-  for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
-  __syncthreads();
 
   uint32_t tot[P], qc[P][4];                                  // thread = bin: count so far / per quarter
   for (int p = 0; p < P; p++) tot[p] = 0;
   const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;       // 16-byte vectors per quarter (a multiple of 256)
   uint32_t* hbase = &L.hist[0][lane & (COLS - 1u)];
+  // The loads of step i + 1 are issued before the bytes of step i are counted, across quarter ends too (the column
+  // sums and their barriers would otherwise run with nothing in flight): ZN_E_STATS_AHEAD.
+  const uint8_t* cs0 = src + c * g.chunk;
+  const uint8_t* xcs0 = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;
+  const uint32_t qbytes = (uint32_t)(g.chunk / 4u);
+  auto fetch = [&](uint4 (&xs)[4], uint32_t q, uint32_t v0) {
+    const uint8_t* qs = cs0 + (uint64_t)q * qbytes;
+    for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ZN_LD_STATS(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
+    if (X && xcs0) {
+      const uint8_t* xqs = xcs0 + (uint64_t)q * qbytes;
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nvec) { const uint4 t = ZN_LD_STATS(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
+    }
+  };
+  uint4 nx[4];
+  if (ZN_E_STATS_AHEAD) fetch(nx, 0u, tid);
+  for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
+  __syncthreads();
   for (int q = 0; q < 4; q++) {
-    const uint8_t* qs = src + c * g.chunk + (uint64_t)q * (g.chunk / 4u);
-    const uint8_t* xqs = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk + (uint64_t)q * (g.chunk / 4u) : nullptr;
-    // 4 independent 16-byte loads in flight per thread per step
+    // 4 independent 16-byte loads in flight per thread per step, one step ahead
     for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
       uint4 xs[4];
-      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ZN_LD_STATS(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
-      if (X && xqs) for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nvec) { const uint4 t = ZN_LD_STATS(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
+      if (!ZN_E_STATS_AHEAD) fetch(nx, (uint32_t)q, v0);
+      for (int u = 0; u < 4; u++) xs[u] = nx[u];
+      const uint32_t v1 = v0 + 4u * ZN_E_THREADS;
+      if (ZN_E_STATS_AHEAD) {
+        if (v1 < nvec) fetch(nx, (uint32_t)q, v1);
+        else if (q < 3) fetch(nx, (uint32_t)q + 1u, tid);
+      }
       for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
         const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
         for (int k = 0; k < 4; k++)
@@ -463,13 +487,16 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
                                                                  const uint64_t* __restrict__ offs_all, const ZnEncDesc* __restrict__ descs_all,
                                                                  uint32_t* __restrict__ status) {
   __shared__ ZnEmitLds<P> L;
-  const ZnESeg S = zn_efind_chunk(one, segs, nseg, blockIdx.x);
+  // ZN_E_EMIT_REVERSE: the emit pass walks the chunks from the last one down — what the stats pass read last is what the
+  // Infinity Cache (256 MB, memory side) still holds
+  const uint32_t bid = ZN_E_EMIT_REVERSE ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const ZnESeg S = zn_efind_chunk(one, segs, nseg, bid);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
   const uint32_t* __restrict__ csize = csize_all + S.pc0; const uint8_t* __restrict__ type = type_all + S.pc0;
   const uint64_t* __restrict__ offs = offs_all + S.pc0; const ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t c = blockIdx.x - S.chunk0;
+  const uint64_t c = bid - S.chunk0;
   const uint8_t* chunk_src = src + c * g.chunk;
   const uint8_t* chunk_xr = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;
   uint64_t off[P]; uint32_t kind[P]; int nhuf = 0;           // kind: 0 raw, 1 RLE, 2 huff0

@@ -154,7 +154,7 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
 }
 
 // What the table builders need to know about one huff0 block.
-struct ZnWaveStats { int hs; uint32_t nsym, tl, lmin; };
+struct ZnWaveStats { int hs; uint32_t nsym, tl, lmin, dom; };   // dom: code space of the most populated code length, in 1/256 of the whole
 
 // HUF_readStats + canonical ordering, by one wave.
 //   src/csize: the huff0 block in the body (any alignment); body_end bounds the staging reads.
@@ -165,7 +165,7 @@ struct ZnWaveStats { int hs; uint32_t nsym, tl, lmin; };
 __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t csize, const uint8_t* body_end, uint32_t lane,
                                                  uint8_t* sh_w, uint8_t* sh_symlist, uint32_t* sh_rank_start,
                                                  uint32_t* sh_sym_start, uint8_t* sh_cell) {
-  ZnWaveStats R; R.hs = -1; R.nsym = 0; R.tl = 0; R.lmin = 1;
+  ZnWaveStats R; R.hs = -1; R.nsym = 0; R.tl = 0; R.lmin = 1; R.dom = 0;
   if (csize == 0) return R;
   ZN_WT_DECL;
   // stage the first 256 bytes of the block across the lanes
@@ -222,7 +222,8 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
   // ---- canonical order: by weight ascending (longest codes first), symbol ascending inside ----
   uint32_t rs[14], ss[14]; uint32_t cells = 0, syms = 0, vmax = 1;
   rs[0] = 0; ss[0] = 0;
-  for (uint32_t v = 1; v <= 12; v++) { rs[v] = cells; ss[v] = syms; cells += cnt[v] << (v - 1u); syms += cnt[v]; if (cnt[v]) vmax = v; }
+  uint32_t dom_cells = 0;
+  for (uint32_t v = 1; v <= 12; v++) { rs[v] = cells; ss[v] = syms; cells += cnt[v] << (v - 1u); syms += cnt[v]; if (cnt[v]) vmax = v; if ((cnt[v] << (v - 1u)) > dom_cells) dom_cells = cnt[v] << (v - 1u); }
   rs[13] = cells; ss[13] = syms;
   if (cells != (1u << tl)) return R;
   for (uint32_t i = 0; i < 14; i++) if (lane == i) { sh_rank_start[i] = rs[i]; sh_sym_start[i] = ss[i]; }
@@ -239,6 +240,6 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
   }
   __builtin_amdgcn_wave_barrier();
   ZN_WT(15);   // canonical order
-  R.hs = (int)(isz + 1u); R.nsym = nsym; R.tl = tl; R.lmin = tl + 1u - vmax;
+  R.hs = (int)(isz + 1u); R.nsym = nsym; R.tl = tl; R.lmin = tl + 1u - vmax; R.dom = (dom_cells << 8) >> tl;
   return R;
 }
