@@ -45,6 +45,9 @@ VARIANTS = {
     "dcap4": (None, ["-DZN_F_DCAP=4"]),
     "dcap3": (None, ["-DZN_F_DCAP=3", "-DZN_F_DCONST2=3"]),
     "dcap5": (None, ["-DZN_F_DCAP=5", "-DZN_F_DCONST2=5"]),
+    "e_abl1": (None, ["-DZN_E_ABL=1"]),
+    "e_abl2": (None, ["-DZN_E_ABL=2"]),
+    "e_abl2na": (None, ["-DZN_E_ABL=2", "-DZN_E_STATS_AHEAD=0"]),
     "e_noahead": (None, ["-DZN_E_STATS_AHEAD=0"]),
     "e_fwd": (None, ["-DZN_E_EMIT_REVERSE=0"]),
     "e_old": (None, ["-DZN_E_STATS_AHEAD=0", "-DZN_E_EMIT_REVERSE=0"]),
