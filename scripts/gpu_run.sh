@@ -13,7 +13,7 @@ echo "== bench =="; timeout 900 python bench.py --steps "$STEPS" --warmup "$WARM
 echo "== other dtypes (1 GiB) =="; timeout 300 python scripts/bench_dtypes.py 1.0 2>&1 | grep GiB | tee "$OUT/dtypes.log"
 echo "== rocprofv3 kernel stats =="
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$R/bench.py" --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline > "$OUT/rocprof.log" 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o bench -- python "$R/bench.py" --steps "$STEPS" --warmup "$WARM" --no-cpu-baseline --no-other-dtypes > "$OUT/rocprof.log" 2>&1
 tail -3 "$OUT/rocprof.log"
 find "$OUT/prof" -name '*kernel_stats*' | head -3 | while read f; do echo "--- $f"; head -12 "$f"; done
 # keep only the small summaries (the merged gpurun_out is capped at 64 MiB)
