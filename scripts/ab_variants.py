@@ -45,6 +45,9 @@ VARIANTS = {
     "dcap4": (None, ["-DZN_F_DCAP=4"]),
     "dcap3": (None, ["-DZN_F_DCAP=3", "-DZN_F_DCONST2=3"]),
     "dcap5": (None, ["-DZN_F_DCAP=5", "-DZN_F_DCONST2=5"]),
+    "noslab": (None, ["-DZN_E_SLABS=0"]),
+    "slab4": (None, ["-DZN_E_SLABS=4"]),
+    "slab2": (None, ["-DZN_E_SLABS=2"]),
     "e_abl1": (None, ["-DZN_E_ABL=1"]),
     "e_abl2": (None, ["-DZN_E_ABL=2"]),
     "e_abl2na": (None, ["-DZN_E_ABL=2", "-DZN_E_STATS_AHEAD=0"]),
@@ -118,11 +121,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "prev", "new", "dcap4")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "prev", "new", "dcap4")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "prev", "new", "dcap4"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "prev", "new", "dcap4", "noslab")),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "prev", "new", "dcap4", "noslab")),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "prev", "new", "dcap4", "noslab"))]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "prev", "new", "dcap4")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "prev", "new", "dcap4", "noslab")))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:

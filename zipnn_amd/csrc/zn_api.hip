@@ -39,6 +39,8 @@ struct Workspace {
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
+  hipStream_t aux = nullptr;     // second stream of the encoder: code tables of slab k while the stats kernel reads slab k + 1
+  hipEvent_t slab_ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
@@ -207,6 +209,11 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
     }
   }
   if ((rc = ws_acquire(w, stream))) return rc;
+  if (!table && !w.aux && zn_encode_slabs() > 1) {   // (failing to get them only means no overlap)
+    bool ok = hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < 10; i++) ok = hipEventCreateWithFlags(&w.slab_ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); if (w.aux) (void)hipStreamDestroy(w.aux); w.aux = nullptr; for (int i = 0; i < 10; i++) if (w.slab_ev[i]) { (void)hipEventDestroy(w.slab_ev[i]); w.slab_ev[i] = nullptr; } }
+  }
   uint64_t* d_totals = (uint64_t*)w.buf[WS_TOTALS];
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
@@ -227,7 +234,8 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
       const uint32_t nseg = (uint32_t)segs[q].size();
       const ZnESeg& one = segs[q][0];
       if (stage == 0) {
-        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream);
+        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream,
+                                     table ? nullptr : w.aux, w.slab_ev, 10);
         zn_launch_encode_generic_stats(P, one, d_segs, nseg, (uint32_t)tails_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES],
                                        (uint8_t*)w.buf[WS_ENC], slot, d_csize, d_type, stream);
       } else if (stage == 1) {
@@ -538,7 +546,7 @@ int zn_release_workspace(void) {
     std::lock_guard<std::mutex> hk(g_host_mu[d]);
     std::lock_guard<std::mutex> lk(g_dev_mu[d]);
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.aux != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -548,6 +556,8 @@ int zn_release_workspace(void) {
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
     zn_host_pipe_release(w.pipe);
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
+    if (w.aux) { (void)hipStreamSynchronize(w.aux); (void)hipStreamDestroy(w.aux); w.aux = nullptr; }
+    for (int i = 0; i < 10; i++) if (w.slab_ev[i]) { (void)hipEventDestroy(w.slab_ev[i]); w.slab_ev[i] = nullptr; }
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   return ZN_OK;
