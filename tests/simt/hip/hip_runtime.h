@@ -233,6 +233,7 @@ static inline uint32_t zn_simt_perm(uint32_t a, uint32_t b, uint32_t sel) {
 // used by the kernels only on values that are already wave-uniform
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_s_sleep(x) ((void)0)
+#define __threadfence() ((void)0)       /* blocks run one after the other: every earlier block's writes are visible */
 // On hardware the lanes of a wave run in lockstep, so LDS written by one lane is visible to the
 // others after the (code-less) wave barrier; here the lanes are fibers, so it must be a real
 // rendezvous of the wave.
