@@ -46,6 +46,7 @@ VARIANTS = {
     "dcap3": (None, ["-DZN_F_DCAP=3", "-DZN_F_DCONST2=3"]),
     "dcap5": (None, ["-DZN_F_DCAP=5", "-DZN_F_DCONST2=5"]),
     "noslab": (None, ["-DZN_E_SLABS=0"]),
+    "notile0": (None, ["-DZN_F_TILE0=0"]),
     "noilv": (None, ["-DZN_E_ILV=0"]),
     "ilvs2": (None, ["-DZN_E_ILV_SYNC=2"]),
     "ilvs0": (None, ["-DZN_E_ILV_SYNC=0"]),
@@ -126,11 +127,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "prev", "new", "dcap4", "noslab", "noilv")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "prev", "new", "dcap4", "noslab", "noilv")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "prev", "new", "dcap4", "noslab", "noilv"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "prev", "new", "notile0")),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "prev", "new", "notile0")),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "prev", "new", "notile0"))]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "prev", "new", "dcap4", "noslab", "noilv")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "prev", "new", "notile0")))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:
