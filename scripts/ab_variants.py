@@ -31,15 +31,10 @@ VARIANTS = {
     "new": (None, []),
     "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
     "prio0": (None, ["-DZN_F_PRIO_SYNC=0", "-DZN_F_PRIO_COUNT=0", "-DZN_F_PRIO_WRITE=0"]),
-    "early": (None, ["-DZN_F_EARLY_ROWS=1"]),
     "plainld": (None, ["-DZN_F_NT_LOADS=0"]),
-    "pad": (None, ["-DZN_F_IN_PAD=1"]),
     "p2m0": (None, ["-DZN_F_P2_MASK=0"]),
     "nosplit": (None, ["-DZN_F_FETCH_SPLIT=0"]),
     "rb8": (None, ["-DZN_F_RB2=8"]),
-    "nob2": (None, ["-DZN_F_BATCH2_AHEAD=0"]),
-    "rb3nob2": (None, ["-DZN_F_RB2=3", "-DZN_F_BATCH2_AHEAD=0"]),
-    "rb4nob2": (None, ["-DZN_F_RB2=4", "-DZN_F_BATCH2_AHEAD=0"]),
     "rb2": (None, ["-DZN_F_RB2=2"]),
     "rb3": (None, ["-DZN_F_RB2=3"]),
     "dcap4": (None, ["-DZN_F_DCAP=4"]),

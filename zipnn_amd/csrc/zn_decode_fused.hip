@@ -72,12 +72,8 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
-#ifndef ZN_F_IN_PAD
-#define ZN_F_IN_PAD 0                    // 1: one dword of padding per 32 in the stream-tile buffer (see ZN_IN_IDX)
-#endif
-// dwords 0 (look-ahead below the tile) .. 64 D (its top): 64 D + 1 entries, padded index of the last one + 1, + 1 spare —
-// not a dword more: the structure is 40 944 bytes, four workgroups per CU need ≤ 40 960
-#define ZN_F_IN_DW (ZN_F_IN_PAD ? (64 * ZN_F_DMAX + (64 * ZN_F_DMAX) / 32 + 2) : (64 * ZN_F_DMAX + 4))
+// dwords 0 (look-ahead below the tile) .. 64 D (its top) of a stream tile, + spare
+#define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #ifndef ZN_F_TF
 #define ZN_F_TF(D) ((D) * 4 + 1)         // whole-group step slots of the register-resident decode for a sub-block of D dwords
 #endif
@@ -149,14 +145,9 @@ extern "C" void zn_debug_tile_counters(unsigned long long* out, int reset) { for
 #define ZN_DBG_COUNT(i) do { } while (0)
 #endif
 
-// stream-tile dword i lives at in[ZN_IN_IDX(i)].  Lane k walks its sub-block of D dwords, so the 32 lanes of a half-wave read
-// with a stride of D dwords: D = 4 puts them on 8 banks, a 4-way conflict on every window refill (two dwords each) — as
-// much LDS time as all of a tile's LUT look-ups.  One dword of padding per 32 spreads a stride of 2, 4 or 8 over all banks.
-#if ZN_F_IN_PAD
-#define ZN_IN_IDX(i) ((i) + ((i) >> 5))
-#else
+// stream-tile dword i lives at in[ZN_IN_IDX(i)] (a padded layout — one dword per 32 against the 4-way bank conflict of the D = 4 refills —
+// was tried: no gain, profiles/r02_decode_experiments.txt)
 #define ZN_IN_IDX(i) (i)
-#endif
 
 // 16-byte output store, non-temporal: the output is written once and never read back by this kernel
 #if !defined(ZN_SIMT_EMULATOR)
@@ -289,9 +280,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   ZN_PT_SHARED;
 
   // raw-plane bytes (and, in emit, ring bytes of plane H) for up to RB rows
-  // two sets: the second holds the rows of a tile's SECOND flush batch, requested behind the first batch's wait and ahead of
-  // its stores, so that waiting for them is not also a wait for those stores (one in-order counter for loads and stores)
-  uint32_t pre[RB][P][EW], preB[RB][P][EW];
+  uint32_t pre[RB][P][EW];
   // the lane index as the HBM address computations see it: made opaque once per tile (below), so that the compiler cannot
   // hoist `base pointer + lane` out of the tile loop as 64-bit per-lane pointers — loop-invariant, so it did, one pair of
   // registers per stream / plane / output, and then spilled them and reloaded them behind an s_waitcnt vmcnt(0)
@@ -312,9 +301,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   auto fetch_row = [&](uint32_t first_row_sym, int r) { fetch_row_to(pre, first_row_sym, r); };
   auto fetch_rows = [&](uint32_t first_row_sym, int nrows) {
     for (int r = 0; r < RB; r++) if (r < nrows) fetch_row_to(pre, first_row_sym, r);
-  };
-  auto fetch_rows_b = [&](uint32_t first_row_sym, int nrows) {
-    for (int r = 0; r < RB; r++) if (r < nrows) fetch_row_to(preB, first_row_sym, r);
   };
   // interleave rows (ring bytes for the Huffman plane, fetched bytes for raw planes) and store them.
   // All loads are complete before the first store is issued, so no store latency is ever waited on.
@@ -417,10 +403,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
   int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
   int nmis = 0;                               // tiles of this stream that needed a fix-up since the run-in was last lengthened
-  uint32_t n_prev = 0;                        // symbols the previous tile decoded to (predicts this tile's rows; 0: no early request)
-#ifndef ZN_F_ROW_MARGIN
-#define ZN_F_ROW_MARGIN 160u                // the prediction's safety margin, in symbols (a tile is ~3100 ± 2 %)
-#endif
 
   // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D-1, and (lane 0) the
   // tile's last dword, in a register of its own so that nothing selects on a loaded value before the staging
@@ -508,33 +490,15 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     lane_v = lane; ZN_OPAQUE32(lane_v);
     hi_dw = __builtin_amdgcn_readfirstlane(hi_dw); carry = __builtin_amdgcn_readfirstlane(carry);
     delta = __builtin_amdgcn_readfirstlane(delta); nmis = __builtin_amdgcn_readfirstlane(nmis);
-    J = zn_uniform(J); JF = zn_uniform(JF); n_prev = zn_uniform(n_prev);
+    J = zn_uniform(J); JF = zn_uniform(JF);
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
 #if !ZN_F_EARLY_STAGE
     stage_tile();
 #endif
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
-#ifndef ZN_F_EARLY_ROWS
-#define ZN_F_EARLY_ROWS 0                // 1: request the raw-plane rows this tile will PROBABLY complete at the top of the tile (0: all of them after the decode pass)
-#endif
-    // The raw-plane rows of this tile's flush can only be counted once the tile is decoded, a compaction's length before
-    // they are needed: at 5 TB/s the HBM latency is several thousand cycles and most of it was exposed in the flush's wait
-    // (dropping the memory operations: -22 %, profiles/r02_decode_experiments.txt).  A stream's tiles decode to nearly the
-    // same number of symbols, so the rows this tile will complete are predicted from the previous tile's count (minus a
-    // margin) and requested NOW, a whole decode pass ahead; what the prediction misses is requested after the pass as
-    // before, a row it over-predicts is simply not used (and read again next tile).  Their registers are live through the
-    // decode pass, which does not raise the peak: that is the start of the compaction either way.
-    int rows_early = 0;
-    if (ZN_F_EARLY_ROWS && TF > 0 && H >= 0) {
-      const uint32_t base0 = zn_uniform(J - JF);
-      const uint32_t guess = n_prev > ZN_F_ROW_MARGIN ? n_prev - ZN_F_ROW_MARGIN : 0u;
-      uint32_t re = (base0 + guess) / UNIT;
-      const uint32_t room = (seg - zn_uniform(JF)) / UNIT;                 // rows left in this quarter
-      re = re > (uint32_t)RB ? (uint32_t)RB : re; re = re > room ? room : re;
-      rows_early = (int)zn_uniform(re);
-      fetch_rows(JF, rows_early);
-    }
+    // (tried, r02: requesting the rows this tile will PROBABLY complete — predicted from the previous tile's count — at the top of
+    //  the tile, a whole decode pass ahead: no gain; a second flush batch's rows requested behind the first batch's wait: slower)
     // (tried, r02: touching the raw-plane lines this tile's flush will need — one dword per 128-byte line, at the top of
     //  the tile, so that the loads proper hit the L2 — made the kernel 8 % SLOWER: profiles/r02_decode_experiments.txt)
     ZN_PT(4);   // stage tile
@@ -598,8 +562,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #define ZN_F_FETCH_SPLIT 1                // 1: request the second half of the flush's raw rows in the middle of the compaction, when half of the record registers are free again
 #endif
           constexpr int RH = (ZN_F_FETCH_SPLIT && RB >= 4) ? RB / 2 : RB;         // rows requested before the compaction
-          for (int r = 0; r < RH; r++) if (r >= rows_early && r < first) fetch_row(JF, r);      // (what an early request did not cover)
-          n_prev = N;
+          for (int r = 0; r < RH; r++) if (r < first) fetch_row(JF, r);
           ZN_PT(8);   // scans / shuffles / issue loads
           ZN_PRIO(ZN_F_PRIO_WRITE);
           if (DC) ZN_ASM_MARK("ZN_MARK pass2");
@@ -610,32 +573,22 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           // the steps before it are dead by then, so the rows' registers do not add to the peak at the start of the compaction.
           bool late_rows = (RH < RB);
           if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB>(ring, base + o_k, rec, nf, nb_, [&](auto I) {
-            if constexpr (RH < RB && decltype(I)::v == TF / 2 - 1) { for (int r = RH; r < RB; r++) if (r >= rows_early && r < first) fetch_row(JF, r); late_rows = false; }
+            if constexpr (RH < RB && decltype(I)::v == TF / 2 - 1) { for (int r = RH; r < RB; r++) if (r < first) fetch_row(JF, r); late_rows = false; }
           });
-          if (late_rows) for (int r = RH; r < RB; r++) if (r >= rows_early && r < first) fetch_row(JF, r);     // (a tile of fewer steps than that)
+          if (late_rows) for (int r = RH; r < RB; r++) if (r < first) fetch_row(JF, r);     // (a tile of fewer steps than that)
           __builtin_amdgcn_wave_barrier();
           ZN_PRIO(0);
           ZN_PT(9);   // compaction
           if (DC) ZN_ASM_MARK("ZN_MARK flush");
           J += N;
           // (the compaction is over: the stream-tile buffer is free for the next tile, staged behind the flush's wait)
-#ifndef ZN_F_BATCH2_AHEAD
-#define ZN_F_BATCH2_AHEAD 0               // 1: request the second flush batch's raw rows behind the first batch's wait, ahead of its stores
-#endif
-          const int second = (ZN_F_BATCH2_AHEAD && !X) ? ((rows - first) < RB ? (rows - first) : RB) : 0;
           emit_rows(JF, first, 0, [&] {
 #if ZN_F_EARLY_STAGE
             if (32 * hi_dw > b0) stage_tile();
 #endif
-            if (second > 0) fetch_rows_b(JF + (uint32_t)first * UNIT, second);
           });
           uint32_t srow = (uint32_t)first;
           JF += (uint32_t)first * UNIT; rows -= first;
-          if (second > 0) {
-            // (no full wait here: the compiler's own vmcnt(N) for these registers lets the first batch's stores stay in flight)
-            emit_rows_from(preB, false, JF, second, srow, [] {});
-            JF += (uint32_t)second * UNIT; srow += (uint32_t)second; rows -= second;
-          }
           while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
           if (total_rows > 0 && J > JF) keep_remainder(total_rows);
           ZN_PT_COUNT(20, 1);                    // write groups (== tiles when nothing overflowed)
