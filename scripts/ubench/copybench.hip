@@ -54,6 +54,32 @@ __global__ __launch_bounds__(256) void k_grid(const T* __restrict__ src, T* __re
 
 // decode-shaped: per 256 KiB "chunk" (one workgroup at a time): read C bytes (two streams: 43 KB "huffman" + 128 KiB "raw"),
 // write 256 KiB as 4 quarters (wave w owns quarter w), 8 rows of 1 KiB per burst — the store pattern of zn_k_decode_fused
+// the same with the waves' regions skewed against each other (SKEW bytes more than 64 KiB apart; a benchmark only: the regions overlap),
+// BR rows per burst, and (ADJ) the four waves writing adjacent 1 KiB rows of one span instead of four quarters
+template <int ST, int SKEW, int BR, int ADJ>
+__global__ __launch_bounds__(256) void k_decode_shape2(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t chunks, size_t cbytes) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (size_t c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const uint8_t* s = src + c * cbytes + (size_t)wave * (cbytes / 4 & ~15ull);
+    uint8_t* d = dst + c * 262144 + (ADJ ? (size_t)wave * 1024 : (size_t)wave * (65536 + SKEW));
+    const int bursts = 64 / BR;
+    const size_t rd_per_burst = ((cbytes / 4) / bursts) & ~15ull;
+    for (int burst = 0; burst < bursts; burst++) {
+      v4u v[BR];
+      v4u a = {};
+      for (size_t o = (size_t)lane * 16; o < rd_per_burst; o += 1024) a ^= __builtin_nontemporal_load((const v4u*)(s + burst * rd_per_burst + o));
+#pragma unroll
+      for (int r = 0; r < BR; r++) { v[r] = a; v[r].x += r; }
+#pragma unroll
+      for (int r = 0; r < BR; r++) {
+        size_t off = ADJ ? ((size_t)(burst * BR + r) * 4096 + lane * 16) : ((size_t)burst * BR * 1024 + r * 1024 + lane * 16);
+        if (!ADJ && off + 16 > 65536 - (size_t)(SKEW > 0 ? 3 * SKEW : 0)) off = lane * 16;
+        v4u* p = (v4u*)(d + off); if (ST) __builtin_nontemporal_store(v[r], p); else *p = v[r];
+      }
+    }
+  }
+}
+
 template <int ST>
 __global__ __launch_bounds__(256) void k_decode_shape(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t chunks, size_t cbytes) {
   const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -84,7 +110,7 @@ static double time_kernel(std::function<void()> f, int reps) {
 }
 
 int main(int argc, char** argv) {
-  const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+  const bool quick = argc > 1 && (!strcmp(argv[1], "quick") || !strcmp(argv[1], "shapes"));
   hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
   const int CUS = pr.multiProcessorCount;
   const size_t N = (size_t)4 << 30;
@@ -130,6 +156,17 @@ int main(int argc, char** argv) {
     const int blocks = wgpc == 64 ? 16384 : CUS * wgpc;
     if (st_) row(nm, 16384ull * 173600 + N, [&] { hipLaunchKernelGGL((k_decode_shape<1>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
     else row(nm, 16384ull * 173600 + N, [&] { hipLaunchKernelGGL((k_decode_shape<0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+  }
+  {
+    const size_t bytes = 16384ull * 173600 + N; const int blocks = CUS * 4;
+    row("decode-shaped, nt, 4 WG/CU: 8 rows per burst, quarters 64 KiB apart (as above)", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 8, 0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 8 rows per burst, quarters 64 KiB + 4352 B apart", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 4352, 8, 0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 8 rows per burst, quarters 64 KiB + 1280 B apart", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 1280, 8, 0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 4 rows per burst, quarters 64 KiB apart", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 4, 0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 2 rows per burst, quarters 64 KiB apart", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 2, 0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 16 rows per burst, quarters 64 KiB apart", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 16, 0>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 8 rows per burst, the four waves' rows ADJACENT (one 4 KiB span per step)", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 8, 1>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
+    row("decode-shaped, nt, 4 WG/CU: 4 rows per burst, the four waves' rows ADJACENT", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 4, 1>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
   }
   return 0;
 }
