@@ -140,6 +140,17 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
 int zn_decompress_delta(const void* body, size_t body_len, const void* delta, int num_buf, int bits_mode,
                         int bytes_mode, size_t chunk, size_t orig_size, int device, void* dst);
 
+/* One call, several GPUs of the node (SURVEY.md §8b proposes exactly this `devices, ndev` form of the two entry points; the
+ * reference's counterpart is its `threads` argument — csrc/zipnn_core.c:401 "y*y*iiiinfii", :881 "y*iiinni" — which fans the
+ * chunks out over pthreads, zipnn_core.c:294-390 / 768-861).  Device i codes the contiguous chunk range [i K / ndev,
+ * (i + 1) K / ndev) on a host thread, stream and workspace of its own; no collective; the host concatenates types and payload
+ * per plane and re-bases cumSizes.  The frame / the bytes are identical to the single-device call's.  ndev = 1 IS that call.
+ * The same device may be listed more than once (its ranges then run one after the other). */
+int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                      size_t chunk, float threshold, const int* devices, int ndev, void* dst, size_t dst_cap, size_t* dst_len);
+int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                        size_t orig_size, const int* devices, int ndev, void* dst);
+
 /* Plumbing for callers that keep the tensors in HBM but hold pageable host buffers (files, Python bytes): the same
  * pinned, multi-threaded transfer the host-buffer entry points above use internally (zipnn_amd/csrc/zn_host_pipe.hpp),
  * on the current device; returns when the n bytes have arrived.  No reference counterpart — the reference's buffers

@@ -627,3 +627,21 @@ def test_plain_host_entry_points_the_reference_binding_calls(lib):
     assert L.zn_decompress(out[32:].ctypes.data, n_out.value - 32, 2, 1, 10, C, len(d), 0, back.ctypes.data) == 0
     assert back.tobytes() == d
     assert torch.cuda.current_device() == 0                  # the host entry points leave the caller's device as it was
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0, 0, 0]], ids=["two-ranges", "five-ranges"])
+def test_multi_device_entry_points_on_the_one_gpu_here(lib, devices):
+    """zn_compress_multi / zn_decompress_multi with the only GPU of this box listed several times: one host thread per
+    range, all on device 0 (its lock serialises them) — the range split, the per-plane assembly and the re-based
+    cumSizes run on real hardware; the frame is the oracle's.  (Distinct devices: tests/test_kernels_simt.py, two
+    emulated devices; the 8-GPU run is the driver's.)"""
+    d = gen_bytes("bf16", 37 * C + 4321, 8)
+    want = O.compress_frame(HDR, d, 2, 1, 10, C)
+    got = lib.compress_multi(HDR, d, 2, 1, 10, C, 0.95, devices)
+    assert bytes(got) == want
+    assert bytes(lib.decompress_multi(want[32:], 2, 1, 10, C, len(d), devices)) == d
+    x = (torch.randn(3 * C // 4 + 11, generator=torch.Generator().manual_seed(2)) * 0.02).numpy().tobytes()     # fp32, ragged
+    want = O.compress_frame(HDR, x, 4, 1, 220, C)
+    assert bytes(lib.compress_multi(HDR, x, 4, 1, 220, C, 0.95, devices)) == want
+    assert bytes(lib.decompress_multi(want[32:], 4, 1, 220, C, len(x), devices)) == x
+    assert torch.cuda.current_device() == 0

@@ -515,3 +515,39 @@ def test_devices_do_not_serialise_each_other(simt_lib):
     assert done_at[0] >= done_at["hold"] - 0.01                # device 0 did
     with pytest.raises(RuntimeError):                          # and an ordinal that does not exist is an error, not device 0
         simt_lib.decompress(ref[32:], 2, 1, 10, C, len(d), device=5)
+
+
+@pytest.mark.parametrize("kind,P,rot,bm,chunk,n", [("bf16", 2, 1, 10, C, 7 * C + 1234), ("fp32", 4, 1, 220, C, 5 * C + 4 * 77), ("fp8w", 1, 0, 10, C // 2, 9 * (C // 2) + 5),
+                                                    ("bf16", 2, 1, 10, C, C // 2 + 3), ("bf16", 2, 1, 10, C, 2 * C)],
+                         ids=["bf16-7.x-chunks", "fp32-5.x-chunks", "fp8-9.x-chunks", "bf16-one-partial-chunk", "bf16-two-chunks"])
+@pytest.mark.parametrize("devices", [[0, 1], [1, 0, 1], [0, 0], [0, 1, 0, 1, 0]], ids=["2-devices", "3-ranges", "same-device-twice", "more-ranges-than-chunks-sometimes"])
+def test_multi_device_entry_points_give_the_single_device_frame(simt_lib, kind, P, rot, bm, chunk, n, devices):
+    """zn_compress_multi / zn_decompress_multi (SURVEY §8b's `devices, ndev` boundary): the chunk ranges are coded on the
+    listed devices by one host thread each (two emulated devices here) and the host does the plane-major bookkeeping —
+    the frame must be the oracle's byte for byte, and any frame must decode to the input, for ranges that are empty,
+    partial-chunk-only, or more numerous than the chunks."""
+    if kind == "fp8w":
+        g = torch.Generator().manual_seed(9)
+        d = (torch.randn(n, generator=g) * 0.02).to(torch.float8_e4m3fn).view(torch.uint8).numpy().tobytes()
+    else:
+        d = gen_bytes(kind, n, 31)
+    ref = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    got = simt_lib.compress_multi(HDR, d, P, rot, bm, chunk, 0.95, devices)
+    assert bytes(got) == ref
+    assert bytes(simt_lib.decompress_multi(ref[32:], P, rot, bm, chunk, len(d), devices)) == d
+
+
+def test_multi_device_decompress_rejects_malformed_size_tables(simt_lib):
+    """The host splits the body by its cumSizes before any device sees it: entries that decrease or point past the
+    payload must come back as ZN_E_CORRUPT (RuntimeError), not as an out-of-bounds memcpy on the host."""
+    d = gen_bytes("bf16", 4 * C, 33)
+    ref = bytearray(O.compress_frame(HDR, d, 2, 1, 10, C)[32:])
+    K = 4
+    bad = bytearray(ref); bad[2 * K + 8 * 1: 2 * K + 8 * 2] = (1 << 40).to_bytes(8, "little")          # plane 0, chunk 1: far past the payload
+    with pytest.raises(RuntimeError):
+        simt_lib.decompress_multi(bytes(bad), 2, 1, 10, C, len(d), [0, 1])
+    bad = bytearray(ref); bad[2 * K + 8 * 2: 2 * K + 8 * 3] = (0).to_bytes(8, "little")                 # decreasing
+    with pytest.raises(RuntimeError):
+        simt_lib.decompress_multi(bytes(bad), 2, 1, 10, C, len(d), [0, 1])
+    with pytest.raises(RuntimeError):                                                                     # too short for its own tables
+        simt_lib.decompress_multi(bytes(ref[:30]), 2, 1, 10, C, len(d), [0, 1])

@@ -227,3 +227,24 @@ def test_reference_produced_checkpoint_through_emulated_kernels(use_simt):
         safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
         from zipnn_amd import zipnn as _Z
         _Z._patches_applied.pop(_Z._zipnn_safetensors, None)      # (the patcher applies a patch once per process, like the reference's: let the next test apply it again)
+
+
+def test_zipnn_devices_keyword_spreads_host_input_over_gpus(use_simt):
+    """ZipNN(devices=[…]) — the keyword-only extension that takes the place of the reference's `threads`: byte / numpy /
+    host-torch input goes through zn_compress_multi / zn_decompress_multi (two emulated devices) and the frames are the ones
+    the plain constructor writes."""
+    from zipnn_amd import ZipNN
+    import numpy as np
+    raw = (torch.randn(5 * 131072 + 77, generator=torch.Generator().manual_seed(4)) * 0.02).to(torch.bfloat16).view(torch.uint8).numpy().tobytes()
+    one = ZipNN().compress(raw)
+    two = ZipNN(devices=[0, 1]).compress(raw)
+    assert bytes(two) == bytes(one)
+    assert bytes(ZipNN(devices=[1, 0, 1]).decompress(one)) == raw
+    t = (torch.randn(3, 70001, generator=torch.Generator().manual_seed(5)) * 0.02).to(torch.float16)
+    f1 = ZipNN(input_format="torch").compress(t)
+    f2 = ZipNN(input_format="torch", devices=[0, 1]).compress(t)
+    assert bytes(f2) == bytes(f1)
+    back = ZipNN(input_format="torch", devices=[0, 1]).decompress(f1)
+    assert back.dtype == t.dtype and back.shape == t.shape and torch.equal(back, t)
+    a = (np.random.default_rng(1).standard_normal(300001) * 0.02).astype(np.float32)
+    assert (ZipNN(input_format="numpy", devices=[0, 1]).decompress(ZipNN(input_format="numpy", devices=[1, 0]).compress(a)) == a).all()

@@ -62,6 +62,10 @@ class ZnLib:
         L.zn_compress.argtypes = [vp, sz, vp, sz, ci, ci, ci, sz, cf, ci, vp, sz, ctypes.POINTER(sz)]
         L.zn_decompress.restype = ci
         L.zn_decompress.argtypes = [vp, sz, ci, ci, ci, sz, sz, ci, vp]
+        L.zn_compress_multi.restype = ci
+        L.zn_compress_multi.argtypes = [vp, sz, vp, sz, ci, ci, ci, sz, cf, ctypes.POINTER(ci), ci, vp, sz, ctypes.POINTER(sz)]
+        L.zn_decompress_multi.restype = ci
+        L.zn_decompress_multi.argtypes = [vp, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ci, vp]
         L.zn_compress_dev.restype = ci
         L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
         L.zn_decompress_dev.restype = ci
@@ -152,6 +156,34 @@ class ZnLib:
         else:
             rc = self._L.zn_decompress_delta(src.addr, bv.nbytes, dl.addr, num_buf, bits_mode, bytes_mode, chunk,
                                              orig_size, device, out.ctypes.data)
+        self._check(rc)
+        return memoryview(out)[:orig_size]
+
+    def compress_multi(self, header, data, num_buf, bits_mode, bytes_mode, chunk, threshold, devices):
+        """compress() with the chunks spread over several GPUs of the node (zn_compress_multi): device i codes the
+        contiguous chunk range [i K / G, (i + 1) K / G) on its own host thread and stream; same frame bytes."""
+        hv = memoryview(header).cast("B")
+        dv = memoryview(data).cast("B")
+        n = dv.nbytes
+        cap = self._L.zn_compress_bound(n, num_buf, chunk, hv.nbytes)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        out_len = ctypes.c_size_t(0)
+        hb = (ctypes.c_char * max(hv.nbytes, 1)).from_buffer_copy(hv.tobytes() or b"\0")
+        src = _as_c_buffer(dv)
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._L.zn_compress_multi(ctypes.addressof(hb), hv.nbytes, src.addr, n, num_buf, bits_mode, bytes_mode, chunk,
+                                       threshold, devs, len(devices), out.ctypes.data, cap, ctypes.byref(out_len))
+        self._check(rc)
+        return memoryview(out)[:out_len.value]
+
+    def decompress_multi(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices):
+        """decompress() with the chunk ranges decoded on several GPUs (zn_decompress_multi); same bytes."""
+        bv = memoryview(body).cast("B")
+        out = np.empty(max(orig_size, 1), dtype=np.uint8)
+        src = _as_c_buffer(bv)
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._L.zn_decompress_multi(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, devs, len(devices),
+                                         out.ctypes.data)
         self._check(rc)
         return memoryview(out)[:orig_size]
 

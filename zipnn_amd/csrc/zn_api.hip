@@ -477,6 +477,126 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
   return zn_decompress_delta(body, body_len, nullptr, num_buf, bits_mode, bytes_mode, chunk, orig_size, device, dst);
 }
 
+// ---- one call, several GPUs (`const int* devices, int ndev`; north_star: "chunks partition embarrassingly
+// across the GPUs of one node on independent HIP streams, no collectives") ------------------------------------------------
+// Chunks are independent, so device i codes the contiguous chunk range [i K / G, (i + 1) K / G) as a tensor of its own, on a
+// host thread of its own (per-device locks, workspaces and streams: zn_api.hip above), and the host does the plane-major
+// bookkeeping: types and payload of the ranges concatenated per plane, cumSizes re-based by what the earlier ranges put into
+// the plane.  The frame is byte-identical to the one a single device writes (zipnn_amd/sharding.py states the same
+// arithmetic in numpy for the one-process-per-GPU path).
+namespace {
+struct ZnRange { size_t lo, hi; };                 // chunk range of one device
+ZnRange zn_range_of(size_t K, int g, int G) { return ZnRange{(size_t)g * K / (size_t)G, (size_t)(g + 1) * K / (size_t)G}; }
+uint64_t zn_rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+}  // namespace
+
+int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                      size_t chunk, float threshold, const int* devices, int ndev, void* dst, size_t dst_cap, size_t* dst_len) {
+  if (!dst_len || (hdr_len && !hdr) || (n && !src) || !dst || !devices || ndev <= 0 || ndev > 64 || !chunk) return ZN_E_ARG;
+  if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
+  if (ndev == 1) return zn_compress(hdr, hdr_len, src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[0], dst, dst_cap, dst_len);
+  try {
+    const size_t P = (size_t)num_buf, K = (n + chunk - 1) / chunk;
+    std::vector<std::vector<uint8_t>> part((size_t)ndev);
+    std::vector<size_t> plen((size_t)ndev, 0);
+    std::vector<int> rcs((size_t)ndev, ZN_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ndev; g++) {
+      const ZnRange r = zn_range_of(K, g, ndev);
+      if (r.hi <= r.lo) continue;
+      th.emplace_back([&, g, r]() {
+        try {
+          const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
+          part[(size_t)g].resize(zn_compress_bound(len, num_buf, chunk, 0) + 16);
+          rcs[(size_t)g] = zn_compress(nullptr, 0, (const uint8_t*)src + off, len, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[g],
+                                       part[(size_t)g].data(), part[(size_t)g].size(), &plen[(size_t)g]);
+        } catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < ndev; g++) if (rcs[(size_t)g]) return rcs[(size_t)g];
+    // assemble: types[P][K] ‖ cumSizes[P][K] ‖ payload plane-major
+    size_t pay_total = 0;
+    for (int g = 0; g < ndev; g++) { const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo; if (k) pay_total += plen[(size_t)g] - 9 * P * k; }
+    const size_t total = hdr_len + 9 * P * K + pay_total;
+    if (total > dst_cap) return ZN_E_CAP;
+    uint8_t* o = (uint8_t*)dst;
+    if (hdr_len) memcpy(o, hdr, hdr_len);
+    uint8_t* types = o + hdr_len; uint8_t* cums = types + P * K; uint8_t* pay = cums + 8 * P * K;
+    size_t pay_at = 0;
+    for (size_t p = 0; p < P; p++) {
+      uint64_t run = 0;                              // bytes the earlier ranges put into plane p
+      for (int g = 0; g < ndev; g++) {
+        const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo;
+        if (!k) continue;
+        const uint8_t* b = part[(size_t)g].data();
+        memcpy(types + p * K + r.lo, b + p * k, k);
+        const uint8_t* c = b + P * k + 8 * p * k;
+        for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(c + 8 * i) + run; memcpy(cums + 8 * (p * K + r.lo + i), &v, 8); }
+        size_t base = 0;                             // where plane p starts in this range's payload
+        for (size_t q = 0; q < p; q++) base += (size_t)zn_rd64(b + P * k + 8 * (q * k + k - 1));
+        const size_t tot = (size_t)zn_rd64(c + 8 * (k - 1));
+        memcpy(pay + pay_at, b + 9 * P * k + base, tot);
+        pay_at += tot; run += tot;
+      }
+    }
+    *dst_len = total;
+    if (hdr_len >= 32) { const uint64_t t64 = total; memcpy(o + 24, &t64, 8); }   // zipnn_core.c:121
+    return ZN_OK;
+  } catch (...) { return ZN_E_ALLOC; }
+}
+
+int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk, size_t orig_size,
+                        const int* devices, int ndev, void* dst) {
+  if ((body_len && !body) || (orig_size && !dst) || !devices || ndev <= 0 || ndev > 64 || !chunk) return ZN_E_ARG;
+  if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
+  if (ndev == 1 || orig_size == 0) return zn_decompress(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices[0], dst);
+  try {
+    const size_t P = (size_t)num_buf, K = (orig_size + chunk - 1) / chunk;
+    if (K > body_len / (9 * P)) return ZN_E_CORRUPT;
+    const uint8_t* b = (const uint8_t*)body;
+    const uint8_t* types = b; const uint8_t* cums = b + P * K; const uint8_t* pay = cums + 8 * P * K;
+    const size_t pay_len = body_len - 9 * P * K;
+    // plane bases and monotone, in-range cumSizes (the per-range bodies below are built from them)
+    std::vector<uint64_t> base(P, 0);
+    uint64_t acc = 0;
+    for (size_t p = 0; p < P; p++) {
+      base[p] = acc;
+      uint64_t prev = 0;
+      for (size_t i = 0; i < K; i++) { const uint64_t v = zn_rd64(cums + 8 * (p * K + i)); if (v < prev || v > pay_len - acc) return ZN_E_CORRUPT; prev = v; }
+      acc += prev;
+    }
+    std::vector<int> rcs((size_t)ndev, ZN_OK);
+    std::vector<std::thread> th;
+    for (int g = 0; g < ndev; g++) {
+      const ZnRange r = zn_range_of(K, g, ndev);
+      if (r.hi <= r.lo) continue;
+      th.emplace_back([&, g, r]() {
+        try {
+          const size_t k = r.hi - r.lo, off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
+          size_t need = 9 * P * k;
+          std::vector<uint64_t> s0(P), s1(P);
+          for (size_t p = 0; p < P; p++) {
+            s0[p] = r.lo ? zn_rd64(cums + 8 * (p * K + r.lo - 1)) : 0; s1[p] = zn_rd64(cums + 8 * (p * K + r.hi - 1));
+            need += (size_t)(s1[p] - s0[p]);
+          }
+          std::vector<uint8_t> sub(need + 16);
+          uint8_t* w = sub.data();
+          for (size_t p = 0; p < P; p++) memcpy(w + p * k, types + p * K + r.lo, k);
+          for (size_t p = 0; p < P; p++)
+            for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(cums + 8 * (p * K + r.lo + i)) - s0[p]; memcpy(w + P * k + 8 * (p * k + i), &v, 8); }
+          size_t at = 9 * P * k;
+          for (size_t p = 0; p < P; p++) { const size_t m = (size_t)(s1[p] - s0[p]); memcpy(w + at, pay + base[p] + s0[p], m); at += m; }
+          rcs[(size_t)g] = zn_decompress(w, need, num_buf, bits_mode, bytes_mode, chunk, len, devices[g], (uint8_t*)dst + off);
+        } catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int g = 0; g < ndev; g++) if (rcs[(size_t)g]) return rcs[(size_t)g];
+    return ZN_OK;
+  } catch (...) { return ZN_E_ALLOC; }
+}
+
 long long zn_last_fused_chunks(void) {
   try {
     int dev = 0;

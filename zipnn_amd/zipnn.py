@@ -39,8 +39,11 @@ class ZipNN:
                  lossy_compressed_type: str = 0, lossy_compressed_factor=27, compression_chunk=256 * 1024,
                  is_streaming: bool = False, streaming_chunk: int = 1024 * 1024, input_file: str = None,
                  compressed_file: str = None, decompressed_file: str = None, zstd_level: int = 3,
-                 lz4_compression_level: int = 0):
-        """Same keywords as the reference constructor (zipnn/zipnn.py:29-51).
+                 lz4_compression_level: int = 0, *, devices=None):
+        """Same keywords as the reference constructor (zipnn/zipnn.py:29-51), plus one keyword-only extension:
+        `devices` — GPU ordinals; with more than one, host-buffer input is coded with its chunk ranges spread over them
+        (zn_compress_multi / zn_decompress_multi: one host thread and stream per device, no collective, same bytes) —
+        the role `threads` plays in the reference core.
 
         `method` only selects header byte 7: on this path the core always codes with huff0,
         exactly as the reference does (zipnn.py:658-668 never changes the codec when byte
@@ -53,6 +56,7 @@ class ZipNN:
         self.bytearray_dtype = bytearray_dtype
         self.is_monotonic = is_monotonic
         self.threads = threads or min(multiprocessing.cpu_count(), 16)
+        self.devices = [int(d) for d in devices] if devices else None
         self.compression_threshold = compression_threshold
         self.check_th_after_percent = check_th_after_percent
         self.byte_reorder = byte_reorder
@@ -298,8 +302,11 @@ class ZipNN:
         h[16:24] = ba.nbytes.to_bytes(8, "little")
         self._ext_header = pack_shape(shape) if shape is not None else self._ext_header
         hdr = bytes(h) + (pack_shape(shape) if shape is not None else b"")
-        frame = lib.compress(hdr, ba, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold,
-                             device=codec.current_device(), delta=delta)
+        if self.devices and len(self.devices) > 1 and delta is None:
+            frame = lib.compress_multi(hdr, ba, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold, self.devices)
+        else:
+            frame = lib.compress(hdr, ba, dt.planes, dt.rotate, dt.byte_mode, chunk, self.compression_threshold,
+                                 device=self.devices[0] if self.devices else codec.current_device(), delta=delta)
         h[24:32] = frame[24:32]   # the core patches the total length into the caller's header (zipnn_core.c:121)
         return memoryview(frame)
 
@@ -460,8 +467,13 @@ class ZipNN:
             frame = memoryview(frame.cpu().contiguous().view(torch.uint8).reshape(-1).numpy())
         if delta is not None and memoryview(delta).nbytes != self.original_len:
             raise ValueError("Length of delta file has to match the length of the decompressed file.")
-        raw = lib.decompress(memoryview(frame)[body_off:], dt.planes, self._bit_reorder, self._byte_reorder, chunk,
-                             self.original_len, device=codec.current_device(), delta=delta if self.original_len else None)
+        if self.devices and len(self.devices) > 1 and delta is None:
+            raw = lib.decompress_multi(memoryview(frame)[body_off:], dt.planes, self._bit_reorder, self._byte_reorder, chunk,
+                                       self.original_len, self.devices)
+        else:
+            raw = lib.decompress(memoryview(frame)[body_off:], dt.planes, self._bit_reorder, self._byte_reorder, chunk,
+                                 self.original_len, device=self.devices[0] if self.devices else codec.current_device(),
+                                 delta=delta if self.original_len else None)
         if fmt == EnumFormat.BYTE.value:
             return memoryview(raw)
         if fmt == EnumFormat.TORCH.value:
