@@ -485,6 +485,16 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
 // the plane.  The frame is byte-identical to the one a single device writes (zipnn_amd/sharding.py states the same
 // arithmetic in numpy for the one-process-per-GPU path).
 namespace {
+// host staging of the multi-device calls: one grow-only buffer per range slot, kept between calls (a fresh 0.5 GiB vector per
+// range cost more in zero-fill and first-touch page faults than the coding itself); one multi-device call at a time per process
+std::mutex g_multi_mu;
+struct ZnStage { uint8_t* p = nullptr; size_t cap = 0; };
+ZnStage g_multi_stage[64];
+uint8_t* zn_stage(int slot, size_t need) {
+  ZnStage& s = g_multi_stage[slot];
+  if (s.cap < need) { free(s.p); s.p = (uint8_t*)malloc(need + (need >> 3) + 4096); s.cap = s.p ? need + (need >> 3) + 4096 : 0; }
+  return s.p;
+}
 struct ZnRange { size_t lo, hi; };                 // chunk range of one device
 ZnRange zn_range_of(size_t K, int g, int G) { return ZnRange{(size_t)g * K / (size_t)G, (size_t)(g + 1) * K / (size_t)G}; }
 uint64_t zn_rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
@@ -497,8 +507,15 @@ int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n
   if (ndev == 1) return zn_compress(hdr, hdr_len, src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[0], dst, dst_cap, dst_len);
   try {
     const size_t P = (size_t)num_buf, K = (n + chunk - 1) / chunk;
-    std::vector<std::vector<uint8_t>> part((size_t)ndev);
+    std::lock_guard<std::mutex> mk(g_multi_mu);
+    std::vector<uint8_t*> part((size_t)ndev, nullptr);
     std::vector<size_t> plen((size_t)ndev, 0);
+    for (int g = 0; g < ndev; g++) {                 // (staging reserved here: the worker threads only fill it)
+      const ZnRange r = zn_range_of(K, g, ndev);
+      if (r.hi <= r.lo) continue;
+      const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
+      if (!(part[(size_t)g] = zn_stage(g, zn_compress_bound(len, num_buf, chunk, 0) + 16))) return ZN_E_ALLOC;
+    }
     std::vector<int> rcs((size_t)ndev, ZN_OK);
     std::vector<std::thread> th;
     for (int g = 0; g < ndev; g++) {
@@ -507,9 +524,8 @@ int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n
       th.emplace_back([&, g, r]() {
         try {
           const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
-          part[(size_t)g].resize(zn_compress_bound(len, num_buf, chunk, 0) + 16);
           rcs[(size_t)g] = zn_compress(nullptr, 0, (const uint8_t*)src + off, len, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[g],
-                                       part[(size_t)g].data(), part[(size_t)g].size(), &plen[(size_t)g]);
+                                       part[(size_t)g], zn_compress_bound(len, num_buf, chunk, 0) + 16, &plen[(size_t)g]);
         } catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
       });
     }
@@ -523,23 +539,38 @@ int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n
     uint8_t* o = (uint8_t*)dst;
     if (hdr_len) memcpy(o, hdr, hdr_len);
     uint8_t* types = o + hdr_len; uint8_t* cums = types + P * K; uint8_t* pay = cums + 8 * P * K;
+    // where every (plane, range) piece goes and what re-bases its cumSizes; then the ranges are copied by one thread each
+    std::vector<size_t> dst_at((size_t)ndev * P, 0); std::vector<uint64_t> rebase((size_t)ndev * P, 0);
     size_t pay_at = 0;
     for (size_t p = 0; p < P; p++) {
       uint64_t run = 0;                              // bytes the earlier ranges put into plane p
       for (int g = 0; g < ndev; g++) {
         const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo;
         if (!k) continue;
-        const uint8_t* b = part[(size_t)g].data();
-        memcpy(types + p * K + r.lo, b + p * k, k);
-        const uint8_t* c = b + P * k + 8 * p * k;
-        for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(c + 8 * i) + run; memcpy(cums + 8 * (p * K + r.lo + i), &v, 8); }
-        size_t base = 0;                             // where plane p starts in this range's payload
-        for (size_t q = 0; q < p; q++) base += (size_t)zn_rd64(b + P * k + 8 * (q * k + k - 1));
-        const size_t tot = (size_t)zn_rd64(c + 8 * (k - 1));
-        memcpy(pay + pay_at, b + 9 * P * k + base, tot);
+        const size_t tot = (size_t)zn_rd64(part[(size_t)g] + P * k + 8 * (p * k + k - 1));
+        dst_at[(size_t)g * P + p] = pay_at; rebase[(size_t)g * P + p] = run;
         pay_at += tot; run += tot;
       }
     }
+    std::vector<std::thread> cp;
+    for (int g = 0; g < ndev; g++) {
+      const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo;
+      if (!k) continue;
+      cp.emplace_back([&, g, r, k]() {
+        const uint8_t* b = part[(size_t)g];
+        size_t base = 0;                             // where plane p starts in this range's payload
+        for (size_t p = 0; p < P; p++) {
+          memcpy(types + p * K + r.lo, b + p * k, k);
+          const uint8_t* c = b + P * k + 8 * p * k;
+          const uint64_t run = rebase[(size_t)g * P + p];
+          for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(c + 8 * i) + run; memcpy(cums + 8 * (p * K + r.lo + i), &v, 8); }
+          const size_t tot = (size_t)zn_rd64(c + 8 * (k - 1));
+          memcpy(pay + dst_at[(size_t)g * P + p], b + 9 * P * k + base, tot);
+          base += tot;
+        }
+      });
+    }
+    for (auto& t : cp) t.join();
     *dst_len = total;
     if (hdr_len >= 32) { const uint64_t t64 = total; memcpy(o + 24, &t64, 8); }   // zipnn_core.c:121
     return ZN_OK;
@@ -566,7 +597,18 @@ int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits
       for (size_t i = 0; i < K; i++) { const uint64_t v = zn_rd64(cums + 8 * (p * K + i)); if (v < prev || v > pay_len - acc) return ZN_E_CORRUPT; prev = v; }
       acc += prev;
     }
+    std::lock_guard<std::mutex> mk(g_multi_mu);
     std::vector<int> rcs((size_t)ndev, ZN_OK);
+    std::vector<uint8_t*> subs((size_t)ndev, nullptr);
+    auto sub_need = [&](const ZnRange& r) {
+      size_t need = 9 * P * (r.hi - r.lo);
+      for (size_t p = 0; p < P; p++) need += (size_t)(zn_rd64(cums + 8 * (p * K + r.hi - 1)) - (r.lo ? zn_rd64(cums + 8 * (p * K + r.lo - 1)) : 0));
+      return need;
+    };
+    for (int g = 0; g < ndev; g++) {
+      const ZnRange r = zn_range_of(K, g, ndev);
+      if (r.hi > r.lo && !(subs[(size_t)g] = zn_stage(g, sub_need(r) + 16))) return ZN_E_ALLOC;
+    }
     std::vector<std::thread> th;
     for (int g = 0; g < ndev; g++) {
       const ZnRange r = zn_range_of(K, g, ndev);
@@ -574,14 +616,10 @@ int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits
       th.emplace_back([&, g, r]() {
         try {
           const size_t k = r.hi - r.lo, off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
-          size_t need = 9 * P * k;
+          const size_t need = sub_need(r);
           std::vector<uint64_t> s0(P), s1(P);
-          for (size_t p = 0; p < P; p++) {
-            s0[p] = r.lo ? zn_rd64(cums + 8 * (p * K + r.lo - 1)) : 0; s1[p] = zn_rd64(cums + 8 * (p * K + r.hi - 1));
-            need += (size_t)(s1[p] - s0[p]);
-          }
-          std::vector<uint8_t> sub(need + 16);
-          uint8_t* w = sub.data();
+          for (size_t p = 0; p < P; p++) { s0[p] = r.lo ? zn_rd64(cums + 8 * (p * K + r.lo - 1)) : 0; s1[p] = zn_rd64(cums + 8 * (p * K + r.hi - 1)); }
+          uint8_t* w = subs[(size_t)g];
           for (size_t p = 0; p < P; p++) memcpy(w + p * k, types + p * K + r.lo, k);
           for (size_t p = 0; p < P; p++)
             for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(cums + 8 * (p * K + r.lo + i)) - s0[p]; memcpy(w + P * k + 8 * (p * k + i), &v, 8); }
@@ -659,6 +697,7 @@ int zn_debug_hold_device_lock(int dev, int ms) {
 #endif
 
 int zn_release_workspace(void) {
+  { std::lock_guard<std::mutex> mk(g_multi_mu); for (int i = 0; i < 64; i++) { free(g_multi_stage[i].p); g_multi_stage[i].p = nullptr; g_multi_stage[i].cap = 0; } }
   int prev = -1;
   if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }
   for (int d = 0; d < 64; d++) {
