@@ -27,6 +27,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, os.path.join(ROOT, "oracle", "_ref"))   # zipnn_core (reference C ext)
+sys.dont_write_bytecode = True                               # (nothing is written under /root/reference, not even __pycache__)
 sys.path.insert(1, "/root/reference")                        # zipnn (reference Python)
 
 

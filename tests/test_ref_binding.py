@@ -21,6 +21,7 @@ RUNNER = os.path.join(ROOT, "tests", "run_reference_cases.py")      # (NOT insid
 def _run(first_on_path, env_extra):
     env = dict(os.environ)
     env["PYTHONPATH"] = os.pathsep.join([first_on_path, REF])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"          # /root/reference is read-only to this repository: no __pycache__ next to its modules
     env.update(env_extra)
     r = subprocess.run([sys.executable, RUNNER], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -42,3 +43,21 @@ def test_stock_reference_package_runs_on_this_library_with_identical_frames(simt
     for name in sorted(ours):
         assert ours[name]["roundtrip"] and theirs[name]["roundtrip"], name
         assert ours[name] == theirs[name], name            # same frame bytes (sha256 + length) from both cores
+
+
+@pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "tests", "simple_stress_tests.py")), reason="/root/reference is not on this machine")
+def test_the_reference_s_own_stress_test_passes_on_this_library(simt_lib, tmp_path):
+    """`/root/reference/tests/simple_stress_tests.py`, unmodified and at its own sizes (bf16 tensors and random bytes around the
+    256 KiB / 1 MiB boundaries, streaming with five chunk sizes, delta, float32, and the safetensors scripts for fp16 / bf16 /
+    fp8), run by pytest in a subprocess with tests/ref_binding/ ahead of the reference on sys.path: the stock Python package, its
+    own assertions, this library underneath (emulated kernels here).  Runs in a scratch directory — the test writes its
+    temporary safetensors files into the cwd — and writes nothing under /root/reference (no bytecode, no pytest cache)."""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([os.path.join(ROOT, "tests", "ref_binding"), REF])
+    env["PYTHONDONTWRITEBYTECODE"] = "1"
+    env["ZIPNN_HIP_LIB"] = simt_lib.path
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(REF, "tests", "simple_stress_tests.py"), "-x", "-q", "-p", "no:cacheprovider",
+                        "--rootdir", str(tmp_path)], env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+    assert not os.path.isdir(os.path.join(REF, "zipnn", "__pycache__"))
