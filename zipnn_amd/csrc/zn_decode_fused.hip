@@ -7,27 +7,31 @@
 //   1. one thread per (chunk, plane) parses the metadata; wave j turns chunk j's tree description into
 //      the canonical symbol order (zn_huf_wave.hpp: FSE chain on the scalar ALU, everything else with
 //      ballots) — four serial jobs side by side; then, chunk by chunk, all 256 threads fill the
-//      single-symbol LUT and from it the MULTI-symbol LUT: per 11-bit window up to 5 symbols, the bit
-//      offset at which each of them starts, the total.
+//      single-symbol LUT and from it the MULTI-symbol LUT: one 8-byte entry per 11-bit window = the (up to) 4
+//      symbols that start in it + a meta word (bits they take, their count, the bit offsets of symbols 2-4).
 //   2. each wave decodes its backward bit-stream IN PARALLEL ACROSS ITS 64 LANES.  huff0 has no gap array,
 //      so this uses Huffman self-synchronisation, format-transparently: the stream is cut into tiles of 64
-//      sub-blocks of D dwords (D from the stream's average code length); lane k guesses a start 16 bits
-//      above its sub-block, decodes until it crosses into it ("sync"), then decodes its sub-block counting
-//      symbols ("refill + 3 whole-group steps", then a boundary step that takes exactly the symbols that
-//      start above the sub-block's end); a wave shuffle checks that every lane's exit position is the next
-//      lane's start (mismatching lanes restart from the exact position until the chain is consistent, and
-//      the run-in is doubled for the rest of the stream — the top lane always starts from the true
-//      position carried from the previous tile); a prefix sum of the counts gives each lane its output
-//      offset and a second decode ORs the symbols into a small LDS staging buffer (ds_or_b32: neighbouring
-//      lanes share boundary dwords; a tile denser than expected is written in lane groups).
+//      sub-blocks of D dwords (D from the stream's average code length; D = 4 is the compile-time instance).
+//      The register-resident form (zn_decode_chain.hpp) takes a tile like this: lane k guesses a start 22 bits
+//      above its sub-block and runs into it ("sync": two whole-group steps + a boundary step on one window
+//      refill); then every lane decodes its sub-block ONCE, each step's 4 symbols and count going into named
+//      registers (zn_pass1: refill + whole-group steps, closed by boundary steps that take exactly the symbols
+//      that start above the sub-block's end); a wave shuffle checks that every lane's exit position is the next
+//      lane's start (a mismatch re-runs the pass from the exact positions; the top lane always starts from the
+//      true position carried from the previous tile, so the result is exact); a prefix sum of the counts gives
+//      each lane its output offset and zn_pass2 shifts the recorded groups into place (v_alignbyte_b32) and ORs
+//      them into a small LDS staging buffer (ds_or_b32, aligned dwords only: neighbouring lanes share boundary
+//      dwords).  What that form does not take (more steps than it has registers for, a chain four iterations do
+//      not close, a tile denser than the staging buffer, a run-time D) is decoded by the looping form: a
+//      counting pass and a writing pass over the same chain (zn_fused_run), in lane groups when needed.
 //   3. the number of complete output rows is known after the prefix sum, so the raw planes' bytes for
-//      exactly those rows are requested from HBM before the write pass and consumed after it: staging
+//      exactly those rows are requested from HBM before the compaction and consumed after it: staging
 //      bytes + raw bytes get the sign-bit rotate undone at plane level, are byte-interleaved with
 //      v_perm_b32 and go out as coalesced 16-byte stores.  The next tile of the stream is prefetched
 //      into registers the same way and copied into its LDS buffer inside this flush — behind the flush's one
 //      wait, ahead of its stores — so that no wave ever waits for a store to be acknowledged (gfx9 counts loads
 //      and stores on one in-order counter).  Decoded symbols never touch HBM; the float stream is written once.
-//   4. wave priorities (s_setprio) rise with the progress through a tile: sync 1, count 2, write 3, the rest 0 —
+//   4. wave priorities (s_setprio) rise with the progress through a tile: sync 1, decode 2, compaction 3, the rest 0 —
 //      the passes are chains of dependent LDS look-ups and should issue ahead of the other waves' flush code.
 //
 // A launch decodes one tensor or a batch (segment table, zn_internal.hpp); the Huffman planes of partial

@@ -1,4 +1,4 @@
-// zn_encode_fused.hip — the bandwidth path of compress: two kernels around one tiny scan, no scratch
+// zn_encode_fused.hip — the bandwidth path of compress: three kernels and one tiny scan, no scratch
 // planes, every compressed byte written once, directly at its final position in the frame body.
 //
 // The wire format is plane-major (all chunks of plane 0, then plane 1, …), so where a chunk's bytes go
@@ -7,19 +7,24 @@
 //
 //   zn_k_encode_stats<P>   one workgroup per full chunk, wave w = quarter w = stream w:
 //                          rotate + split on the fly, byte histograms with bank-conflict-free LDS atomics
-//                          (packed 16-bit counters, one column per lane of a half-wave);
-//                          HUF_compress control flow per plane (RLE / "not compressible" heuristic /
-//                          exact code lengths + tree description, zn_huf_tables.hpp), stream sizes by summing
-//                          code lengths over each quarter, capacity and threshold rules → type + stored size per (plane, chunk);
-//                          kept planes leave their code table + tree description in a small descriptor.
+//                          (packed 16-bit counters, one column per lane of a half-wave), quarter by quarter —
+//                          which yields the per-stream symbol counts; the cheap exits of HUF_compress (RLE,
+//                          "not compressible") decided here, the other planes marked for a code table.
+//   zn_k_encode_tables     one wave per marked (plane, chunk): HUF_sort as a rank sort over the lanes, the serial
+//                          part of HUF_compress on lane 0 (tree, length limiting, tree description incl. its FSE
+//                          coding: zn_huf_tables.hpp), symbol-parallel the rest; stream sizes = per-quarter counts ·
+//                          code lengths, capacity and threshold rules → type + stored size; kept planes leave their
+//                          code table + tree description in a small descriptor.
 //   zn_k_scan_sizes        (zn_encode_generic.hip) per-plane inclusive scan → types, cumSizes, offsets, total.
-//   zn_k_encode_emit<P>    one workgroup per full chunk: re-reads the chunk (L2 / Infinity Cache), writes raw
+//   zn_k_encode_emit<P>    one workgroup per full chunk: re-reads the chunk, writes raw
 //                          planes straight to their payload position and bit-packs the 4 streams of a Huffman
 //                          plane in place: each lane packs the codes of 32 consecutive symbols in registers,
 //                          a wave prefix sum of the bit counts gives its bit offset in the tile, `ds_or_b32`
 //                          merges the lanes' words in an LDS tile buffer, full dwords go out coalesced.
 //
-// Algorithmic HBM bytes: N in + C out; this design reads N twice (second read mostly cache-resident).
+// Algorithmic HBM bytes: N in + C out; this design reads N twice — 2 N + C, which is what the plane-major layout costs
+// any encoder of a tensor larger than the Infinity Cache (no byte of plane 1 can be placed before the
+// sizes of ALL chunks of plane 0 are known).
 // Chunks these kernels do not take (the partial tail; or everything when chunk % (8192·P) ≠ 0 or planes
 // exceed 128 KiB) are handled by zn_encode_generic.hip — the host splits the chunk range.
 //
