@@ -645,3 +645,40 @@ def test_multi_device_entry_points_on_the_one_gpu_here(lib, devices):
     assert bytes(lib.compress_multi(HDR, x, 4, 1, 220, C, 0.95, devices)) == want
     assert bytes(lib.decompress_multi(want[32:], 4, 1, 220, C, len(x), devices)) == x
     assert torch.cuda.current_device() == 0
+
+
+def test_damaged_bodies_are_rejected_or_decoded_never_fatal(lib):
+    """The CPU suite's random-damage test (tests/test_kernels_simt.py) on the device: bytes flipped in the size tables, in
+    tree descriptions / jump tables, anywhere; truncated bodies.  Every call either raises one of the documented
+    exceptions or returns bytes; the device is left usable — the undamaged body decodes bit-exactly right after each."""
+    from zipnn_amd import codec
+    r = np.random.default_rng(99)
+    cases = [("bf16", 9 * C + 5000, 2, 1, 10, C), ("fp32", 5 * C + 4, 4, 1, 220, C), ("fp8", 4 * C + 20001, 1, 0, 10, C // 2)]
+    for kind, nb, P, rot, bm, chunk in cases:
+        d = gen_bytes(kind, nb, 23)
+        body = bytearray(O.compress_frame(HDR, d, P, rot, bm, chunk)[32:])
+        good = torch.frombuffer(bytearray(body), dtype=torch.uint8).cuda()
+        want = torch.frombuffer(bytearray(d), dtype=torch.uint8)
+        K = (nb + chunk - 1) // chunk
+        meta = 9 * P * K
+        rejected = 0
+        for trial in range(40):
+            b = bytearray(body)
+            mode = trial % 4
+            if mode == 0:
+                b[int(r.integers(0, meta))] ^= int(r.integers(1, 256))
+            elif mode == 1:
+                b[meta + int(r.integers(0, min(200, len(b) - meta)))] ^= int(r.integers(1, 256))
+            elif mode == 2:
+                for _ in range(8):
+                    b[int(r.integers(0, len(b)))] ^= int(r.integers(1, 256))
+            else:
+                b = b[: int(r.integers(1, len(b)))]
+            t = torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda()
+            try:
+                codec.decompress_device(lib, t, P, rot, bm, chunk, nb)
+            except (RuntimeError, MemoryError, ValueError):
+                rejected += 1
+            out = codec.decompress_device(lib, good, P, rot, bm, chunk, nb)
+            assert torch.equal(out.cpu(), want)
+        assert rejected >= 10          # truncations and size-table damage at the least
