@@ -273,7 +273,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = world > 1
+    dist = world > 1 or ("LOCAL_RANK" in os.environ and "MASTER_ADDR" in os.environ)   # (under torch.distributed.run even a single rank takes the RCCL path)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     td = None
