@@ -448,6 +448,30 @@ def test_replicated_decode_single_rank(lib):
 
 
 @pytest.mark.gpu
+def test_replicated_decode_through_rccl_with_a_group_of_one(lib):
+    """The exchange step of sharding.decompress_replicated on the device: a one-rank `nccl` (= RCCL) process group, so that
+    the decoded shard goes through all_gather_into_tensor on the GPU (the 2-rank case: tests/test_sharding_gloo.py on CPU;
+    more GPUs than one are the driver's)."""
+    import socket
+    import torch.distributed as dist
+    from test_oracle import gen_bytes
+    from zipnn_amd import sharding
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        nb = 11 * C + 777
+        d = gen_bytes("bf16", nb, 6)
+        body = O.compress_frame(b"", d, 2, 1, 10, C, threads=4)
+        out = sharding.decompress_replicated(lib, body, 2, 1, 10, C, nb, torch.device("cuda:0"))
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == d
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
 def test_pinned_host_pipe_copies_and_host_entry_points(lib, monkeypatch):
     """zn_copy_to_device / zn_copy_to_host (the pinned, multi-threaded transfer of zn_host_pipe.hpp) move pageable
     buffers bit-exactly for sizes around its slice and stripe boundaries, with several thread counts; the

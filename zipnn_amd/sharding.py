@@ -98,7 +98,7 @@ def decompress_replicated(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig
         sub, off, length = split_body(body, num_buf, chunk, orig_size, world, ranges)[rank]
         sub_t = codec.to_device(lib, sub, device)          # (the library's pinned multi-threaded transfer)
         codec.decompress_device(lib, sub_t, num_buf, bits_mode, bytes_mode, chunk, length, out=full[off:off + length])
-    if world > 1:
+    if dist.is_initialized():                                           # (a group of one still goes through the collective: RCCL on GPUs)
         mine = full[rank * shard:(rank + 1) * shard].clone()            # (gloo does not take an aliasing input)
         dist.all_gather_into_tensor(full[:shard * world], mine, group=group)
     return full[:orig_size]
