@@ -168,5 +168,16 @@ int main(int argc, char** argv) {
     row("decode-shaped, nt, 4 WG/CU: 8 rows per burst, the four waves' rows ADJACENT (one 4 KiB span per step)", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 8, 1>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
     row("decode-shaped, nt, 4 WG/CU: 4 rows per burst, the four waves' rows ADJACENT", bytes, [&] { hipLaunchKernelGGL((k_decode_shape2<1, 0, 4, 1>), dim3(blocks), dim3(256), 0, 0, a, b, (size_t)16384, (size_t)173600); });
   }
+  {
+    // per-lane access width: the decode reads its raw rows 8 bytes per lane and its stream tiles 4 bytes per lane
+    typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+    const int blocks = CUS * 4;
+    row("read 4 GiB: span 64 KiB per WG step, 16 B/lane x4, nt, 4 WG/CU", N, [&] { hipLaunchKernelGGL((k_span<v4u, 1, 1, 4>), dim3(blocks), dim3(256), 0, 0, (const v4u*)a, (v4u*)b, (size_t)0, N / 16, (size_t)65536 / 16); });
+    row("read 4 GiB: span 64 KiB per WG step,  8 B/lane x4, nt, 4 WG/CU", N, [&] { hipLaunchKernelGGL((k_span<v2u, 1, 1, 4>), dim3(blocks), dim3(256), 0, 0, (const v2u*)a, (v2u*)b, (size_t)0, N / 8, (size_t)65536 / 8); });
+    row("read 4 GiB: span 64 KiB per WG step,  8 B/lane x8, nt, 4 WG/CU", N, [&] { hipLaunchKernelGGL((k_span<v2u, 1, 1, 8>), dim3(blocks), dim3(256), 0, 0, (const v2u*)a, (v2u*)b, (size_t)0, N / 8, (size_t)65536 / 8); });
+    row("read 4 GiB: span 64 KiB per WG step,  4 B/lane x4, nt, 4 WG/CU", N, [&] { hipLaunchKernelGGL((k_span<uint32_t, 1, 1, 4>), dim3(blocks), dim3(256), 0, 0, (const uint32_t*)a, (uint32_t*)b, (size_t)0, N / 4, (size_t)65536 / 4); });
+    row("read 4 GiB: span 64 KiB per WG step,  4 B/lane x8, nt, 4 WG/CU", N, [&] { hipLaunchKernelGGL((k_span<uint32_t, 1, 1, 8>), dim3(blocks), dim3(256), 0, 0, (const uint32_t*)a, (uint32_t*)b, (size_t)0, N / 4, (size_t)65536 / 4); });
+    row("read 4 GiB: span 64 KiB per WG step,  4 B/lane x16, nt, 4 WG/CU", N, [&] { hipLaunchKernelGGL((k_span<uint32_t, 1, 1, 16>), dim3(blocks), dim3(256), 0, 0, (const uint32_t*)a, (uint32_t*)b, (size_t)0, N / 4, (size_t)65536 / 4); });
+  }
   return 0;
 }
