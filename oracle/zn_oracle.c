@@ -274,6 +274,16 @@ static size_t fse_compress_with(uint8_t* dst, size_t cap, const uint8_t* src, si
   return bitw_close(&w);
 }
 
+/* How the weight coder writes a count that rounds below one table cell.  zstd >= 1.4.7 (this oracle's pin, and what the
+ * product's encoder emits) passes useLowProbCount = 0 to FSE_normalizeCount from HUF_compressWeights: such a weight gets a
+ * full cell (+1).  The huff0 of the FiniteStateEntropy library the reference's PyPI wheels are built from
+ * (/root/reference/setup.py:23-28, .gitmodules:4-6; un-vendored) predates that parameter and always writes the
+ * "less than one" marker (-1): the symbol gets the table's top cell.  Both forms decode with every huff0 decoder; only the
+ * tree-description bytes differ.  -1 here makes the oracle write what a real wheel writes (tests of the decoders only). */
+static int g_weight_low_prob = +1;
+void zo_set_weight_low_prob(int v) { g_weight_low_prob = (v < 0) ? -1 : +1; }
+int zo_get_weight_low_prob(void) { return g_weight_low_prob; }
+
 /* HUF_compressWeights: 0 = not compressible, 1 = single value, else size / error */
 static size_t huf_compress_weights(uint8_t* dst, size_t cap, const uint8_t* w, size_t nw) {
   unsigned count[HUF_LOG_MAX + 1] = {0};
@@ -288,7 +298,7 @@ static size_t huf_compress_weights(uint8_t* dst, size_t cap, const uint8_t* w, s
   if (max_c == nw) return 1;
   if (max_c == 1) return 0;
   tl = zo_optimal_table_log(WEIGHT_FSE_LOG, nw, max_sv, 2);
-  { size_t e = zo_fse_normalize_count(norm, tl, count, nw, max_sv, +1); if (zo_huf_is_error(e)) return e; }
+  { size_t e = zo_fse_normalize_count(norm, tl, count, nw, max_sv, g_weight_low_prob); if (zo_huf_is_error(e)) return e; }
   { size_t h = fse_write_ncount(op, norm, max_sv, tl); if (zo_huf_is_error(h)) return h; op += h; }
   fse_build_ctable(st, tt, norm, max_sv, tl);
   { size_t c = fse_compress_with(op, cap - (size_t)(op - dst), w, nw, st, tt, tl); if (c == 0) return 0; op += c; }

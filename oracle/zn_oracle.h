@@ -64,6 +64,11 @@ size_t zo_huf_read_stats(uint8_t* weights, unsigned* n_sym, unsigned* table_log,
 size_t zo_fse_normalize_count(short* norm, unsigned table_log, const unsigned* count,
                               size_t total, unsigned max_sv, int low_prob);
 
+/* Low-probability weight counts in the tree description: +1 (default; zstd 1.4.8, the pin) or -1 (the legacy
+ * FiniteStateEntropy huff0 that the reference's PyPI wheels bundle).  Process-wide; set before compressing. */
+void zo_set_weight_low_prob(int v);
+int zo_get_weight_low_prob(void);
+
 /* ---- byte-plane transforms (one chunk) ---- */
 /* In-place sign-bit rotate over len/4 words, as the reference does it (a trailing
  * 2-byte element of a 16-bit stream is left un-rotated). num_buf = 2 or 4. */

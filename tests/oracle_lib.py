@@ -4,6 +4,7 @@ oracle/_ref/zipnn_core.so (the reference csrc/ compiled from /root/reference).
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg.  The product package (zipnn_amd/) never imports this module.
 """
+import contextlib
 import ctypes
 import importlib.util
 import os
@@ -55,8 +56,26 @@ def lib():
         L.zo_decompress_body.restype = ctypes.c_int
         L.zo_decompress_body.argtypes = [u8p, sz, ctypes.c_int, ctypes.c_int, ctypes.c_int, sz, sz,
                                          ctypes.c_int, u8p]
+        L.zo_set_weight_low_prob.restype = None
+        L.zo_set_weight_low_prob.argtypes = [ctypes.c_int]
+        L.zo_get_weight_low_prob.restype = ctypes.c_int
         _LIB = L
     return _LIB
+
+
+@contextlib.contextmanager
+def legacy_weights():
+    """Inside this block the oracle's ENCODER writes tree descriptions the way the legacy FiniteStateEntropy huff0
+    does — the one the reference's PyPI wheels bundle (/root/reference/setup.py:23-28): weight counts that round below
+    one FSE cell are written as -1 ("less than one"), where zstd >= 1.4.7 writes +1.  Both decode everywhere; the
+    frames differ in the tree-description bytes only.  Used to feed the decoders what real wheels produce."""
+    L = lib()
+    old = L.zo_get_weight_low_prob()
+    L.zo_set_weight_low_prob(-1)
+    try:
+        yield
+    finally:
+        L.zo_set_weight_low_prob(old)
 
 
 def _ptr(a):

@@ -1,0 +1,207 @@
+"""Tree descriptions as REAL zipnn wheels write them (legacy FiniteStateEntropy huff0: low-probability weight counts as -1,
+where the zstd 1.4.8 pin of this repository's encoder writes +1; /root/reference/setup.py:23-28, csrc/zipnn_core.c:807).
+
+The decoders must read both.  `tests/golden/golden_legacy_v1.npz` (generator committed, frames validated against
+oracle/_ref at generation time) pins the -1 frames; live frames add geometries the fixture is too small for.  CPU tests
+run the product's kernels under the SIMT emulator; the `-m gpu` tests run the same frames through the C ABI on the device
+(`zn_decompress`, `zn_decompress_dev`, `zn_decompress_batch_dev`, the safetensors plugin) and assert that the fused kernel
+— whose tree-description parser (zn_huf_wave.hpp, the `norm[s] == -1` cells) is the code under test — is what decoded them."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+from test_oracle import gen_bytes
+
+HDR = bytes(range(32))
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_legacy_v1.npz")
+
+
+def _golden():
+    z = np.load(_PATH)
+    meta = json.loads(bytes(z["meta.json"]).decode())
+    return [(m, bytes(z[m["name"] + ".frame"])) for m in meta]
+
+
+GOLD = _golden()
+IDS = [m["name"] for m, _ in GOLD]
+
+
+def _sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def _full_chunks(m):
+    return m["in_len"] // m["chunk"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# CPU: the oracle's -1 writer is pinned; the reference build and the emulated product decode the frames
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,frame", GOLD, ids=IDS)
+def test_oracle_reproduces_the_legacy_golden(m, frame):
+    d = gen_bytes(m["kind"], m["in_len"], m["seed"])
+    assert _sha(d) == m["in_sha256"] and _sha(frame) == m["frame_sha256"]
+    with O.legacy_weights():
+        again = O.compress_frame(HDR, d, m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"])
+    assert again == frame
+    plain = O.compress_frame(HDR, d, m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"])       # (the switch is restored)
+    assert _sha(plain) == m["plus1_frame_sha256"] and plain != frame
+    assert O.decompress_body(frame[32:], m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"], m["in_len"]) == d
+
+
+@pytest.mark.parametrize("m,frame", GOLD, ids=IDS)
+def test_reference_build_decodes_the_legacy_golden(m, frame):
+    if O.ref_core() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference on this host)")
+    d = gen_bytes(m["kind"], m["in_len"], m["seed"])
+    assert O.ref_decompress_body(frame[32:], m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"], m["in_len"], 2) == d
+
+
+@pytest.mark.parametrize("m,frame", GOLD, ids=IDS)
+def test_emulated_product_decodes_the_legacy_golden(simt_lib, m, frame):
+    d = gen_bytes(m["kind"], m["in_len"], m["seed"])
+    got = simt_lib.decompress(frame[32:], m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"], m["in_len"])
+    assert bytes(got) == d
+    assert simt_lib.last_fused_chunks() == _full_chunks(m)          # the fused kernel's own tree-description parser read them
+    if m["in_len"] % m["chunk"] >= 4096 * m["num_buf"]:
+        assert simt_lib.last_tail_planes() >= 1                      # ... and the tail workgroups' (same parser, ragged streams)
+
+
+def test_emulated_product_decodes_a_legacy_batch(use_simt):
+    """A safetensors shard's worth of -1 frames (every dtype, ragged sizes) in ONE batched call."""
+    from zipnn_amd import codec
+    items, want = [], []
+    for m, frame in GOLD:
+        body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8)
+        items.append((body, m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"], m["in_len"]))
+        want.append(gen_bytes(m["kind"], m["in_len"], m["seed"]))
+    outs = codec.decompress_device_batch(use_simt, items)
+    for o, w, (m, _) in zip(outs, want, GOLD):
+        assert o.numpy().tobytes() == w, m["name"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU: the same frames through the C ABI on the device
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def lib():
+    from zipnn_amd import _capi
+    L = _capi.lib()
+    assert L.device_count() >= 1
+    return L
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,frame", GOLD, ids=IDS)
+def test_gpu_decodes_the_legacy_golden(lib, m, frame):
+    from zipnn_amd import codec
+    d = gen_bytes(m["kind"], m["in_len"], m["seed"])
+    P, rot, bm, chunk, n = m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"], m["in_len"]
+    assert bytes(lib.decompress(frame[32:], P, rot, bm, chunk, n)) == d                      # zn_decompress (host buffers)
+    assert lib.last_fused_chunks() == _full_chunks(m)
+    body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8).cuda()
+    out = codec.decompress_device(lib, body, P, rot, bm, chunk, n)                             # zn_decompress_dev
+    torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == d
+    assert lib.last_fused_chunks() == _full_chunks(m) and "zn_k_decode_fused" in lib.last_kernels()
+    if n % chunk >= 4096 * P:
+        assert lib.last_tail_planes() >= 1
+
+
+LIVE = [("bf16", 24 * 256 * 1024 + 250_000, 2, 1, 10, 256 * 1024), ("fp16", 16 * 256 * 1024, 2, 0, 10, 256 * 1024),
+        ("fp32", 16 * 256 * 1024 + 4, 4, 1, 220, 256 * 1024), ("fp8", 33 * 128 * 1024 + 77, 1, 1, 10, 128 * 1024)]
+
+
+@pytest.mark.gpu
+def test_gpu_decodes_legacy_frames_single_and_batched(lib):
+    """Larger -1 frames made here by the oracle (the fixture is kept small): each alone through zn_decompress_dev, then all
+    of them — with the golden ones — in one zn_decompress_batch_dev call."""
+    from zipnn_amd import codec
+    items, want = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(LIVE):
+        d = gen_bytes(kind, nb, 60 + i)
+        plain = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)
+        with O.legacy_weights():
+            frame = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=4)
+        assert frame != plain
+        body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8).cuda()
+        out = codec.decompress_device(lib, body, P, rot, bm, chunk, nb)
+        torch.cuda.synchronize()
+        assert out.cpu().numpy().tobytes() == d, kind
+        assert lib.last_fused_chunks() == nb // chunk, kind
+        items.append((body, P, rot, bm, chunk, nb)); want.append(d)
+    for m, frame in GOLD:
+        items.append((torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8).cuda(), m["num_buf"], m["bits_mode"], m["bytes_mode"], m["chunk"], m["in_len"]))
+        want.append(gen_bytes(m["kind"], m["in_len"], m["seed"]))
+    outs = codec.decompress_device_batch(lib, items)
+    torch.cuda.synchronize()
+    for o, w in zip(outs, want):
+        assert o.cpu().numpy().tobytes() == w
+    assert "zn_k_decode_fused" in lib.last_kernels()
+    assert lib.last_fused_chunks() == sum(it[5] // it[4] for it in items)
+
+
+def _legacy_reencode(frame_bytes):
+    """A ZN frame of this repository's producer -> the same tensor as a -1 frame (what the PyPI wheel would have written)."""
+    import golden_util as G
+    p = G.parse_frame(bytes(frame_bytes))
+    raw = O.decompress_body(p["body"], p["num_buf"], p["bits_mode"], p["bytes_mode"], p["chunk"], p["orig_len"])
+    with O.legacy_weights():
+        return O.compress_frame(p["header"], raw, p["num_buf"], p["bits_mode"], p["bytes_mode"], p["chunk"], threads=4)
+
+
+@pytest.mark.gpu
+def test_plugin_loads_a_checkpoint_written_with_legacy_descriptions(lib, tmp_path):
+    """A `.znn.safetensors` file whose frames carry -1 tree descriptions — what a file compressed with the PyPI wheel holds —
+    through zipnn_safetensors() + safe_open(device="cuda:0") and through safetensors_io.load_file (one batched decode)."""
+    import safetensors
+    import safetensors.torch
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    g = torch.Generator().manual_seed(77)
+    tensors = {"w_bf16": (torch.randn(1100, 513, generator=g) * 0.02).to(torch.bfloat16),
+               "w_fp16": (torch.randn(700, 300, generator=g) * 0.02).to(torch.float16),
+               "w_fp32": torch.randn(513, 257, generator=g) * 0.02,
+               "w_fp8": (torch.randn(900, 400, generator=g) * 0.02).to(torch.float8_e4m3fn),
+               "ids": torch.arange(5000, dtype=torch.int64)}
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    znn = safetensors_io.compress_safetensors_file(src)
+    # rewrite every compressed tensor as a -1 frame, metadata untouched
+    with safetensors.safe_open(znn, "pt", "cpu") as f:
+        meta = dict(f.metadata())
+        blobs = {k: f.get_tensor(k) for k in f.keys()}
+    changed = 0
+    for k in list(blobs):
+        if k.startswith("w_"):
+            old = blobs[k].numpy().tobytes()
+            new = _legacy_reencode(old)
+            changed += int(new != old)
+            blobs[k] = torch.frombuffer(bytearray(new), dtype=torch.uint8)
+    assert changed == 4
+    legacy = os.path.join(tmp_path, "legacy.znn.safetensors")
+    save_file(blobs, legacy, meta)
+
+    def tsha(t):
+        return _sha(t.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes())
+    loaded = safetensors_io.load_file(legacy, device="cuda:0")
+    for k, v in tensors.items():
+        assert loaded[k].is_cuda and loaded[k].dtype == v.dtype and loaded[k].shape == v.shape and tsha(loaded[k]) == tsha(v), k
+    orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
+    try:
+        zipnn_safetensors()
+        with safetensors.safe_open(legacy, framework="pt", device="cuda:0") as f:
+            for k, v in tensors.items():
+                got = f.get_tensor(k)
+                assert got.is_cuda and tsha(got) == tsha(v), k
+                if k.startswith("w_"):
+                    assert "zn_k_decode" in lib.last_kernels()
+    finally:
+        safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+        from zipnn_amd import zipnn as _Z
+        _Z._patches_applied.pop(_Z._zipnn_safetensors, None)
