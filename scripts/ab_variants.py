@@ -78,6 +78,15 @@ VARIANTS = {
     "d32": (None, ["-DZN_F_DELTA0=32"]),
     "p2m1": (None, ["-DZN_F_P2_MASK=1"]),
     "p2m2": (None, ["-DZN_F_P2_MASK=2"]),
+    # round 3
+    "r02": ("8959d1d", []),                         # the kernels of the round-2 final state
+    "noah": (None, ["-DZN_F_AHEAD2=0"]),
+    "d33": (None, ["-DZN_F_DELTA0=33"]),
+    "d33noah": (None, ["-DZN_F_DELTA0=33", "-DZN_F_AHEAD2=0"]),
+    "at3": (None, ["-DZN_F_AHEAD_AT=3"]),
+    "at0": (None, ["-DZN_F_AHEAD_AT=0"]),
+    "nmis1": (None, ["-DZN_F_NMIS=1"]),
+    "nmis2": (None, ["-DZN_F_NMIS=2"]),
 }
 
 
@@ -115,6 +124,9 @@ def load(path):
     return L
 
 
+ALLD = ("r01", "r02", "c1", "prev", "new", "notile0", "d33", "nmis1", "nmis2", "d33noah")
+
+
 def run(names):
     import torch
     libs = [(n, load(so_path(n))) for n in names if os.path.exists(so_path(n))]
@@ -122,11 +134,11 @@ def run(names):
     C = 262144
     f8 = getattr(torch, "float8_e4m3fn", None)
     cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16, None),
-             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ("r01", "c1", "prev", "new", "notile0")),
-             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ("r01", "c1", "prev", "new", "notile0")),
-             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ("r01", "c1", "prev", "new", "notile0"))]
+             ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16, ALLD),
+             ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32, ALLD),
+             ("bf16 256MiB", 256 << 20, 2, 1, 10, torch.bfloat16, ALLD)]
     if f8 is not None:
-        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ("r01", "c1", "prev", "new", "notile0")))
+        cases.append(("fp8 1GiB", 1 << 30, 1, 0, 10, f8, ALLD))
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Developer tool: build libzipnn_hip_prof.so (-DZN_PHASE_TIMERS) and print where wave 0 of the
 fused decode kernel spends its shader-clock cycles, per chunk.  Runs on the GPU box:
-    python scripts/phase_profile.py [GiB]
+    python scripts/phase_profile.py [GiB] [bf16|fp16|fp32|fp8] [-Dflag ...]
+(`--build-only` compiles the library and exits: done in the build container, the .so travels with the snapshot.)
 """
 import ctypes
 import os
@@ -19,36 +20,46 @@ NAMES = {0: "metadata", 1: "tree description (serial)", 2: "LUT fill", 3: "flush
          6: "decode pass", 7: "fix-up passes", 8: "scan/shuffles", 9: "compaction / write pass"}
 
 
+GEOM = {"bf16": (torch.bfloat16, 2, 1, 10, 256 * 1024), "fp16": (torch.float16, 2, 0, 10, 256 * 1024),
+        "fp32": (torch.float32, 4, 1, 220, 256 * 1024), "fp8": (getattr(torch, "float8_e4m3fn", None), 1, 0, 10, 128 * 1024)}
+
+
 def main():
-    gib = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+    args = [a for a in sys.argv[1:] if not a.startswith("-")]
+    gib = float(args[0]) if args else 1.0
+    kind = args[1] if len(args) > 1 else "bf16"
     so = os.path.join(ROOT, "zipnn_amd", "libzipnn_hip_prof.so")
-    extra = [a for a in sys.argv[2:] if a.startswith("-D")]
-    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZN_PHASE_TIMERS",
-                    "-o", so] + extra + sources(), check=True)
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    if extra or "--build-only" in sys.argv or not os.path.exists(so):
+        subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZN_PHASE_TIMERS",
+                        "-o", so] + extra + sources(), check=True)
+    if "--build-only" in sys.argv:
+        return
     lib = _capi.ZnLib(so)
     raw = ctypes.CDLL(so)
-    n = int(gib * (1 << 30)) // (256 * 1024) * (256 * 1024)
+    dt, P, rot, bm, chunk = GEOM[kind]
+    n = int(gib * (1 << 30)) // chunk * chunk
     torch.manual_seed(1)
-    x = (torch.randn(n // 2, device="cuda") * 0.02).to(torch.bfloat16)
+    x = (torch.randn(n // torch.empty(0, dtype=dt).element_size(), device="cuda") * 0.02).to(dt)
     flat = codec.flat_bytes(x)
-    body = codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95).clone()
+    body = codec.compress_device(lib, flat, P, rot, bm, chunk, 0.95).clone()
     out = torch.empty(n, dtype=torch.uint8, device="cuda")
     acc = (ctypes.c_ulonglong * 64)()
-    codec.decompress_device(lib, body, 2, 1, 10, 256 * 1024, n, out=out)
+    codec.decompress_device(lib, body, P, rot, bm, chunk, n, out=out)
     raw.zn_debug_phase_read(acc, 1)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
-    codec.decompress_device(lib, body, 2, 1, 10, 256 * 1024, n, out=out, check=False)
+    codec.decompress_device(lib, body, P, rot, bm, chunk, n, out=out, check=False)
     t1.record(); torch.cuda.synchronize()
     raw.zn_debug_phase_read(acc, 1)
     assert torch.equal(out, flat)
     chunks = acc[19] or 1
     tot = sum(acc[i] for i in range(10))
-    print(f"{gib} GiB, {chunks} chunks, decode {t0.elapsed_time(t1):.3f} ms (with timers)")
+    print(f"{kind} {gib} GiB, {chunks} chunks of {chunk >> 10} KiB, ratio {body.numel() / n:.4f}, decode {t0.elapsed_time(t1):.3f} ms (with timers)")
     for i in range(10):
         print(f"  {NAMES[i]:28s} {acc[i] / chunks:10.0f} cyc/chunk  {100.0 * acc[i] / tot:5.1f} %")
     print(f"  total                        {tot / chunks:10.0f} cyc/chunk")
-    for i, nm in () if not any("ZN_PHASE_TIMERS_SUB" in a for a in sys.argv) else ((10, "readNCount"), (11, "FSE decode table"), (12, "FSE state chain"), (13, "stage+weights total"), (14, "weight statistics"), (15, "canonical order")):
+    for i, nm in () if not any("ZN_PHASE_TIMERS_SUB" in a or a == "--sub" for a in sys.argv) else ((10, "readNCount"), (11, "FSE decode table"), (12, "FSE state chain"), (13, "stage+weights total"), (14, "weight statistics"), (15, "canonical order")):
         print(f"    tree description / {nm:22s} {acc[i] / chunks:10.0f} cyc/chunk")
     print(f"  (in flush) wait for fetched rows {acc[10] / chunks:10.0f} cyc/chunk")
     print(f"  wait for slowest wave at chunk start {acc[21] / chunks:10.0f} cyc/chunk")
@@ -56,7 +67,7 @@ def main():
           f"mismatching lanes/tile {acc[17] / max(acc[18], 1):.3f}  tiles in the looping form {acc[22] / max(acc[18], 1):.3f}")
     # encoder statistics kernel
     raw.zn_debug_phase_read_enc(acc, 1)
-    codec.compress_device(lib, flat, 2, 1, 10, 256 * 1024, 0.95)
+    codec.compress_device(lib, flat, P, rot, bm, chunk, 0.95)
     raw.zn_debug_phase_read_enc(acc, 1)
     ch = acc[19] or 1
     jobs = acc[18] or 1

@@ -191,10 +191,11 @@ class ZipNN:
                 raise ValueError("Length of delta file has to match the length of the original file.")
         elif delta_second_data is not None:
             raise ValueError("ZipNN isn't set for delta compression, but delta_second_data is not null.")
+        delta_second_data = _delta_bytes(delta_second_data)      # (bytes view or None; never tested for truth as an array)
 
         if self.is_streaming and self.input_format == EnumFormat.BYTE.value:
             mv = memoryview(data).cast("B")
-            mvd = memoryview(delta_second_data).cast("B") if delta_second_data else None
+            mvd = delta_second_data
             batched = self._compress_stream_batched(mv, mvd)
             if batched is not None:
                 return batched
@@ -205,7 +206,7 @@ class ZipNN:
                     piece = _xor(piece, mvd[off:off + self.streaming_chunk])
                 out += self.compress_torch_numpy_byte(piece, lossy_compressed_type, lossy_compressed_factor)
             return out
-        if delta_second_data:
+        if delta_second_data is not None:
             if self.input_format == EnumFormat.BYTE.value:
                 # the XOR with the second buffer happens inside the kernels that read the data (fused, no host pass)
                 return self.compress_torch_numpy_byte(data, lossy_compressed_type, lossy_compressed_factor, delta=delta_second_data)
@@ -325,8 +326,11 @@ class ZipNN:
                 raise FileNotFoundError("Encountered an error when reading the delta file")
         elif delta_second_data is not None:
             raise ValueError("ZipNN isn't set for delta compression, but delta_second_data is not null.")
+        # the second buffer as bytes, whatever it came as (a tensor or an array has no truth value); an EMPTY one counts
+        # as "no second buffer", which is what the reference's `if delta_second_data:` makes of it (zipnn.py:968,1000)
+        delta_second_data = _delta_bytes(delta_second_data)
 
-        if isinstance(data, torch.Tensor) and not (data.is_cuda and not delta_second_data and self.input_format != EnumFormat.BYTE.value):
+        if isinstance(data, torch.Tensor) and not (data.is_cuda and delta_second_data is None and self.input_format != EnumFormat.BYTE.value):
             # a frame handed over as a tensor: only the device-resident fast path (a CUDA frame, no second buffer, TORCH /
             # NUMPY result) works on the tensor itself; every other case (delta, streaming blobs of BYTE frames) takes the
             # host-bytes route — the reference only ever sees bytes here (zipnn.py:928-1005)
@@ -349,7 +353,7 @@ class ZipNN:
                 return batched
             out = bytearray()
             off = od = 0
-            mvd = memoryview(delta_second_data).cast("B") if delta_second_data else None
+            mvd = delta_second_data
             while off < mv.nbytes:
                 total = int.from_bytes(mv[off + 24:off + 32], "little")
                 piece = self.decompress_bin(mv[off:off + total])
@@ -364,11 +368,11 @@ class ZipNN:
             if mvd is not None and od != mvd.nbytes:
                 raise ValueError("Length of delta file has to match the length of the decompressed file.")
             return out
-        if delta_second_data:
+        if delta_second_data is not None:
             if self.input_format == EnumFormat.BYTE.value and mv is not None:
                 return self.decompress_bin(mv, delta=delta_second_data)     # XOR fused into the kernels that write the output
             plain = self.decompress_bin(mv)
-            if len(plain) != len(delta_second_data):
+            if len(plain) != delta_second_data.nbytes:
                 raise ValueError("Length of delta file has to match the length of the decompressed file.")
             return _xor(plain, delta_second_data)
         return self.decompress_bin(data if mv is None else mv, target)
@@ -401,7 +405,7 @@ class ZipNN:
         dev = torch.device("cuda", codec.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         blob = codec.to_device(_capi.lib(), mv, dev)
         base = None
-        if delta_second_data:
+        if delta_second_data is not None:
             mvd = memoryview(delta_second_data).cast("B")
             if mvd.nbytes != n_out:
                 raise ValueError("Length of delta file has to match the length of the decompressed file.")
@@ -421,11 +425,7 @@ class ZipNN:
         dict(body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape)."""
         # header + shape extension: 1 byte ndim, then per dim a width byte and ≤ 8 bytes (header.pack_shape) — read what
         # this frame's ndim needs, not a fixed window (a 12-dimensional shape does not fit 80 bytes)
-        def _take(a, b):
-            return bytes(frame[a:b].cpu().numpy()) if isinstance(frame, torch.Tensor) else bytes(memoryview(frame)[a:b])
-        nd = _take(HEADER_LEN, HEADER_LEN + 1)
-        head = _take(0, HEADER_LEN + 1 + 9 * (nd[0] if nd else 0))
-        body_off = self._retrieve_header(head)
+        body_off = self._retrieve_header(_frame_head(frame))
         dt = dtype_from_code(self.dtype)
         chunk = self.compression_chunk if dt.planes != 1 else min(FP8_CHUNK_CAP, self.compression_chunk)
         return dict(body_off=body_off, num_buf=dt.planes, bits_mode=self._bit_reorder, bytes_mode=self._byte_reorder,
@@ -435,12 +435,7 @@ class ZipNN:
         """One frame -> bytes / tensor / array (reference zipnn.py:1072-1198).  delta (BYTE format): second buffer
         of the original length, XORed into the output on the device."""
         on_device = isinstance(frame, torch.Tensor) and frame.is_cuda
-        if isinstance(frame, torch.Tensor):       # (the header and a shape extension sized from its ndim byte: 1 + 9 per dim)
-            nd = int(frame[HEADER_LEN]) if frame.numel() > HEADER_LEN else 0
-            head = bytes(frame[:HEADER_LEN + 1 + 9 * nd].cpu().numpy())
-        else:
-            head = frame
-        body_off = self._retrieve_header(head)
+        body_off = self._retrieve_header(_frame_head(frame))
         dt = dtype_from_code(self.dtype)
         if self.input_format == EnumFormat.NUMPY.value and dt.numpy is None:
             raise ValueError(f"Unsupported Dtype {self.dtype}")
@@ -496,6 +491,37 @@ class ZipNN:
         with open(self.decompressed_file, "wb") as f:
             f.write(ba_decom)
         return 0
+
+
+_HEAD_WINDOW = HEADER_LEN + 1 + 9 * 8       # header + the shape extension of a tensor of up to 8 dimensions
+
+
+def _frame_head(frame):
+    """Header (+ shape extension) of one frame as host bytes.  A frame that lives in a tensor (possibly in HBM) is read
+    with ONE small copy: a fixed window that holds the shape extension of up to 8 dimensions; the extension exists only in
+    TORCH / NUMPY frames (header byte 8), and only a frame with more dimensions than that costs a second read."""
+    if not isinstance(frame, torch.Tensor):
+        mv = memoryview(frame)
+        return mv[:HEADER_LEN + 1 + 9 * 255]
+    flat = frame.reshape(-1)
+    head = bytes(flat[:_HEAD_WINDOW].cpu().numpy())
+    if len(head) > HEADER_LEN and head[8] in (EnumFormat.TORCH.value, EnumFormat.NUMPY.value):
+        need = HEADER_LEN + 1 + 9 * head[HEADER_LEN]
+        if need > len(head) and flat.numel() > len(head):
+            head = bytes(flat[:need].cpu().numpy())
+    return head
+
+
+def _delta_bytes(delta):
+    """The delta base as a flat byte view, or None for "no second buffer" (None or empty)."""
+    if delta is None:
+        return None
+    if isinstance(delta, torch.Tensor):
+        delta = delta.detach().cpu().contiguous().view(torch.uint8).reshape(-1).numpy()
+    mv = memoryview(delta)
+    if mv.nbytes == 0:
+        return None
+    return mv.cast("B") if mv.contiguous else memoryview(mv.tobytes())
 
 
 def _xor(a, b):
