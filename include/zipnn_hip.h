@@ -151,12 +151,40 @@ int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n
 int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
                         size_t orig_size, const int* devices, int ndev, void* dst);
 
+/* The same with the TENSOR resident in HBM, range by range — what a sharded loader / saver holds: device i owns the bytes of the
+ * chunk range zn_multi_range(n, chunk, ndev, i) gives, at d_dst[i] / d_src[i] (device memory of devices[i]; NULL for an empty
+ * range).  The frame (or its body) stays a host buffer — it comes from / goes to a file.  Decompress: each range's size tables are
+ * re-based on the host (9 num_buf bytes per chunk), its payload slices go from `body` straight through that device's pinned pipe
+ * into HBM, the decoded bytes never cross PCIe.  Compress: each device codes its range where it lies; only the compressed bodies
+ * come back.  One host thread, stream and workspace per listed device; no collective.  Bytes identical to the single-device call. */
+int zn_multi_range(size_t n, size_t chunk, int ndev, int i, size_t* off, size_t* len);
+int zn_decompress_multi_dev(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                            size_t orig_size, const int* devices, int ndev, void* const* d_dst);
+int zn_compress_multi_dev(const void* hdr, size_t hdr_len, const void* const* d_src, size_t n, int num_buf, int bits_mode,
+                          int bytes_mode, size_t chunk, float threshold, const int* devices, int ndev, void* dst, size_t dst_cap,
+                          size_t* dst_len);
+
+/* The two halves of the same for ONE process per GPU (torch.distributed ranks, each with its own device): a rank decodes the chunk
+ * range [chunk_lo, chunk_hi) of a host-resident frame body straight into its own HBM (the sub-body is put together on the device:
+ * re-based size tables from the host, payload slices through the pinned pipe; nothing decoded crosses PCIe) … */
+int zn_decompress_range_dev(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                            size_t orig_size, size_t chunk_lo, size_t chunk_hi, int device, void* d_dst);
+/* … and the bodies the ranks wrote for CONSECUTIVE chunk ranges (rank i: zn_compress_dev of its num_chunks[i] chunks) become the one
+ * body a single device would have written: types and payload concatenated per plane, cumSizes re-based (host pointers; one thread
+ * per part does the copying).  dst_cap >= the sum of the body lengths. */
+int zn_merge_range_bodies(const void* const* bodies, const size_t* body_lens, const size_t* num_chunks, int nparts, int num_buf,
+                          void* dst, size_t dst_cap, size_t* dst_len);
+
 /* Plumbing for callers that keep the tensors in HBM but hold pageable host buffers (files, Python bytes): the same
  * pinned, multi-threaded transfer the host-buffer entry points above use internally (zipnn_amd/csrc/zn_host_pipe.hpp),
  * on the current device; returns when the n bytes have arrived.  No reference counterpart — the reference's buffers
  * never leave the host (zipnn/zipnn.py:714-725, 1143-1151 hand host pointers straight to the C core). */
 int zn_copy_to_device(void* d_dst, const void* src, size_t n);
 int zn_copy_to_host(void* dst, const void* d_src, size_t n);
+
+/* Tuning knob: chunks one workgroup of the fused decoder takes, 1..4; 0 (default) = automatic (4 when the tensor has enough chunks
+ * to fill every workgroup slot of the device with groups, fewer for small tensors).  Process-wide.  Returns 0 or ZN_E_ARG. */
+int zn_set_decode_group(int chunks_per_workgroup);
 
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Developer tool (GPU box): decode time by chunks-per-workgroup (ZN_DECODE_GROUP) and tensor size."""
+"""Developer tool (GPU box): decode time by chunks-per-workgroup (zn_set_decode_group) and tensor size."""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,8 +18,7 @@ for mib in (64, 128, 256, 512, 1024, 2048, 4096):
     out = torch.empty(n, dtype=torch.uint8, device="cuda")
     row = []
     for grp in ("", "1", "2", "3", "4"):
-        if grp: os.environ["ZN_DECODE_GROUP"] = grp
-        else: os.environ.pop("ZN_DECODE_GROUP", None)
+        lib.set_decode_group(int(grp) if grp else 0)
         for _ in range(12): codec.decompress_device(lib, body, 2, 1, 10, C, n, out=out, check=False)
         best = 1e9
         for _ in range(3):

@@ -31,7 +31,7 @@ def main():
     so = os.path.join(ROOT, "zipnn_amd", "libzipnn_hip_prof.so")
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     if extra or "--build-only" in sys.argv or not os.path.exists(so):
-        subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZN_PHASE_TIMERS",
+        subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DZN_PHASE_TIMERS", "-DZN_DEV_BUILD",
                         "-o", so] + extra + sources(), check=True)
     if "--build-only" in sys.argv:
         return

@@ -52,3 +52,16 @@ def use_simt(simt_lib, monkeypatch):
     import zipnn_amd._capi as capi
     monkeypatch.setattr(capi, "_LIB", simt_lib)
     return simt_lib
+
+
+@pytest.fixture()
+def decode_group():
+    """Force the fused decoder's chunks-per-workgroup (zn_set_decode_group) for one test; back to automatic afterwards."""
+    used = []
+
+    def set_(lib, group):
+        lib.set_decode_group(group)
+        used.append(lib)
+    yield set_
+    for lib in used:
+        lib.set_decode_group(0)

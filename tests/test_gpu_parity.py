@@ -89,10 +89,10 @@ def test_two_streams_share_the_device_workspace_safely(lib):
 
 
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
-def test_fused_decode_chunk_groups(lib, group, monkeypatch):
+def test_fused_decode_chunk_groups(lib, group, decode_group):
     """Workgroups decode `group` consecutive chunks; mixed Huffman / raw / RLE / two-Huffman-plane chunks, short last group."""
     from test_kernels_simt import _gen2
-    monkeypatch.setenv("ZN_DECODE_GROUP", str(group))
+    decode_group(lib, group)
     ch = 65536
     r = np.random.default_rng(5)
     parts = []

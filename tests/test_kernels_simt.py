@@ -129,10 +129,10 @@ def test_fused_decode_path(simt_lib, case):
 
 
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
-def test_fused_decode_chunk_groups(simt_lib, group, monkeypatch):
+def test_fused_decode_chunk_groups(simt_lib, group, decode_group):
     """A workgroup decodes `group` consecutive chunks; groups may mix Huffman, raw-only, RLE and
     two-Huffman-plane (one extra accumulate pass) chunks, and the last group may be short."""
-    monkeypatch.setenv("ZN_DECODE_GROUP", str(group))
+    decode_group(simt_lib, group)
     ch = 16384
     r = np.random.default_rng(5)
     parts = []
@@ -551,3 +551,25 @@ def test_multi_device_decompress_rejects_malformed_size_tables(simt_lib):
         simt_lib.decompress_multi(bytes(bad), 2, 1, 10, C, len(d), [0, 1])
     with pytest.raises(RuntimeError):                                                                     # too short for its own tables
         simt_lib.decompress_multi(bytes(ref[:30]), 2, 1, 10, C, len(d), [0, 1])
+
+
+@pytest.mark.parametrize("kind,P,rot,bm,chunk,n", [("bf16", 2, 1, 10, C, 7 * C + 1234), ("fp32", 4, 1, 220, C, 5 * C + 4 * 77), ("bf16", 2, 1, 10, C, C // 2 + 3)],
+                         ids=["bf16-7.x-chunks", "fp32-5.x-chunks", "bf16-one-partial-chunk"])
+@pytest.mark.parametrize("devices", [[0, 1], [1, 0, 1], [0, 0], [0, 1, 0, 1, 0]], ids=["2-devices", "3-ranges", "same-device-twice", "more-ranges-than-chunks-sometimes"])
+def test_multi_device_entries_with_the_tensor_resident_per_device(simt_lib, kind, P, rot, bm, chunk, n, devices):
+    """zn_decompress_multi_dev / zn_compress_multi_dev: device i holds the bytes of its chunk range (zn_multi_range) in its own
+    memory — what a sharded loader / saver has.  Host body in, ranges decoded in place on the devices (nothing decoded crosses
+    the host); per-device ranges in, the oracle's frame out.  (Emulated devices: their 'HBM' is host memory.)"""
+    d = gen_bytes(kind, n, 41)
+    ref = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    G = len(devices)
+    rng = [simt_lib.multi_range(n, chunk, G, i) for i in range(G)]
+    assert sum(l for _, l in rng) == n and all(rng[i][0] + rng[i][1] == rng[i + 1][0] for i in range(G - 1) if rng[i + 1][1])
+    outs = [torch.zeros(max(l, 1), dtype=torch.uint8) for _, l in rng]
+    simt_lib.decompress_multi_dev(ref[32:], P, rot, bm, chunk, n, devices, [o.data_ptr() if l else 0 for o, (_, l) in zip(outs, rng)])
+    assert b"".join(o.numpy().tobytes()[:l] for o, (_, l) in zip(outs, rng)) == d
+    parts = [torch.frombuffer(bytearray(d[o:o + l]) or bytearray(1), dtype=torch.uint8) for o, l in rng]
+    got = simt_lib.compress_multi_dev(HDR, [p.data_ptr() if l else 0 for p, (_, l) in zip(parts, rng)], n, P, rot, bm, chunk, 0.95, devices)
+    assert bytes(got) == ref
+    with pytest.raises(ValueError):                          # a non-empty range without a destination
+        simt_lib.decompress_multi_dev(ref[32:], P, rot, bm, chunk, n, devices, [0] * G)

@@ -55,11 +55,12 @@ def test_two_ranks_merge_to_single_rank_frame(case, simt_lib):
     merged = sharding.merge_bodies([(b, k) for _, b, k, _ in got], P)
     data = gen_bytes(kind, nb, 9)
     assert merged == O.compress_frame(b"", data, P, rot, bm, C)          # byte-identical to the 1-rank frame
+    assert sharding.merge_bodies([(b, k) for _, b, k, _ in got], P, lib=simt_lib) == merged      # the library's placement (zn_merge_range_bodies)
     assert O.decompress_body(merged, P, rot, bm, C, nb) == data
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
-def test_split_bodies_decode_independently(world):
+def test_split_bodies_decode_independently(world, simt_lib):
     kind, nb, P, rot, bm = CASES[0]
     data = gen_bytes(kind, nb, 9)
     body = O.compress_frame(b"", data, P, rot, bm, C)
@@ -69,6 +70,14 @@ def test_split_bodies_decode_independently(world):
     K = (nb + C - 1) // C
     again = sharding.merge_bodies([(sub, hi - lo) for (sub, _, _), (lo, hi) in zip(parts, sharding.chunk_ranges(K, world))], P)
     assert again == body
+    assert sharding.merge_bodies([(sub, hi - lo) for (sub, _, _), (lo, hi) in zip(parts, sharding.chunk_ranges(K, world))], P, lib=simt_lib) == body
+    # one range alone, decoded by the library straight from the whole body (zn_decompress_range_dev; emulated device memory = host)
+    for lo, hi in sharding.chunk_ranges(K, world):
+        if hi > lo:
+            n_r = min(hi * C, nb) - lo * C
+            out = torch.zeros(n_r, dtype=torch.uint8)
+            simt_lib.decompress_range_dev(body, P, rot, bm, C, nb, lo, hi, 0, out.data_ptr())
+            assert out.numpy().tobytes() == data[lo * C: lo * C + n_r]
 
 
 def _replicated_worker(rank, world, port, case, q):

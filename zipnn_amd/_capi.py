@@ -66,6 +66,19 @@ class ZnLib:
         L.zn_compress_multi.argtypes = [vp, sz, vp, sz, ci, ci, ci, sz, cf, ctypes.POINTER(ci), ci, vp, sz, ctypes.POINTER(sz)]
         L.zn_decompress_multi.restype = ci
         L.zn_decompress_multi.argtypes = [vp, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ci, vp]
+        vpp = ctypes.POINTER(ctypes.c_void_p)
+        L.zn_multi_range.restype = ci
+        L.zn_multi_range.argtypes = [sz, sz, ci, ci, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.zn_decompress_multi_dev.restype = ci
+        L.zn_decompress_multi_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, ctypes.POINTER(ci), ci, vpp]
+        L.zn_compress_multi_dev.restype = ci
+        L.zn_compress_multi_dev.argtypes = [vp, sz, vpp, sz, ci, ci, ci, sz, cf, ctypes.POINTER(ci), ci, vp, sz, ctypes.POINTER(sz)]
+        L.zn_decompress_range_dev.restype = ci
+        L.zn_decompress_range_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, sz, sz, ci, vp]
+        L.zn_merge_range_bodies.restype = ci
+        L.zn_merge_range_bodies.argtypes = [vpp, ctypes.POINTER(sz), ctypes.POINTER(sz), ci, ci, vp, sz, ctypes.POINTER(sz)]
+        L.zn_set_decode_group.restype = ci
+        L.zn_set_decode_group.argtypes = [ci]
         L.zn_compress_dev.restype = ci
         L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
         L.zn_decompress_dev.restype = ci
@@ -88,7 +101,7 @@ class ZnLib:
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
         L.zn_last_tail_planes.restype = ctypes.c_longlong
         self._L = L
-        if L.zn_abi_version() != 2:
+        if L.zn_abi_version() != 3:
             raise ImportError(f"{path}: unexpected ABI version {L.zn_abi_version()}")
 
     # -- error mapping: the Python-visible exceptions of the reference ------------------
@@ -186,6 +199,60 @@ class ZnLib:
                                          out.ctypes.data)
         self._check(rc)
         return memoryview(out)[:orig_size]
+
+    def multi_range(self, n, chunk, ndev, i):
+        """(byte offset, byte length) of the chunk range device i of ndev codes (zn_multi_range)."""
+        off, ln = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self._check(self._L.zn_multi_range(n, chunk, ndev, i, ctypes.byref(off), ctypes.byref(ln)))
+        return off.value, ln.value
+
+    def decompress_multi_dev(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices, dst_ptrs):
+        """zn_decompress_multi_dev: host body -> range i decoded into device memory dst_ptrs[i] of devices[i]
+        (the decoded bytes never cross PCIe)."""
+        bv = memoryview(body).cast("B")
+        src = _as_c_buffer(bv)
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        ptrs = (ctypes.c_void_p * len(devices))(*[ctypes.c_void_p(p or None) for p in dst_ptrs])
+        self._check(self._L.zn_decompress_multi_dev(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, devs,
+                                                    len(devices), ptrs))
+
+    def compress_multi_dev(self, header, src_ptrs, n, num_buf, bits_mode, bytes_mode, chunk, threshold, devices):
+        """zn_compress_multi_dev: range i of the tensor lies at device pointer src_ptrs[i] on devices[i]; -> frame (host)."""
+        hv = memoryview(header).cast("B")
+        cap = self._L.zn_compress_bound(n, num_buf, chunk, hv.nbytes)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        out_len = ctypes.c_size_t(0)
+        hb = (ctypes.c_char * max(hv.nbytes, 1)).from_buffer_copy(hv.tobytes() or b"\0")
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        ptrs = (ctypes.c_void_p * len(devices))(*[ctypes.c_void_p(p or None) for p in src_ptrs])
+        self._check(self._L.zn_compress_multi_dev(ctypes.addressof(hb), hv.nbytes, ptrs, n, num_buf, bits_mode, bytes_mode, chunk,
+                                                  threshold, devs, len(devices), out.ctypes.data, cap, ctypes.byref(out_len)))
+        return memoryview(out)[:out_len.value]
+
+    def decompress_range_dev(self, body, num_buf, bits_mode, bytes_mode, chunk, orig_size, chunk_lo, chunk_hi, device, dst_ptr):
+        """zn_decompress_range_dev: chunks [chunk_lo, chunk_hi) of a host-resident body decoded into device memory at dst_ptr."""
+        bv = memoryview(body).cast("B")
+        src = _as_c_buffer(bv)
+        self._check(self._L.zn_decompress_range_dev(src.addr, bv.nbytes, num_buf, bits_mode, bytes_mode, chunk, orig_size, chunk_lo,
+                                                    chunk_hi, int(device), dst_ptr or None))
+
+    def merge_range_bodies(self, parts, num_buf):
+        """zn_merge_range_bodies: [(body bytes-like, num_chunks)] of consecutive chunk ranges -> one body (memoryview, numpy-backed)."""
+        parts = [(memoryview(b).cast("B"), int(k)) for b, k in parts]
+        bufs = [_as_c_buffer(b) for b, _ in parts]
+        n = len(parts)
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[ctypes.c_void_p(c.addr) for c in bufs])
+        lens = (ctypes.c_size_t * max(n, 1))(*[b.nbytes for b, _ in parts])
+        ks = (ctypes.c_size_t * max(n, 1))(*[k for _, k in parts])
+        cap = sum(b.nbytes for b, _ in parts)
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        out_len = ctypes.c_size_t(0)
+        self._check(self._L.zn_merge_range_bodies(ptrs, lens, ks, n, num_buf, out.ctypes.data, cap, ctypes.byref(out_len)))
+        return memoryview(out)[:out_len.value]
+
+    def set_decode_group(self, chunks_per_workgroup):
+        """Tuning knob (zn_set_decode_group): chunks per workgroup of the fused decoder, 1..4; 0 = automatic."""
+        self._check(self._L.zn_set_decode_group(int(chunks_per_workgroup)))
 
     # -- device pointers (ints), used by zipnn_amd.codec with torch tensors -----------------
     def compress_dev(self, src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap, stream=0,

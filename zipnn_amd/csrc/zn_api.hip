@@ -39,8 +39,6 @@ struct Workspace {
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
-  hipStream_t aux = nullptr;     // second stream of the encoder: code tables of slab k while the stats kernel reads slab k + 1
-  hipEvent_t slab_ev[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
@@ -106,7 +104,7 @@ void zn_note_kernel(const char* name) { if (!t_kernels.empty()) t_kernels += ";"
 
 extern "C" {
 
-int zn_abi_version(void) { return 2; }
+int zn_abi_version(void) { return 3; }
 
 const char* zn_strerror(int s) {
   switch (s) {
@@ -209,11 +207,6 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
     }
   }
   if ((rc = ws_acquire(w, stream))) return rc;
-  if (!table && !w.aux && zn_encode_slabs() > 1) {   // (failing to get them only means no overlap)
-    bool ok = hipStreamCreateWithFlags(&w.aux, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; ok && i < 10; i++) ok = hipEventCreateWithFlags(&w.slab_ev[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { (void)hipGetLastError(); if (w.aux) (void)hipStreamDestroy(w.aux); w.aux = nullptr; for (int i = 0; i < 10; i++) if (w.slab_ev[i]) { (void)hipEventDestroy(w.slab_ev[i]); w.slab_ev[i] = nullptr; } }
-  }
   uint64_t* d_totals = (uint64_t*)w.buf[WS_TOTALS];
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
@@ -234,8 +227,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
       const uint32_t nseg = (uint32_t)segs[q].size();
       const ZnESeg& one = segs[q][0];
       if (stage == 0) {
-        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream,
-                                     table ? nullptr : w.aux, w.slab_ev, 10);
+        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream);
         zn_launch_encode_generic_stats(P, one, d_segs, nseg, (uint32_t)tails_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES],
                                        (uint8_t*)w.buf[WS_ENC], slot, d_csize, d_type, stream);
       } else if (stage == 1) {
@@ -483,10 +475,14 @@ int zn_decompress(const void* body, size_t body_len, int num_buf, int bits_mode,
 // host thread of its own (per-device locks, workspaces and streams: zn_api.hip above), and the host does the plane-major
 // bookkeeping: types and payload of the ranges concatenated per plane, cumSizes re-based by what the earlier ranges put into
 // the plane.  The frame is byte-identical to the one a single device writes (zipnn_amd/sharding.py states the same
-// arithmetic in numpy for the one-process-per-GPU path).
+// arithmetic in numpy for the one-process-per-GPU path).  The reference's counterpart is its pthread fan-out over chunks
+// (csrc/zipnn_core.c:294-301, 509-523).
+extern "C++" {
 namespace {
-// host staging of the multi-device calls: one grow-only buffer per range slot, kept between calls (a fresh 0.5 GiB vector per
-// range cost more in zero-fill and first-touch page faults than the coding itself); one multi-device call at a time per process
+// host staging of the multi-device COMPRESS calls (a range's body before it is placed in the frame): one grow-only buffer per
+// range slot, kept between calls (a fresh 0.5 GiB vector per range cost more in zero-fill and first-touch page faults than the
+// coding itself); g_multi_mu guards it.  Decompress stages nothing on the host: the ranges' payload slices go from the caller's
+// body straight into HBM.
 std::mutex g_multi_mu;
 struct ZnStage { uint8_t* p = nullptr; size_t cap = 0; };
 ZnStage g_multi_stage[64];
@@ -498,7 +494,205 @@ uint8_t* zn_stage(int slot, size_t need) {
 struct ZnRange { size_t lo, hi; };                 // chunk range of one device
 ZnRange zn_range_of(size_t K, int g, int G) { return ZnRange{(size_t)g * K / (size_t)G, (size_t)(g + 1) * K / (size_t)G}; }
 uint64_t zn_rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+// the worker threads of one call: joined on EVERY way out of the scope (a std::thread destroyed while joinable terminates the
+// process), and a thread that cannot be started — EAGAIN under a thread limit — fails the call instead of throwing through it
+struct ZnWorkers {
+  std::vector<std::thread> th;
+  bool failed = false;
+  template <class F> void start(F&& f) { if (failed) return; try { th.emplace_back(std::forward<F>(f)); } catch (...) { failed = true; } }
+  void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+  ~ZnWorkers() { join(); }
+};
+
+// The size tables of a frame body, checked once: plane bases, and cumSizes monotone and inside the payload (every per-range
+// sub-body below is cut out of them).
+struct ZnBodyView { const uint8_t* types; const uint8_t* cums; const uint8_t* pay; size_t P, K, pay_len; std::vector<uint64_t> base; };
+int zn_body_view(const void* body, size_t body_len, int num_buf, size_t chunk, size_t orig_size, ZnBodyView* v) {
+  const size_t P = (size_t)num_buf, K = (orig_size + chunk - 1) / chunk;
+  if (K > body_len / (9 * P)) return ZN_E_CORRUPT;
+  const uint8_t* b = (const uint8_t*)body;
+  v->P = P; v->K = K; v->types = b; v->cums = b + P * K; v->pay = v->cums + 8 * P * K; v->pay_len = body_len - 9 * P * K;
+  v->base.assign(P, 0);
+  uint64_t acc = 0;
+  for (size_t p = 0; p < P; p++) {
+    v->base[p] = acc;
+    uint64_t prev = 0;
+    for (size_t i = 0; i < K; i++) { const uint64_t c = zn_rd64(v->cums + 8 * (p * K + i)); if (c < prev || c > v->pay_len - acc) return ZN_E_CORRUPT; prev = c; }
+    acc += prev;
+  }
+  return ZN_OK;
+}
+uint64_t zn_cum_before(const ZnBodyView& v, size_t p, size_t c) { return c ? zn_rd64(v.cums + 8 * (p * v.K + c - 1)) : 0; }
+size_t zn_sub_need(const ZnBodyView& v, const ZnRange& r) {
+  size_t need = 9 * v.P * (r.hi - r.lo);
+  for (size_t p = 0; p < v.P; p++) need += (size_t)(zn_cum_before(v, p, r.hi) - zn_cum_before(v, p, r.lo));
+  return need;
+}
+
+// Decode the chunk range `r` of a host-resident frame body on `device`.  The range's sub-body is put together IN HBM: its
+// size tables (9 P k bytes, re-based) are built on the host, its P payload slices go from the caller's body through the
+// device's pinned pipe to their place behind them — no host copy of the payload.  The decoded bytes land in `d_dst` (device
+// memory of `device`, when given) or are copied to `h_dst` (host).
+int zn_decode_range(const ZnBodyView& v, const ZnRange& r, int num_buf, int bits_mode, int bytes_mode, size_t chunk, size_t orig_size,
+                    int device, void* h_dst, void* d_dst) {
+  const size_t P = v.P, K = v.K, k = r.hi - r.lo;
+  if (!k) return ZN_OK;
+  const size_t off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
+  DeviceScope scope(device);              // (restored on every return path)
+  if (!scope.ok) { t_hip_err = "hipSetDevice"; return ZN_E_HIP; }
+  int dev = 0;
+  ZN_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  std::lock_guard<std::mutex> hk(g_host_mu[dev]);
+  const size_t need = zn_sub_need(v, r);
+  uint8_t* d_in = nullptr; void* d_out = d_dst;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+    Workspace& w = g_ws[dev];
+    int rc0;
+    if ((rc0 = ws_reserve(w, WS_HOST_IN, need + 16))) return rc0;
+    d_in = (uint8_t*)w.buf[WS_HOST_IN];
+    if (!d_out) { if ((rc0 = ws_reserve(w, WS_HOST_OUT, len ? len : 16))) return rc0; d_out = w.buf[WS_HOST_OUT]; }
+  }
+  std::vector<uint8_t> meta(9 * P * k);
+  std::vector<uint64_t> s0(P);
+  for (size_t p = 0; p < P; p++) {
+    s0[p] = zn_cum_before(v, p, r.lo);
+    memcpy(meta.data() + p * k, v.types + p * K + r.lo, k);
+    for (size_t i = 0; i < k; i++) { const uint64_t c = zn_rd64(v.cums + 8 * (p * K + r.lo + i)) - s0[p]; memcpy(meta.data() + P * k + 8 * (p * k + i), &c, 8); }
+  }
+  ZnHostPipe& pipe = g_ws[dev].pipe;
+  if (zn_host_pipe_copy(pipe, d_in, meta.data(), meta.size(), true) != hipSuccess) { t_hip_err = "host pipe H2D"; (void)hipGetLastError(); return ZN_E_HIP; }
+  size_t at = meta.size();
+  for (size_t p = 0; p < P; p++) {
+    const size_t m = (size_t)(zn_cum_before(v, p, r.hi) - s0[p]);
+    if (m && zn_host_pipe_copy(pipe, d_in + at, const_cast<uint8_t*>(v.pay + v.base[p] + s0[p]), m, true) != hipSuccess) { t_hip_err = "host pipe H2D"; (void)hipGetLastError(); return ZN_E_HIP; }
+    at += m;
+  }
+  int rc = zn_decompress_dev(d_in, need, num_buf, bits_mode, bytes_mode, chunk, len, d_out, nullptr, 1);
+  if (rc) return rc;
+  if (h_dst && len && zn_host_pipe_copy(pipe, d_out, (uint8_t*)h_dst + off, len, false) != hipSuccess) { t_hip_err = "host pipe D2H"; (void)hipGetLastError(); return ZN_E_HIP; }
+  return ZN_OK;
+}
+
+// Bodies of CONSECUTIVE chunk ranges (part i: ks[i] chunks, plen[i] bytes = types ‖ cumSizes ‖ payload of that range alone) ->
+// hdr ‖ one body: types and payload concatenated per plane, cumSizes re-based by what the earlier ranges put into the plane;
+// one thread per range does the copying.
+int zn_assemble_ranges(const void* hdr, size_t hdr_len, const std::vector<const uint8_t*>& part, const std::vector<size_t>& plen,
+                       const std::vector<size_t>& ks, size_t P, void* dst, size_t dst_cap, size_t* dst_len) {
+  const size_t G = part.size();
+  size_t K = 0, pay_total = 0;
+  for (size_t g = 0; g < G; g++) {
+    const size_t k = ks[g];
+    if (!k) continue;
+    if (!part[g] || plen[g] < 9 * P * k) return ZN_E_ARG;
+    K += k; pay_total += plen[g] - 9 * P * k;
+  }
+  const size_t total = hdr_len + 9 * P * K + pay_total;
+  if (total > dst_cap) return ZN_E_CAP;
+  uint8_t* o = (uint8_t*)dst;
+  if (hdr_len) memcpy(o, hdr, hdr_len);
+  uint8_t* types = o + hdr_len; uint8_t* cums = types + P * K; uint8_t* pay = cums + 8 * P * K;
+  // where every (plane, range) piece goes and what re-bases its cumSizes
+  std::vector<size_t> dst_at(G * P, 0), c0(G, 0); std::vector<uint64_t> rebase(G * P, 0);
+  { size_t c = 0; for (size_t g = 0; g < G; g++) { c0[g] = c; c += ks[g]; } }
+  size_t pay_at = 0;
+  for (size_t p = 0; p < P; p++) {
+    uint64_t run = 0;                              // bytes the earlier ranges put into plane p
+    for (size_t g = 0; g < G; g++) {
+      const size_t k = ks[g];
+      if (!k) continue;
+      const size_t tot = (size_t)zn_rd64(part[g] + P * k + 8 * (p * k + k - 1));
+      dst_at[g * P + p] = pay_at; rebase[g * P + p] = run;
+      pay_at += tot; run += tot;
+    }
+  }
+  if (pay_at != pay_total) return ZN_E_CORRUPT;   // a part whose cumSizes disagree with its length
+  {
+    ZnWorkers cp;
+    for (size_t g = 0; g < G; g++) {
+      const size_t k = ks[g];
+      if (!k) continue;
+      cp.start([&, g, k]() {
+        const uint8_t* b = part[g];
+        size_t base = 0;                             // where plane p starts in this range's payload
+        for (size_t p = 0; p < P; p++) {
+          memcpy(types + p * K + c0[g], b + p * k, k);
+          const uint8_t* c = b + P * k + 8 * p * k;
+          const uint64_t run = rebase[g * P + p];
+          for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(c + 8 * i) + run; memcpy(cums + 8 * (p * K + c0[g] + i), &v, 8); }
+          const size_t tot = (size_t)zn_rd64(c + 8 * (k - 1));
+          memcpy(pay + dst_at[g * P + p], b + 9 * P * k + base, tot);
+          base += tot;
+        }
+      });
+    }
+    cp.join();
+    if (cp.failed) return ZN_E_ALLOC;
+  }
+  *dst_len = total;
+  if (hdr_len >= 32) { const uint64_t t64 = total; memcpy(o + 24, &t64, 8); }   // zipnn_core.c:121
+  return ZN_OK;
+}
+
+// Compress with the chunk ranges on several devices; `part_src(g)` says where range g's bytes are: a host pointer (h != null:
+// staged through HBM by zn_compress) or a device pointer on devices[g].  The ranges' bodies come back to host staging and are
+// placed in the frame by one thread per range.
+struct ZnPartSrc { const void* h; const void* d; };
+template <class SRC>
+int zn_compress_ranges(const void* hdr, size_t hdr_len, size_t n, int num_buf, int bits_mode, int bytes_mode, size_t chunk, float threshold,
+                       const int* devices, int ndev, void* dst, size_t dst_cap, size_t* dst_len, SRC&& part_src) {
+  const size_t P = (size_t)num_buf, K = (n + chunk - 1) / chunk;
+  std::lock_guard<std::mutex> mk(g_multi_mu);
+  std::vector<uint8_t*> part((size_t)ndev, nullptr);
+  std::vector<size_t> plen((size_t)ndev, 0);
+  for (int g = 0; g < ndev; g++) {                 // (staging reserved here: the worker threads only fill it)
+    const ZnRange r = zn_range_of(K, g, ndev);
+    if (r.hi <= r.lo) continue;
+    const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
+    if (!(part[(size_t)g] = zn_stage(g, zn_compress_bound(len, num_buf, chunk, 0) + 16))) return ZN_E_ALLOC;
+  }
+  std::vector<int> rcs((size_t)ndev, ZN_OK);
+  {
+    ZnWorkers wk;
+    for (int g = 0; g < ndev; g++) {
+      const ZnRange r = zn_range_of(K, g, ndev);
+      if (r.hi <= r.lo) continue;
+      wk.start([&, g, r]() {
+        try {
+          const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
+          const size_t cap = zn_compress_bound(len, num_buf, chunk, 0) + 16;
+          const ZnPartSrc ps = part_src(g, off);
+          if (ps.h || !len) {
+            rcs[(size_t)g] = zn_compress(nullptr, 0, ps.h, len, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[g], part[(size_t)g], cap, &plen[(size_t)g]);
+            return;
+          }
+          // the range is in HBM already: code it there, bring only the body back
+          DeviceScope scope(devices[g]);
+          if (!scope.ok) { rcs[(size_t)g] = ZN_E_HIP; return; }
+          int dev = 0;
+          if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); rcs[(size_t)g] = ZN_E_HIP; return; }
+          std::lock_guard<std::mutex> hk(g_host_mu[dev]);
+          void* d_body = nullptr;
+          { std::lock_guard<std::mutex> lk(g_dev_mu[dev]); const int rc0 = ws_reserve(g_ws[dev], WS_HOST_OUT, cap); if (rc0) { rcs[(size_t)g] = rc0; return; } d_body = g_ws[dev].buf[WS_HOST_OUT]; }
+          size_t blen = 0;
+          int rc = zn_compress_dev(ps.d, len, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, cap, &blen, nullptr);
+          if (!rc && blen && zn_host_pipe_copy(g_ws[dev].pipe, d_body, part[(size_t)g], blen, false) != hipSuccess) { (void)hipGetLastError(); rc = ZN_E_HIP; }
+          plen[(size_t)g] = blen; rcs[(size_t)g] = rc;
+        } catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
+      });
+    }
+    wk.join();
+    if (wk.failed) return ZN_E_ALLOC;
+  }
+  for (int g = 0; g < ndev; g++) if (rcs[(size_t)g]) return rcs[(size_t)g];
+  std::vector<const uint8_t*> cpart((size_t)ndev, nullptr); std::vector<size_t> ks((size_t)ndev, 0);
+  for (int g = 0; g < ndev; g++) { const ZnRange r = zn_range_of(K, g, ndev); cpart[(size_t)g] = part[(size_t)g]; ks[(size_t)g] = r.hi - r.lo; }
+  return zn_assemble_ranges(hdr, hdr_len, cpart, plen, ks, P, dst, dst_cap, dst_len);
+}
 }  // namespace
+}  // extern "C++"
 
 int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
                       size_t chunk, float threshold, const int* devices, int ndev, void* dst, size_t dst_cap, size_t* dst_len) {
@@ -506,75 +700,81 @@ int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n
   if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
   if (ndev == 1) return zn_compress(hdr, hdr_len, src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[0], dst, dst_cap, dst_len);
   try {
-    const size_t P = (size_t)num_buf, K = (n + chunk - 1) / chunk;
-    std::lock_guard<std::mutex> mk(g_multi_mu);
-    std::vector<uint8_t*> part((size_t)ndev, nullptr);
-    std::vector<size_t> plen((size_t)ndev, 0);
-    for (int g = 0; g < ndev; g++) {                 // (staging reserved here: the worker threads only fill it)
-      const ZnRange r = zn_range_of(K, g, ndev);
-      if (r.hi <= r.lo) continue;
-      const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
-      if (!(part[(size_t)g] = zn_stage(g, zn_compress_bound(len, num_buf, chunk, 0) + 16))) return ZN_E_ALLOC;
-    }
-    std::vector<int> rcs((size_t)ndev, ZN_OK);
-    std::vector<std::thread> th;
-    for (int g = 0; g < ndev; g++) {
-      const ZnRange r = zn_range_of(K, g, ndev);
-      if (r.hi <= r.lo) continue;
-      th.emplace_back([&, g, r]() {
-        try {
-          const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
-          rcs[(size_t)g] = zn_compress(nullptr, 0, (const uint8_t*)src + off, len, num_buf, bits_mode, bytes_mode, chunk, threshold, devices[g],
-                                       part[(size_t)g], zn_compress_bound(len, num_buf, chunk, 0) + 16, &plen[(size_t)g]);
-        } catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
-      });
-    }
-    for (auto& t : th) t.join();
-    for (int g = 0; g < ndev; g++) if (rcs[(size_t)g]) return rcs[(size_t)g];
-    // assemble: types[P][K] ‖ cumSizes[P][K] ‖ payload plane-major
-    size_t pay_total = 0;
-    for (int g = 0; g < ndev; g++) { const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo; if (k) pay_total += plen[(size_t)g] - 9 * P * k; }
-    const size_t total = hdr_len + 9 * P * K + pay_total;
-    if (total > dst_cap) return ZN_E_CAP;
-    uint8_t* o = (uint8_t*)dst;
-    if (hdr_len) memcpy(o, hdr, hdr_len);
-    uint8_t* types = o + hdr_len; uint8_t* cums = types + P * K; uint8_t* pay = cums + 8 * P * K;
-    // where every (plane, range) piece goes and what re-bases its cumSizes; then the ranges are copied by one thread each
-    std::vector<size_t> dst_at((size_t)ndev * P, 0); std::vector<uint64_t> rebase((size_t)ndev * P, 0);
-    size_t pay_at = 0;
-    for (size_t p = 0; p < P; p++) {
-      uint64_t run = 0;                              // bytes the earlier ranges put into plane p
-      for (int g = 0; g < ndev; g++) {
-        const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo;
-        if (!k) continue;
-        const size_t tot = (size_t)zn_rd64(part[(size_t)g] + P * k + 8 * (p * k + k - 1));
-        dst_at[(size_t)g * P + p] = pay_at; rebase[(size_t)g * P + p] = run;
-        pay_at += tot; run += tot;
-      }
-    }
-    std::vector<std::thread> cp;
-    for (int g = 0; g < ndev; g++) {
-      const ZnRange r = zn_range_of(K, g, ndev); const size_t k = r.hi - r.lo;
-      if (!k) continue;
-      cp.emplace_back([&, g, r, k]() {
-        const uint8_t* b = part[(size_t)g];
-        size_t base = 0;                             // where plane p starts in this range's payload
-        for (size_t p = 0; p < P; p++) {
-          memcpy(types + p * K + r.lo, b + p * k, k);
-          const uint8_t* c = b + P * k + 8 * p * k;
-          const uint64_t run = rebase[(size_t)g * P + p];
-          for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(c + 8 * i) + run; memcpy(cums + 8 * (p * K + r.lo + i), &v, 8); }
-          const size_t tot = (size_t)zn_rd64(c + 8 * (k - 1));
-          memcpy(pay + dst_at[(size_t)g * P + p], b + 9 * P * k + base, tot);
-          base += tot;
-        }
-      });
-    }
-    for (auto& t : cp) t.join();
-    *dst_len = total;
-    if (hdr_len >= 32) { const uint64_t t64 = total; memcpy(o + 24, &t64, 8); }   // zipnn_core.c:121
-    return ZN_OK;
+    return zn_compress_ranges(hdr, hdr_len, n, num_buf, bits_mode, bytes_mode, chunk, threshold, devices, ndev, dst, dst_cap, dst_len,
+                              [&](int, size_t off) { return ZnPartSrc{(const uint8_t*)src + off, nullptr}; });
   } catch (...) { return ZN_E_ALLOC; }
+}
+
+int zn_compress_multi_dev(const void* hdr, size_t hdr_len, const void* const* d_src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                          size_t chunk, float threshold, const int* devices, int ndev, void* dst, size_t dst_cap, size_t* dst_len) {
+  if (!dst_len || (hdr_len && !hdr) || (n && !d_src) || !dst || !devices || ndev <= 0 || ndev > 64 || !chunk) return ZN_E_ARG;
+  if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  const size_t K = (n + chunk - 1) / chunk;
+  for (int g = 0; g < ndev; g++) { const ZnRange r = zn_range_of(K, g, ndev); if (r.hi > r.lo && !d_src[g]) return ZN_E_ARG; }
+  try {
+    return zn_compress_ranges(hdr, hdr_len, n, num_buf, bits_mode, bytes_mode, chunk, threshold, devices, ndev, dst, dst_cap, dst_len,
+                              [&](int g, size_t) { return ZnPartSrc{nullptr, d_src[g]}; });
+  } catch (...) { return ZN_E_ALLOC; }
+}
+
+int zn_multi_range(size_t n, size_t chunk, int ndev, int i, size_t* off, size_t* len) {
+  if (!chunk || ndev <= 0 || i < 0 || i >= ndev || !off || !len) return ZN_E_ARG;
+  const size_t K = (n + chunk - 1) / chunk;
+  const ZnRange r = zn_range_of(K, i, ndev);
+  *off = r.lo * chunk; *len = r.hi > r.lo ? (r.hi * chunk < n ? r.hi * chunk : n) - r.lo * chunk : 0;
+  return ZN_OK;
+}
+
+int zn_merge_range_bodies(const void* const* bodies, const size_t* body_lens, const size_t* num_chunks, int nparts, int num_buf,
+                          void* dst, size_t dst_cap, size_t* dst_len) {
+  if (nparts < 0 || (nparts && (!bodies || !body_lens || !num_chunks)) || !dst || !dst_len) return ZN_E_ARG;
+  if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
+  try {
+    std::vector<const uint8_t*> part((size_t)nparts); std::vector<size_t> plen((size_t)nparts), ks((size_t)nparts);
+    for (int i = 0; i < nparts; i++) { part[(size_t)i] = (const uint8_t*)bodies[i]; plen[(size_t)i] = body_lens[i]; ks[(size_t)i] = num_chunks[i]; }
+    return zn_assemble_ranges(nullptr, 0, part, plen, ks, (size_t)num_buf, dst, dst_cap, dst_len);
+  } catch (...) { return ZN_E_ALLOC; }
+}
+
+int zn_decompress_range_dev(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk, size_t orig_size,
+                            size_t chunk_lo, size_t chunk_hi, int device, void* d_dst) {
+  if ((body_len && !body) || !chunk) return ZN_E_ARG;
+  if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
+  const size_t K = (orig_size + chunk - 1) / chunk;
+  if (chunk_lo > chunk_hi || chunk_hi > K) return ZN_E_ARG;
+  if (chunk_lo == chunk_hi) return ZN_OK;
+  if (!d_dst) return ZN_E_ARG;
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  try {
+    ZnBodyView v;
+    const int rc = zn_body_view(body, body_len, num_buf, chunk, orig_size, &v);
+    if (rc) return rc;
+    return zn_decode_range(v, ZnRange{chunk_lo, chunk_hi}, num_buf, bits_mode, bytes_mode, chunk, orig_size, device, nullptr, d_dst);
+  } catch (...) { return ZN_E_ALLOC; }
+}
+
+static int zn_decompress_ranges(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk, size_t orig_size,
+                                const int* devices, int ndev, void* h_dst, void* const* d_dst) {
+  ZnBodyView v;
+  int rc = zn_body_view(body, body_len, num_buf, chunk, orig_size, &v);
+  if (rc) return rc;
+  std::vector<int> rcs((size_t)ndev, ZN_OK);
+  {
+    ZnWorkers wk;
+    for (int g = 0; g < ndev; g++) {
+      const ZnRange r = zn_range_of(v.K, g, ndev);
+      if (r.hi <= r.lo) continue;
+      wk.start([&, g, r]() {
+        try { rcs[(size_t)g] = zn_decode_range(v, r, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices[g], h_dst, d_dst ? d_dst[g] : nullptr); }
+        catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
+      });
+    }
+    wk.join();
+    if (wk.failed) return ZN_E_ALLOC;
+  }
+  for (int g = 0; g < ndev; g++) if (rcs[(size_t)g]) return rcs[(size_t)g];
+  return ZN_OK;
 }
 
 int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk, size_t orig_size,
@@ -582,57 +782,21 @@ int zn_decompress_multi(const void* body, size_t body_len, int num_buf, int bits
   if ((body_len && !body) || (orig_size && !dst) || !devices || ndev <= 0 || ndev > 64 || !chunk) return ZN_E_ARG;
   if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
   if (ndev == 1 || orig_size == 0) return zn_decompress(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices[0], dst);
-  try {
-    const size_t P = (size_t)num_buf, K = (orig_size + chunk - 1) / chunk;
-    if (K > body_len / (9 * P)) return ZN_E_CORRUPT;
-    const uint8_t* b = (const uint8_t*)body;
-    const uint8_t* types = b; const uint8_t* cums = b + P * K; const uint8_t* pay = cums + 8 * P * K;
-    const size_t pay_len = body_len - 9 * P * K;
-    // plane bases and monotone, in-range cumSizes (the per-range bodies below are built from them)
-    std::vector<uint64_t> base(P, 0);
-    uint64_t acc = 0;
-    for (size_t p = 0; p < P; p++) {
-      base[p] = acc;
-      uint64_t prev = 0;
-      for (size_t i = 0; i < K; i++) { const uint64_t v = zn_rd64(cums + 8 * (p * K + i)); if (v < prev || v > pay_len - acc) return ZN_E_CORRUPT; prev = v; }
-      acc += prev;
-    }
-    std::lock_guard<std::mutex> mk(g_multi_mu);
-    std::vector<int> rcs((size_t)ndev, ZN_OK);
-    std::vector<uint8_t*> subs((size_t)ndev, nullptr);
-    auto sub_need = [&](const ZnRange& r) {
-      size_t need = 9 * P * (r.hi - r.lo);
-      for (size_t p = 0; p < P; p++) need += (size_t)(zn_rd64(cums + 8 * (p * K + r.hi - 1)) - (r.lo ? zn_rd64(cums + 8 * (p * K + r.lo - 1)) : 0));
-      return need;
-    };
-    for (int g = 0; g < ndev; g++) {
-      const ZnRange r = zn_range_of(K, g, ndev);
-      if (r.hi > r.lo && !(subs[(size_t)g] = zn_stage(g, sub_need(r) + 16))) return ZN_E_ALLOC;
-    }
-    std::vector<std::thread> th;
-    for (int g = 0; g < ndev; g++) {
-      const ZnRange r = zn_range_of(K, g, ndev);
-      if (r.hi <= r.lo) continue;
-      th.emplace_back([&, g, r]() {
-        try {
-          const size_t k = r.hi - r.lo, off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
-          const size_t need = sub_need(r);
-          std::vector<uint64_t> s0(P), s1(P);
-          for (size_t p = 0; p < P; p++) { s0[p] = r.lo ? zn_rd64(cums + 8 * (p * K + r.lo - 1)) : 0; s1[p] = zn_rd64(cums + 8 * (p * K + r.hi - 1)); }
-          uint8_t* w = subs[(size_t)g];
-          for (size_t p = 0; p < P; p++) memcpy(w + p * k, types + p * K + r.lo, k);
-          for (size_t p = 0; p < P; p++)
-            for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(cums + 8 * (p * K + r.lo + i)) - s0[p]; memcpy(w + P * k + 8 * (p * k + i), &v, 8); }
-          size_t at = 9 * P * k;
-          for (size_t p = 0; p < P; p++) { const size_t m = (size_t)(s1[p] - s0[p]); memcpy(w + at, pay + base[p] + s0[p], m); at += m; }
-          rcs[(size_t)g] = zn_decompress(w, need, num_buf, bits_mode, bytes_mode, chunk, len, devices[g], (uint8_t*)dst + off);
-        } catch (...) { rcs[(size_t)g] = ZN_E_ALLOC; }
-      });
-    }
-    for (auto& t : th) t.join();
-    for (int g = 0; g < ndev; g++) if (rcs[(size_t)g]) return rcs[(size_t)g];
-    return ZN_OK;
-  } catch (...) { return ZN_E_ALLOC; }
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  try { return zn_decompress_ranges(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices, ndev, dst, nullptr); }
+  catch (...) { return ZN_E_ALLOC; }
+}
+
+int zn_decompress_multi_dev(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk, size_t orig_size,
+                            const int* devices, int ndev, void* const* d_dst) {
+  if ((body_len && !body) || !devices || ndev <= 0 || ndev > 64 || !chunk || (orig_size && !d_dst)) return ZN_E_ARG;
+  if (num_buf != 1 && num_buf != 2 && num_buf != 4) return ZN_E_ARG;
+  if (orig_size == 0) return ZN_OK;
+  if (zn_device_count() <= 0) return ZN_E_NODEV;
+  const size_t K = (orig_size + chunk - 1) / chunk;
+  for (int g = 0; g < ndev; g++) { const ZnRange r = zn_range_of(K, g, ndev); if (r.hi > r.lo && !d_dst[g]) return ZN_E_ARG; }
+  try { return zn_decompress_ranges(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices, ndev, nullptr, d_dst); }
+  catch (...) { return ZN_E_ALLOC; }
 }
 
 long long zn_last_fused_chunks(void) {
@@ -705,7 +869,7 @@ int zn_release_workspace(void) {
     std::lock_guard<std::mutex> hk(g_host_mu[d]);
     std::lock_guard<std::mutex> lk(g_dev_mu[d]);
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr || w.aux != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -715,8 +879,6 @@ int zn_release_workspace(void) {
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
     zn_host_pipe_release(w.pipe);
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
-    if (w.aux) { (void)hipStreamSynchronize(w.aux); (void)hipStreamDestroy(w.aux); w.aux = nullptr; }
-    for (int i = 0; i < 10; i++) if (w.slab_ev[i]) { (void)hipEventDestroy(w.slab_ev[i]); w.slab_ev[i] = nullptr; }
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   return ZN_OK;

@@ -95,6 +95,19 @@ __device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P,
   return chunk_len / P + (p < chunk_len % P ? 1u : 0u);
 }
 
+// Developer-only switches.  ZN_F_ABL / ZN_E_ABL drop a phase of a kernel to price it on the device (WRONG output), ZN_F_ONLY_HOT
+// compiles one instance, ZN_PHASE_TIMERS(_SUB) adds shader-clock timers, ZN_F_P2_MASK=0 issues LDS atomics below the staging buffer.
+// None of them may reach a product build: zipnn_amd/build.py never defines ZN_DEV_BUILD, and without it any of these is an error
+// (scripts/ab_variants.py and scripts/phase_profile.py define it for their throw-away libraries).
+#if !defined(ZN_DEV_BUILD) && !defined(ZN_SIMT_EMULATOR)
+#if defined(ZN_F_ABL) || defined(ZN_E_ABL) || defined(ZN_F_ONLY_HOT) || defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB)
+#error "developer-only macro (ZN_F_ABL / ZN_E_ABL / ZN_F_ONLY_HOT / ZN_PHASE_TIMERS) without ZN_DEV_BUILD: not a product configuration"
+#endif
+#if defined(ZN_F_P2_MASK) && (ZN_F_P2_MASK == 0)
+#error "ZN_F_P2_MASK=0 without ZN_DEV_BUILD: not a product configuration"
+#endif
+#endif
+
 // ---------------------------------------------------------------------------
 // Optional in-kernel phase timers (developer tool: scripts/phase_profile.py builds a second
 // library with -DZN_PHASE_TIMERS; the shipped libzipnn_hip.so has none of this).  Thread 0 of

@@ -242,7 +242,9 @@ __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& 
     const uint32_t g = ~wm1;                               // low two bits = (-wpos) & 3
     uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & ~3u));
 #ifndef ZN_F_P2_MASK
-#define ZN_F_P2_MASK 2        // 1: lanes with nothing to add stay out of the atomics (exec mask) — 2: per dword
+#define ZN_F_P2_MASK 2        // 1: lanes with nothing to add stay out of the atomics (exec mask) — 2: per dword.  (0, every lane every dword, is a
+                              // developer measurement only, refused outside ZN_DEV_BUILD: with wpos == 0 the pair starts one dword BELOW the staging
+                              // buffer — the neighbouring wave's last dword, or the LUT's — and only the masks keep that zero-valued atomic from being issued)
 #endif
     const uint32_t lo = zn_alignbyte(sv, 0u, g), hi = zn_alignbyte(0u, sv, g);
     if (ZN_F_P2_MASK == 0) { atomicOr(d, lo); atomicOr(d + 1, hi); }

@@ -45,7 +45,6 @@
 // HUF_decompress (:807), combine_buffers_dtype16/32 + revert_all_floats_* (data_manipulation_
 // dtype16.c:145-216, data_manipulation_dtype32.c:275-294,391-456).
 #include "zn_internal.hpp"
-#include <cstdlib>
 #include <atomic>
 #include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
@@ -991,6 +990,7 @@ extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
 
 // chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
 // outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
+static std::atomic<int> g_zn_decode_group{0};
 uint32_t zn_decode_fused_group(uint64_t K) {
   static std::atomic<int> slots_of[64];          // per device (a node may mix parts); 0 = not asked yet
   int dev = 0;
@@ -1004,8 +1004,14 @@ uint32_t zn_decode_fused_group(uint64_t K) {
   }
   uint32_t ncg = (uint32_t)(K / (uint64_t)slots);
   ncg = ncg > 4u ? 4u : (ncg < 1u ? 1u : ncg);
-  if (const char* e = getenv("ZN_DECODE_GROUP")) { const int v = atoi(e); if (v >= 1 && v <= 4) ncg = (uint32_t)v; }   // test / tuning knob
+  const int forced = g_zn_decode_group.load(std::memory_order_relaxed);      // zn_set_decode_group (include/zipnn_hip.h): 0 = automatic
+  if (forced >= 1 && forced <= 4) ncg = (uint32_t)forced;
   return ncg;
+}
+extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
+  if (chunks_per_workgroup < 0 || chunks_per_workgroup > 4) return -1;     // ZN_E_ARG
+  g_zn_decode_group.store(chunks_per_workgroup, std::memory_order_relaxed);
+  return 0;
 }
 
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,

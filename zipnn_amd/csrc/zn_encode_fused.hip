@@ -47,20 +47,8 @@ __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { const zn_ev4u v = _
 __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { return *(const uint4*)p; }
 #endif
 #define ZN_LD_STATS(p) zn_ldnt128(p)
-#ifndef ZN_E_SLABS
-#define ZN_E_SLABS 0                       // > 1: stats / tables slabs of one big tensor overlapped on two streams.  Measured (4 GiB bf16): 2.431 ms per
-                                           // call without, 2.440 / 2.464 / 2.548 ms with 2 / 4 / 8 slabs — the cross-stream event hand-overs cost more than
-                                           // the 0.2 ms of table building they hide (profiles/r02_decode_experiments.txt); off, kept for the next attempt
-#endif
-#ifndef ZN_E_SLAB_MIN_CHUNKS
-#if defined(ZN_SIMT_EMULATOR)
-#define ZN_E_SLAB_MIN_CHUNKS 2             // (the emulated build cuts small test tensors into slabs too: same index arithmetic)
-#else
-#define ZN_E_SLAB_MIN_CHUNKS 2048
-#endif
-#endif
 #ifndef ZN_E_ABL
-#define ZN_E_ABL 0
+#define ZN_E_ABL 0                         // developer builds only (ZN_DEV_BUILD, zn_common.hpp): timing experiments with WRONG statistics
 #endif
 #ifndef ZN_E_EMIT_REVERSE
 #define ZN_E_EMIT_REVERSE 0               // 1: emit walks the chunks from the last one down (what the stats pass read last is what the 256 MB Infinity Cache still holds); measured ±0 at 4 GiB
@@ -118,9 +106,9 @@ struct ZnStatsLds {
 template <int P, bool X>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                   uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
-                                                                  ZnEncDesc* __restrict__ descs_all, uint32_t blk0) {
+                                                                  ZnEncDesc* __restrict__ descs_all) {
   __shared__ ZnStatsLds<P> L;
-  const uint32_t sbid = blockIdx.x + blk0;       // (a launch covers one slab of the chunks: zn_launch_encode_fused_stats)
+  const uint32_t sbid = blockIdx.x;
   const ZnESeg S = zn_efind_chunk(one, segs, nseg, sbid);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); const float threshold = S.threshold;
@@ -245,17 +233,16 @@ struct ZnTablesLds {
 
 __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                          uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
-                                                         ZnEncDesc* __restrict__ descs_all, uint32_t slab_c0, uint32_t slab_cn) {
+                                                         ZnEncDesc* __restrict__ descs_all) {
   __shared__ ZnTablesLds L;
-  // slab_cn > 0 (single tensor only): this launch covers the jobs of chunks [slab_c0, slab_c0 + slab_cn), plane-major
-  const ZnESeg S = slab_cn ? one : zn_efind_job(one, segs, nseg, blockIdx.x);
+  const ZnESeg S = zn_efind_job(one, segs, nseg, blockIdx.x);
   const ZnGeom g = S.g; const uint64_t nfull = S.nfull; const float threshold = S.threshold;
   uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
   ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
   const uint32_t lane = threadIdx.x;
-  const uint64_t job = blockIdx.x - (slab_cn ? 0u : S.job0);
-  const uint32_t p = (uint32_t)(slab_cn ? job / slab_cn : job / nfull);
-  const uint64_t c = slab_cn ? (uint64_t)slab_c0 + job % slab_cn : job % nfull, pc = (uint64_t)p * g.K + c;
+  const uint64_t job = blockIdx.x - S.job0;
+  const uint32_t p = (uint32_t)(job / nfull);
+  const uint64_t c = job % nfull, pc = (uint64_t)p * g.K + c;
   if (type_out[pc] != 2) return;
   const uint32_t n = (uint32_t)(g.chunk / g.P);
   const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
@@ -581,47 +568,19 @@ bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr) {
   return (g.chunk % 16384ull) == 0 && (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
 }
 
-int zn_encode_slabs() { return ZN_E_SLABS; }
-
 void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
-                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream,
-                                  hipStream_t aux, hipEvent_t* ev, int nev) {
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream) {
   if (total_chunks == 0) return;
-#define ZN_GO(P_, X_, GRID_, BLK0_) hipLaunchKernelGGL((zn_k_encode_stats<P_, X_>), dim3(GRID_), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, (uint32_t)(BLK0_))
-#define ZN_STATS(GRID_, BLK0_) do { \
-    if (!delta) { if (P == 1) ZN_GO(1, false, GRID_, BLK0_); else if (P == 2) ZN_GO(2, false, GRID_, BLK0_); else ZN_GO(4, false, GRID_, BLK0_); } \
-    else { if (P == 1) ZN_GO(1, true, GRID_, BLK0_); else if (P == 2) ZN_GO(2, true, GRID_, BLK0_); else ZN_GO(4, true, GRID_, BLK0_); } } while (0)
-  // One big tensor: the table kernel is serial-latency bound (≈65 µs per job, ≈5 600 jobs on the chip at once: 0.21 ms for
-  // the 16 384 chunks of 4 GiB) and needs nothing but its own chunks' counts — so the chunks are cut into slabs, and the
-  // tables of slab k are built on a second stream while the stats kernel reads slab k + 1.  Only the last slab's
-  // tables are left exposed.  (ZN_E_SLABS: most slabs; 0 = one launch of each, as for batches of tensors.)
-  int slabs = (d_segs == nullptr && nseg == 1 && aux && ev) ? (int)(total_chunks / ZN_E_SLAB_MIN_CHUNKS) : 0;
-  if (slabs > ZN_E_SLABS) slabs = ZN_E_SLABS;
-  if (slabs > nev - 1) slabs = nev - 1;
-  if (slabs >= 2) {
-    const uint32_t per = (total_chunks + (uint32_t)slabs - 1u) / (uint32_t)slabs;
-    slabs = (int)((total_chunks + per - 1u) / per);          // (rounding `per` up can leave fewer slabs than asked for)
-    bool ok = true;
-    for (int k = 0; k < slabs; k++) {
-      const uint32_t c0 = per * (uint32_t)k, cn = (c0 + per <= total_chunks) ? per : total_chunks - c0;
-      ZN_STATS(cn, c0);
-      ok = ok && hipEventRecord(ev[k], stream) == hipSuccess && hipStreamWaitEvent(aux, ev[k], 0) == hipSuccess;
-      hipLaunchKernelGGL(zn_k_encode_tables, dim3(cn * (uint32_t)P), dim3(64), 0, aux, one, d_segs, nseg, d_csize, d_type, d_descs, c0, cn);
-    }
-    ok = ok && hipEventRecord(ev[slabs], aux) == hipSuccess && hipStreamWaitEvent(stream, ev[slabs], 0) == hipSuccess;
-    zn_note_kernel(delta ? "zn_k_encode_stats^delta" : "zn_k_encode_stats");
-    zn_note_kernel("zn_k_encode_tables");
-    if (ok) return;
-    (void)hipGetLastError();                   // an event call failed: fall through to one plain tables launch behind everything (jobs already done return at once)
-    (void)hipStreamSynchronize(aux);
-    hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, 0u, 0u);
-    return;
-  }
-  ZN_STATS(total_chunks, 0u);
-#undef ZN_STATS
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_stats<P_, X_>), dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs)
+  // (the table kernel is serial-latency bound — ≈65 µs per job, ≈5 600 jobs on the chip at once, 0.21 ms for the 16 384 chunks of
+  //  4 GiB.  Building the tables of one slab of chunks on a second stream while the stats kernel reads the next was tried in round 2
+  //  and removed in round 3: 2.431 ms per call without, 2.440 / 2.464 / 2.548 ms with 2 / 4 / 8 slabs — the cross-stream event
+  //  hand-overs cost more than the table build they hide: profiles/r02_decode_experiments.txt)
+  if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
+  else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO
   zn_note_kernel(delta ? "zn_k_encode_stats^delta" : "zn_k_encode_stats");
-  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, 0u, 0u);
+  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
   zn_note_kernel("zn_k_encode_tables");
 }
 

@@ -80,10 +80,8 @@ struct ZnESeg {
 // Slot stride of the generic path's scratch planes = zn_plane_slot(chunk, P).  All launchers: `one` when
 // d_segs == nullptr, else the table; grid totals are sums over the launch's tensors.
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr);    // d_xr: delta base or null
-int zn_encode_slabs();
 void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
-                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream,
-                                  hipStream_t aux = nullptr, hipEvent_t* ev = nullptr, int nev = 0);   // aux + events: overlap the tables of slab k with the stats of slab k + 1
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream);
 void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
                                  uint32_t* d_status, bool delta, hipStream_t stream);

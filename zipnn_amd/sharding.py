@@ -5,8 +5,10 @@ Chunks are independent, so G ranks can code disjoint chunk ranges with no data-p
 regions of the final payload; these helpers do that arithmetic:
 
   chunk_ranges(K, G)                 contiguous ranges [g*K/G, (g+1)*K/G)
-  split_body(body, P, chunk, n, G)   one standalone body per rank (types / re-based cumSizes / payload slices)
-  merge_bodies(parts, P)             the inverse: bodies of consecutive chunk ranges -> one body
+  sub_body(body, P, chunk, n, lo, hi)  the standalone body of ONE chunk range (types / re-based cumSizes / payload slices)
+  split_body(body, P, chunk, n, G)   … of every rank's range (tests, tools; a rank that needs only its own calls sub_body)
+  merge_bodies(parts, P, lib=None)   the inverse: bodies of consecutive chunk ranges -> one body; with `lib` the copying is the
+                                     library's (zn_merge_range_bodies: one thread per part), without it plain numpy
   decompress_replicated(...)         every rank decodes its chunk range in HBM, one all-gather (RCCL over xGMI)
                                      leaves the whole tensor on every GPU (replicated-weight loading)
 
@@ -33,31 +35,38 @@ def uniform_ranges(num_chunks, world):
     return [(min(g * per, num_chunks), min((g + 1) * per, num_chunks)) for g in range(world)]
 
 
+def sub_body(body, num_buf, chunk, orig_size, lo, hi):
+    """-> (sub_body: bytes, byte_offset, byte_length) of the chunk range [lo, hi) alone: only that range's bytes are touched."""
+    P = num_buf
+    K = (orig_size + chunk - 1) // chunk
+    k = hi - lo
+    if k <= 0:
+        return b"", lo * chunk, 0
+    types, cum, payload = _parse(body, P, K)
+    plane_base = np.concatenate([[0], np.cumsum(cum[:, -1])[:-1]])
+    pieces, cums = [], []
+    for p in range(P):
+        start = int(cum[p, lo - 1]) if lo else 0
+        end = int(cum[p, hi - 1])
+        pieces.append(payload[int(plane_base[p]) + start: int(plane_base[p]) + end])
+        cums.append((cum[p, lo:hi] - start).astype(np.uint64))
+    sub = b"".join([types[:, lo:hi].tobytes()] + [c.tobytes() for c in cums] + [x.tobytes() for x in pieces])
+    off = lo * chunk
+    return sub, off, min(hi * chunk, orig_size) - off
+
+
 def split_body(body, num_buf, chunk, orig_size, world, ranges=None):
     """-> list of (sub_body: bytes, byte_offset, byte_length) for each rank's chunk range
     (ranges: explicit [(lo, hi)] per rank; default chunk_ranges(K, world))."""
-    P = num_buf
     K = (orig_size + chunk - 1) // chunk
-    types, cum, payload = _parse(body, P, K)
-    plane_base = np.concatenate([[0], np.cumsum(cum[:, -1])[:-1]]) if K else np.zeros(P, dtype=np.int64)
-    out = []
-    for lo, hi in (ranges if ranges is not None else chunk_ranges(K, world)):
-        k = hi - lo
-        pieces, cums = [], []
-        for p in range(P):
-            start = int(cum[p, lo - 1]) if lo else 0
-            end = int(cum[p, hi - 1]) if hi else 0
-            pieces.append(payload[int(plane_base[p]) + start: int(plane_base[p]) + end])
-            cums.append((cum[p, lo:hi] - start).astype(np.uint64))
-        sub = b"".join([types[:, lo:hi].tobytes()] + [c.tobytes() for c in cums] + [x.tobytes() for x in pieces]) if k else b""
-        off = lo * chunk
-        length = min(hi * chunk, orig_size) - off if k else 0
-        out.append((sub, off, length))
-    return out
+    return [sub_body(body, num_buf, chunk, orig_size, lo, hi) for lo, hi in (ranges if ranges is not None else chunk_ranges(K, world))]
 
 
-def merge_bodies(parts, num_buf):
-    """parts: list of (body: bytes-like, num_chunks) for consecutive chunk ranges -> one body (bytes)."""
+def merge_bodies(parts, num_buf, lib=None):
+    """parts: list of (body: bytes-like, num_chunks) for consecutive chunk ranges -> one body (bytes).
+    lib: a zipnn_amd._capi.ZnLib — the plane-major placement is then done by the library (zn_merge_range_bodies)."""
+    if lib is not None:
+        return bytes(lib.merge_range_bodies([(b, k) for b, k in parts if k], num_buf))
     P = num_buf
     types_all, cum_all, pay_all = [[] for _ in range(P)], [[] for _ in range(P)], [[] for _ in range(P)]
     run = np.zeros(P, dtype=np.int64)
@@ -86,7 +95,7 @@ def decompress_replicated(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig
     Returns a uint8 tensor of orig_size bytes on `device`."""
     import torch
     import torch.distributed as dist
-    from . import codec
+    device = torch.device(device)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     K = (orig_size + chunk - 1) // chunk
@@ -95,9 +104,13 @@ def decompress_replicated(lib, body, num_buf, bits_mode, bytes_mode, chunk, orig
     full = torch.empty(max(shard * world, 1), dtype=torch.uint8, device=device)
     lo, hi = ranges[rank]
     if hi > lo:
-        sub, off, length = split_body(body, num_buf, chunk, orig_size, world, ranges)[rank]
-        sub_t = codec.to_device(lib, sub, device)          # (the library's pinned multi-threaded transfer)
-        codec.decompress_device(lib, sub_t, num_buf, bits_mode, bytes_mode, chunk, length, out=full[off:off + length])
+        # only this rank's range is touched: its re-based size tables are built by the library, its payload slices go from `body`
+        # through the pinned pipe straight into HBM (zn_decompress_range_dev) and are decoded into the rank's shard of `full`
+        off = lo * chunk
+        dev_index = device.index if (device.type == "cuda" and device.index is not None) else (torch.cuda.current_device() if device.type == "cuda" else 0)
+        if device.type == "cuda":
+            torch.cuda.current_stream(device).synchronize()             # (`full` may be a block kernels queued earlier still use)
+        lib.decompress_range_dev(body, num_buf, bits_mode, bytes_mode, chunk, orig_size, lo, hi, dev_index, full.data_ptr() + off)
     if dist.is_initialized():                                           # (a group of one still goes through the collective: RCCL on GPUs)
         mine = full[rank * shard:(rank + 1) * shard].clone()            # (gloo does not take an aliasing input)
         dist.all_gather_into_tensor(full[:shard * world], mine, group=group)
