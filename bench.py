@@ -24,8 +24,17 @@ Also on the JSON line:
   other_dtypes       fp16 / fp32 / fp8-e4m3 tensors of 1 GiB each (BASELINE.json configs[2]): event-timed decode and
                      compress, GB/s, ratio, (N + C)/t as a fraction of 8 TB/s, exact round trip (N = 1 only)
   cpu_baseline       the reference's own C core (oracle/_ref: reference csrc/ + libzstd 1.4.8 huff0; "port" = our C
-                     restatement if that build is absent) timed on the host cores, and the WHOLE GPU frame compared
-                     with the CPU frame of the same tensor (gpu_frame_equals_cpu_frame)
+                     restatement if that build is absent) timed on the host cores at T = min(nproc, 16) (the reference's
+                     default) and at T = nproc, with nproc / CPU model / NUMA nodes / malloc environment on the line, and
+                     the WHOLE GPU frame compared with the CPU frame of the same tensor (gpu_frame_equals_cpu_frame)
+  plugin_gpt2        BASELINE.json configs[3] (N = 1): a real-size GPT-2 checkpoint (148 fp32 tensors, 498 MB, synthesised),
+                     compressed once, then loaded onto cuda:0 through zipnn_safetensors() + safe_open and through
+                     safetensors_io.load_file — seconds split into file read / H2D / decode — beside the reference's
+                     per-tensor CPU decode of the same frames
+  llama8b            BASELINE.json configs[4] on the same line at every N: the --workload llama8b run (strong scaling: the
+                     chunk ranges of every tensor split over the ranks), value / ms / (N + C)/t fraction, and at N = 1 a sample
+                     of its batched bodies compared with the CPU oracle's
+  rccl_ranks         ranks that took part in an all_reduce over RCCL (N > 1 or under torch.distributed.run)
 
 --workload llama8b.  The 291 tensors of a Llama-3-8B checkpoint (bf16, N(0, 0.02), ~16 GB) plus an fp8-e4m3 copy of
 its linear weights (~7 GB), synthesised on the devices.  Every tensor's chunks are split into WORLD_SIZE contiguous
@@ -77,43 +86,89 @@ def time_events(fn, steps):
     return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
+def host_info():
+    """What BASELINE.md §3 wants next to every CPU number."""
+    info = {"nproc": os.cpu_count() or 1, "cpu_model": None, "numa_nodes": None,
+            "malloc_env": {k: v for k, v in os.environ.items() if k.startswith("MALLOC_") or k in ("LD_PRELOAD",)}}
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                info["cpu_model"] = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        info["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        pass
+    return info
+
+
 def cpu_baseline(raw, want_body):
     """Time the CPU reference on the host cores (rank 0, N = 1 only) and compare its frame with the GPU's.
     Test infrastructure is used here strictly as the thing being compared AGAINST."""
+    import hashlib
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as O
-    threads = min(os.cpu_count() or 1, 16)            # the reference default (zipnn/zipnn.py:176-177)
+    hi = host_info()
+    nproc = hi["nproc"]
+    t_ref = min(nproc, 16)                            # the reference default (zipnn/zipnn.py:176-177)
     hdr = bytes(32)
     kind = "reference" if O.ref_core() is not None else "port"
-    best_c = best_d = 1e9
-    frame = None
+
+    def run(buf_np, threads, reps):
+        best_c = best_d = 1e9
+        frame = back = None
+        for _ in range(reps):
+            if kind == "reference":
+                buf = bytearray(buf_np.tobytes())     # the reference rotates its input in place
+                t0 = time.perf_counter()
+                frame = O.ref_core().zipnn_core(bytearray(hdr), buf, P, ROT, BMODE, 0, CHUNK, THR, 10, threads)
+                best_c = min(best_c, time.perf_counter() - t0)
+                del buf
+                t0 = time.perf_counter()
+                back = O.ref_core().combine_dtype(memoryview(frame)[32:], P, ROT, BMODE, CHUNK, buf_np.size, threads)
+                best_d = min(best_d, time.perf_counter() - t0)
+            else:
+                t0 = time.perf_counter()
+                frame = O.compress_frame(hdr, buf_np, P, ROT, BMODE, CHUNK, THR, threads)
+                best_c = min(best_c, time.perf_counter() - t0)
+                t0 = time.perf_counter()
+                back = O.decompress_body(frame[32:], P, ROT, BMODE, CHUNK, buf_np.size, threads)
+                best_d = min(best_d, time.perf_counter() - t0)
+        return best_c, best_d, frame, back
     reps = 2 if raw.size > (1 << 30) else 3
-    for _ in range(reps):
-        if kind == "reference":
-            buf = bytearray(raw.tobytes())             # the reference rotates its input in place
-            t0 = time.perf_counter()
-            frame = O.ref_core().zipnn_core(bytearray(hdr), buf, P, ROT, BMODE, 0, CHUNK, THR, 10, threads)
-            best_c = min(best_c, time.perf_counter() - t0)
-            del buf
-            t0 = time.perf_counter()
-            back = O.ref_core().combine_dtype(memoryview(frame)[32:], P, ROT, BMODE, CHUNK, raw.size, threads)
-            best_d = min(best_d, time.perf_counter() - t0)
-        else:
-            t0 = time.perf_counter()
-            frame = O.compress_frame(hdr, raw, P, ROT, BMODE, CHUNK, THR, threads)
-            best_c = min(best_c, time.perf_counter() - t0)
-            t0 = time.perf_counter()
-            back = O.decompress_body(frame[32:], P, ROT, BMODE, CHUNK, raw.size, threads)
-            best_d = min(best_d, time.perf_counter() - t0)
-    import numpy as np
+    best_c, best_d, frame, back = run(raw, t_ref, reps)
     assert np.array_equal(np.frombuffer(back, dtype=np.uint8), raw)
     fb = np.frombuffer(memoryview(frame)[32:], dtype=np.uint8)
     parity = bool(fb.size == want_body.size and np.array_equal(fb, want_body)) if want_body is not None else None
     gb = raw.size / 1e9
-    return {"value": round(gb / best_d, 3), "unit": "GB/s", "cores": threads, "kind": kind,
-            "compress_GBps": round(gb / best_c, 3),
-            "sample": f"the first {raw.size >> 20} MiB of the same tensor (all of it when that is its size), decompress best of {reps}, {threads} threads",
-            "gpu_frame_equals_cpu_frame": parity, "frame_compare_bytes": int(raw.size)}
+    out = {"value": round(gb / best_d, 3), "unit": "GB/s", "cores": t_ref, "kind": kind,
+           "compress_GBps": round(gb / best_c, 3),
+           "sample": f"the first {raw.size >> 20} MiB of the same tensor (all of it when that is its size), decompress best of {reps}, {t_ref} threads",
+           "gpu_frame_equals_cpu_frame": parity, "frame_compare_bytes": int(raw.size),
+           "frame_sha256": hashlib.sha256(memoryview(frame)).hexdigest(), "ratio": round(len(frame) / raw.size, 5)}
+    out.update(hi)
+    if nproc != t_ref:                                # BASELINE.md §3: T = nproc beside the reference default (1 GiB sample, best of 2)
+        sub = raw[: min(raw.size, 1 << 30) // CHUNK * CHUNK]
+        tn = nproc if kind == "reference" else min(nproc, 64)        # (the port caps its pthreads at 64; the reference's core does not)
+        c2, d2, _, _ = run(sub, tn, 2)
+        out["all_cores"] = {"cores": tn, "value": round(sub.size / 1e9 / d2, 3), "compress_GBps": round(sub.size / 1e9 / c2, 3),
+                            "sample": f"the first {sub.size >> 20} MiB, best of 2, T = nproc"}
+    return out
+
+
+def traffic_of(kind, n_bytes):
+    """HBM bytes per decode launch of `kind` from the committed PMC pass (profiles/traffic_pmc.json: FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, per GiB; scripts/pmc_traffic.py writes it from a rocprofv3 --pmc run of the kernels named there), scaled to this
+    size; the source file and the commit of the kernels it was measured on travel with the number."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as f:
+            t = json.load(f)
+        e = t["decode"][kind]
+        return int(e["hbm_bytes_per_gib_launch"] * (n_bytes / (1 << 30))), {"file": "profiles/traffic_pmc.json", "from": e.get("from"), "kernels_commit": t.get("kernels_commit")}
+    except Exception:
+        return None, None
 
 
 def other_dtypes(lib, codec, device, steps):
@@ -141,7 +196,8 @@ def other_dtypes(lib, codec, device, steps):
         c = stats(time_events(lambda: codec.compress_device(lib, flat, nb, rot, bm, chunk, THR, body=body), max(2, steps // 2)))
         exact = exact and bool(torch.equal(dst, flat))
         cpl = used - 9 * nb * ((n + chunk - 1) // chunk)
-        out[name] = {"GiB": 1.0, "ratio": round((used + 32) / n, 5), "exact": exact,
+        tr, _ = traffic_of({"fp8_e4m3": "fp8"}.get(name, name), n)
+        out[name] = {"GiB": 1.0, "ratio": round((used + 32) / n, 5), "exact": exact, "decompress_traffic": tr, "algorithmic_bytes": int(n + cpl),
                      "decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "decompress_ms_min": round(d["min"], 4),
                      "decompress_roofline_frac": round((n + cpl) / (d["avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      "compress_GBps": round(n / c["avg"] / 1e6, 1), "compress_ms": round(c["avg"], 4), "compress_ms_min": round(c["min"], 4),
@@ -149,6 +205,120 @@ def other_dtypes(lib, codec, device, steps):
         del x, flat, body, dst
         torch.cuda.empty_cache()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# plugin_gpt2 (BASELINE.json configs[3]; reference zipnn/zipnn.py:1584-1643, scripts/zipnn_compress_safetensors.py:74-123)
+# ---------------------------------------------------------------------------------------------------------------
+def gpt2_state(device, layers=12, width=768, vocab=50257, npos=1024, seed=4242):
+    """The 148 tensors of `transformers.GPT2LMHeadModel(GPT2Config())` (497.8 MB fp32), initialised the way GPT-2 is:
+    N(0, 0.02) weights, zero biases, unit LayerNorm gains (no network for the real checkpoint)."""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    n = lambda *sh: torch.randn(*sh, generator=g, device=device) * 0.02       # noqa: E731
+    sd = {"transformer.wte.weight": n(vocab, width), "transformer.wpe.weight": n(npos, width)}
+    for i in range(layers):
+        p = f"transformer.h.{i}."
+        sd.update({p + "ln_1.weight": torch.ones(width, device=device), p + "ln_1.bias": torch.zeros(width, device=device),
+                   p + "attn.c_attn.weight": n(width, 3 * width), p + "attn.c_attn.bias": torch.zeros(3 * width, device=device),
+                   p + "attn.c_proj.weight": n(width, width), p + "attn.c_proj.bias": torch.zeros(width, device=device),
+                   p + "ln_2.weight": torch.ones(width, device=device), p + "ln_2.bias": torch.zeros(width, device=device),
+                   p + "mlp.c_fc.weight": n(width, 4 * width), p + "mlp.c_fc.bias": torch.zeros(4 * width, device=device),
+                   p + "mlp.c_proj.weight": n(4 * width, width), p + "mlp.c_proj.bias": torch.zeros(width, device=device)})
+    sd.update({"transformer.ln_f.weight": torch.ones(width, device=device), "transformer.ln_f.bias": torch.zeros(width, device=device)})
+    return sd
+
+
+def plugin_gpt2(lib, device):
+    """Load-time decompress of a GPT-2 `.znn.safetensors` on one GPU, end to end from the file: the plugin path
+    (zipnn_safetensors() + safe_open(device=...) + get_tensor per tensor) and the batched path (safetensors_io.load_file),
+    each best of 3 with the file in the page cache; beside them the reference's own per-tensor decode on the host cores
+    (oracle/_ref = the reference C core, called once per compressed tensor as its plugin does)."""
+    import shutil
+    import tempfile
+    import safetensors
+    import safetensors.torch
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io, zipnn_safetensors
+    from zipnn_amd import zipnn as _Z
+    tmp = tempfile.mkdtemp(prefix="zn_gpt2_")
+    res = {}
+    try:
+        sd = gpt2_state(device)
+        raw_bytes = sum(v.numel() * v.element_size() for v in sd.values())
+        src = os.path.join(tmp, "gpt2.safetensors")
+        save_file({k: v.cpu() for k, v in sd.items()}, src, {"format": "pt"})
+        t0 = time.perf_counter()
+        znn = safetensors_io.compress_safetensors_file(src, device=str(device))        # staged in HBM, one batched compress
+        torch.cuda.synchronize()
+        res["compress_file_s"] = round(time.perf_counter() - t0, 4)
+        res.update(tensors=len(sd), raw_bytes=int(raw_bytes), file_bytes=os.path.getsize(znn), ratio=round(os.path.getsize(znn) / raw_bytes, 5))
+
+        def check(loaded):
+            return all(bool(torch.equal(loaded[k], sd[k])) and loaded[k].is_cuda for k in sd) and set(loaded) == set(sd)
+        best, split, exact = 1e9, None, True
+        for _ in range(3):
+            tm = {}
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            loaded = safetensors_io.load_file(znn, device=str(device), timings=tm)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            exact = exact and check(loaded)
+            if dt < best:
+                best, split = dt, tm
+            del loaded
+        res["load_file"] = {"seconds": round(best, 4), "GBps": round(raw_bytes / best / 1e9, 2), "file_read_s": round(split["read_s"], 4),
+                            "h2d_s": round(split["h2d_s"], 4), "decode_s": round(split["decode_s"], 4),
+                            "decode_GBps": round(split["decoded_bytes"] / max(split["decode_s"], 1e-9) / 1e9, 1),
+                            "compressed_tensors": split["compressed_tensors"], "kernels": lib.last_kernels(), "bit_exact": exact}
+        orig_a, orig_b = safetensors.torch.safe_open, safetensors.safe_open
+        try:
+            zipnn_safetensors()
+            best, exact = 1e9, True
+            for _ in range(3):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                loaded = {}
+                with safetensors.safe_open(znn, framework="pt", device=str(device)) as f:
+                    for k in f.keys():
+                        loaded[k] = f.get_tensor(k)
+                torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+                exact = exact and check(loaded)
+                del loaded
+            res["plugin_safe_open"] = {"seconds": round(best, 4), "GBps": round(raw_bytes / best / 1e9, 2), "bit_exact": exact,
+                                       "note": "zipnn_safetensors() + safetensors.safe_open(device=cuda) + get_tensor per tensor: one decode launch set per tensor"}
+        finally:
+            safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
+            _Z._patches_applied.pop(_Z._zipnn_safetensors, None)
+        # the reference's plugin on the host cores: its C core, once per compressed tensor (zipnn.py:1592-1626 -> :1143)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        if O.ref_core() is not None:
+            from zipnn_amd.zipnn import ZipNN, COMPRESSED_DTYPE, COMPRESSION_METHOD, get_compressed_tensors_metadata
+            threads = min(os.cpu_count() or 1, 16)
+            with safetensors.safe_open(znn, "pt", "cpu") as f:
+                infos = get_compressed_tensors_metadata(dict(f.metadata() or {}))
+                frames = []
+                for k in f.keys():
+                    if k in infos:
+                        t = f.get_tensor(k)
+                        fp = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD).frame_params(t)
+                        frames.append((k, t.numpy().tobytes()[fp["body_off"]:], fp))
+            best = 1e9
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ok = True
+                for k, body, fp in frames:
+                    back = O.ref_core().combine_dtype(body, fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"], threads)
+                    ok = ok and len(back) == fp["orig_size"]
+                best = min(best, time.perf_counter() - t0)
+            dec = sum(fp["orig_size"] for _, _, fp in frames)
+            res["cpu_reference_core"] = {"seconds": round(best, 4), "GBps": round(dec / best / 1e9, 2), "threads": threads, "tensors": len(frames),
+                                         "what": "oracle/_ref (the reference's C core + libzstd 1.4.8 huff0), combine_dtype once per compressed tensor as its plugin "
+                                                 "calls it, frames already in host memory; the reference's Python package is not on this box, its per-tensor Python "
+                                                 "overhead is not in this number (BASELINE.md §2 measured the whole plugin at 0.46 s on 8 vCPUs)"}
+        else:
+            res["cpu_reference_core"] = None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -169,7 +339,7 @@ def llama8b_shapes(layers=32, hidden=4096, inter=14336, vocab=128256, kv_heads=8
     return t
 
 
-def run_llama8b(args, lib, codec, device, world, rank, dist, td):
+def run_llama8b(args, lib, codec, device, world, rank, dist, td, sample_oracle=False):
     from zipnn_amd import sharding
     shapes = llama8b_shapes(layers=args.layers)
     f8 = getattr(torch, "float8_e4m3fn", None)
@@ -235,8 +405,10 @@ def run_llama8b(args, lib, codec, device, world, rank, dist, td):
         cb = torch.tensor([float(c_bytes)], device=device, dtype=torch.float64)
         td.all_reduce(cb)
         c_bytes = int(cb.item())
+    line = None
     if rank == 0:
         d = stats(dms)
+        c_payload = c_bytes - sum(9 * nb * ((f.numel() + chunk - 1) // chunk) for (f, nb, rot, bm, chunk, _) in items) if world == 1 else None
         line = {"metric": "Llama-3-8B-shaped checkpoint (bf16 + fp8 copy of the linears): decompress GB/s, chunk ranges sharded over the GPUs",
                 "value": round(total_bytes * args.steps / elapsed / 1e9, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
@@ -249,7 +421,25 @@ def run_llama8b(args, lib, codec, device, world, rank, dist, td):
                 "ratio": round(c_bytes / total_bytes, 5), "bit_exact_roundtrip": exact,
                 "rank0_decode_ms": {k: round(v, 4) for k, v in d.items()},
                 "kernels": {"decompress": decode_kernels, "compress": encode_kernels}}
-        print(json.dumps(line), flush=True)
+        if c_payload is not None:                     # (N + C) / t on rank 0's event-timed launches, as a fraction of 8 TB/s
+            line["decompress_roofline_frac"] = round((total_bytes + c_payload) / (d["avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        if world == 1 and sample_oracle:
+            # a sample of the batched bodies against the CPU oracle's frames of the same tensors: the smallest, the largest that the
+            # oracle codes in about a second, one fp8 tensor and one bf16 tensor with a ragged tail
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            order = sorted(range(len(items)), key=lambda i: items[i][0].numel())
+            pick = {order[0], order[len(order) // 2]}
+            pick |= {next(i for i in order if items[i][1] == 1 and items[i][0].numel() >= (8 << 20))} if any(it[1] == 1 for it in items) else set()
+            pick |= {next(i for i in reversed(order) if items[i][0].numel() <= (128 << 20))}
+            same, nbytes = True, 0
+            for i in sorted(pick):
+                f, nb, rot, bm, chunk, th = items[i]
+                want = O.compress_frame(b"", f.cpu().numpy(), nb, rot, bm, chunk, th, threads=min(os.cpu_count() or 1, 16))
+                same = same and bodies[i].cpu().numpy().tobytes() == want
+                nbytes += f.numel()
+            line["bodies_equal_oracle"] = {"tensors": len(pick), "bytes": int(nbytes), "equal": same}
+    return line
 
 
 def main():
@@ -267,6 +457,8 @@ def main():
     ap.add_argument("--layers", type=int, default=32, help="llama8b: transformer layers to synthesise (32 = the real model)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-dtypes", action="store_true")
+    ap.add_argument("--no-plugin", action="store_true", help="skip plugin_gpt2 (BASELINE.json configs[3])")
+    ap.add_argument("--no-llama8b", action="store_true", help="skip the llama8b sub-run on the default line (BASELINE.json configs[4])")
     ap.add_argument("--cpu-sample-mib", type=int, default=4096, help="bytes of the tensor the CPU reference is timed on and the GPU frame is compared on")
     args = ap.parse_args()
 
@@ -284,8 +476,17 @@ def main():
     from zipnn_amd import _capi, codec
     lib = _capi.lib()
 
+    rccl_ranks = None
+    if dist:                                      # how many ranks are really there, over the collective library itself
+        ones = torch.ones(1, device=device, dtype=torch.float64)
+        td.all_reduce(ones)
+        rccl_ranks = int(ones.item())
+
     if args.workload == "llama8b":
-        run_llama8b(args, lib, codec, device, world, rank, dist, td)
+        line = run_llama8b(args, lib, codec, device, world, rank, dist, td, sample_oracle=(world == 1))
+        if rank == 0:
+            line["rccl_ranks"] = rccl_ranks
+            print(json.dumps(line), flush=True)
         if dist:
             td.barrier()
             td.destroy_process_group()
@@ -358,13 +559,7 @@ def main():
         alg = n_bytes + c_payload
         achieved = alg / (d["avg"] * 1e-3) / 1e9
         c_achieved = alg / (c["avg"] * 1e-3) / 1e9
-        traffic = None     # HBM bytes per launch from the committed PMC pass, scaled to this size
-        try:
-            with open(os.path.join(ROOT, "profiles", "decode_traffic_pmc.json")) as f:
-                t = json.load(f)
-            traffic = int(t["hbm_bytes_per_gib_launch"] * (n_bytes / (1 << 30)) / t["gib"])
-        except Exception:
-            pass
+        traffic, traffic_src = traffic_of("bf16", n_bytes)
         line = {
             "metric": "bf16 decompress GB/s (uncompressed bytes / s; compress GB/s beside it)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -378,7 +573,7 @@ def main():
             "compress_steps": csteps, "compress_frame_identical_every_step": same_body,
             "ratio": round((body.numel() + 32) / n_bytes, 5), "bit_exact_roundtrip": exact,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": decode_kernels, "avg_launch_ms": round(d["avg"], 4),
                          "min_launch_ms": round(d["min"], 4), "median_launch_ms": round(d["median"], 4),
                          "algorithmic_bytes": alg},
@@ -389,18 +584,29 @@ def main():
                                   "note": "events bracket the whole zn_compress_dev call: four kernels + one 8-byte length read-back"},
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},
         }
+        line["rccl_ranks"] = rccl_ranks
+    # ---- BASELINE.json configs[4] on the same line, at every N (every rank takes part; strong scaling) ----
+    del x, flat, body_buf, out
+    torch.cuda.empty_cache()
+    if not args.no_llama8b:
+        import copy
+        a2 = copy.copy(args); a2.steps = max(2, min(args.steps, 10)); a2.warmup = min(args.warmup, 3)
+        llama = run_llama8b(a2, lib, codec, device, world, rank, dist, td, sample_oracle=(world == 1))
+        torch.cuda.empty_cache()
+        if rank == 0:
+            line["llama8b"] = llama
+    if rank == 0:
         if world == 1 and not args.no_other_dtypes:
-            del out
-            torch.cuda.empty_cache()
             line["other_dtypes"] = other_dtypes(lib, codec, device, max(4, min(args.steps, 20)))
+        if world == 1 and not args.no_plugin:
+            line["plugin_gpt2"] = plugin_gpt2(lib, device)
         if world == 1 and not args.no_cpu_baseline:
             sample = min(args.cpu_sample_mib << 20, n_bytes) // CHUNK * CHUNK
             if sample:
-                if sample == n_bytes:
-                    sbody = body
-                else:
-                    sbody = codec.compress_device(lib, flat[:sample], P, ROT, BMODE, CHUNK, THR)
-                line["cpu_baseline"] = cpu_baseline(flat[:sample].cpu().numpy(), sbody.cpu().numpy())
+                xs = make_tensor(sample, device, 1234 + 1000 * rank)       # (the same seeds: the first `sample` bytes of the timed tensor)
+                fs = codec.flat_bytes(xs)
+                sbody = body if sample == n_bytes else codec.compress_device(lib, fs, P, ROT, BMODE, CHUNK, THR)
+                line["cpu_baseline"] = cpu_baseline(fs.cpu().numpy(), sbody.cpu().numpy())
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

@@ -84,31 +84,126 @@ def decompress_safetensors_file(filename, out_path=None, device="cpu"):
     return out_path
 
 
-def load_file(filename, device="cuda:0"):
-    """Load a (possibly ZipNN-compressed) safetensors file straight onto `device`: compressed tensors cross
-    PCIe compressed and are decoded by ONE batched launch (zn_decompress_batch_dev), so a file of many small
-    tensors decodes at the rate of one large tensor.  -> {name: tensor}.  The batched counterpart of looping
-    SafeOpen.get_tensor (reference zipnn.py:1592-1626, scripts/zipnn_decompress_safetensors.py:75-120)."""
-    from safetensors import safe_open
+_ST_DTYPES = {"F64": torch.float64, "F32": torch.float32, "F16": torch.float16, "BF16": torch.bfloat16, "I64": torch.int64, "I32": torch.int32,
+              "I16": torch.int16, "I8": torch.int8, "U8": torch.uint8, "BOOL": torch.bool, "F8_E4M3": getattr(torch, "float8_e4m3fn", None),
+              "F8_E5M2": getattr(torch, "float8_e5m2", None), "U16": getattr(torch, "uint16", None), "U32": getattr(torch, "uint32", None),
+              "U64": getattr(torch, "uint64", None)}
+
+
+def _read_layout(filename):
+    """The safetensors container itself: 8-byte little-endian header length, a JSON header {name: {dtype, shape, data_offsets}}
+    (+ "__metadata__"), then the tensors' bytes back to back.  -> (metadata, {name: (dtype, shape, lo, hi)}, data_start), or None
+    when the header names a dtype this loader does not know (the per-tensor path then reads the file through safetensors)."""
+    import json
+    with open(filename, "rb") as f:
+        n = int.from_bytes(f.read(8), "little")
+        hdr = json.loads(f.read(n))
+    meta = hdr.pop("__metadata__", None) or {}
+    layout = {}
+    for name, e in hdr.items():
+        dt = _ST_DTYPES.get(e["dtype"])
+        if dt is None:
+            return None
+        layout[name] = (dt, tuple(e["shape"]), int(e["data_offsets"][0]), int(e["data_offsets"][1]))
+    return meta, layout, 8 + n
+
+
+def load_file(filename, device="cuda:0", timings=None):
+    """Load a (possibly ZipNN-compressed) safetensors file straight onto `device`: the file's data section crosses PCIe ONCE, as it
+    lies on disk (compressed tensors compressed), through the library's pinned multi-threaded transfer; every compressed tensor is
+    then decoded by ONE batched launch (zn_decompress_batch_dev) from where its frame landed in HBM, so a file of many small tensors
+    moves at the PCIe rate and decodes at the rate of one large tensor.  -> {name: tensor}.  The batched counterpart of looping
+    SafeOpen.get_tensor (reference zipnn.py:1592-1626, scripts/zipnn_decompress_safetensors.py:75-120).
+    timings: an optional dict that receives the seconds spent mapping the file and parsing its header (`read_s`), moving the data
+    section to the device (`h2d_s`) and decoding (`decode_s`), each ended by a device sync."""
+    import mmap
+    import time
     from . import _capi, codec
     dev = torch.device(device)
+    lay = _read_layout(filename)
+    if lay is None:
+        return _load_file_per_tensor(filename, dev, timings)
+    lib = _capi.lib()
+    t0 = time.perf_counter()
+    metadata, layout, data_start = lay
+    infos = get_compressed_tensors_metadata(dict(metadata))
     out, items, meta = {}, [], []
+    with open(filename, "rb") as f:
+        size = os.fstat(f.fileno()).st_size
+        mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
+    t1 = time.perf_counter()
+    try:
+        blob = codec.to_device(lib, memoryview(mm)[data_start:], dev) if (mm is not None and size > data_start) else torch.empty(0, dtype=torch.uint8, device=dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        head_len = 32 + 1 + 9 * 8                     # header + the shape extension of up to 8 dimensions (zipnn._frame_head)
+        for name, (dt, shape, lo, hi) in layout.items():
+            if name not in infos:
+                piece = blob[lo:hi]
+                es = torch.empty(0, dtype=dt).element_size()
+                if (piece.data_ptr() % es) != 0:      # (a view needs the element alignment the file did not give this tensor)
+                    piece = piece.clone()
+                out[name] = piece.view(dt).reshape(shape) if hi > lo else torch.empty(shape, dtype=dt, device=dev)
+                continue
+            # the frame header is parsed from the HOST mapping (no device read-back per tensor); the body stays where it landed
+            znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
+            fp = znn.frame_params(memoryview(mm)[data_start + lo: data_start + min(hi, lo + head_len + 9 * 255)])
+            items.append((blob[lo + fp["body_off"]:hi], fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"]))
+            meta.append((name, fp["torch_dtype"], fp["shape"]))
+    finally:
+        if mm is not None:
+            mm.close()
+    flats = codec.decompress_device_batch(lib, items)
+    for (name, dtype, shape), flat in zip(meta, flats):
+        out[name] = flat.view(dtype).reshape(shape) if flat.numel() else torch.empty(shape, dtype=dtype, device=dev)
+    if timings is not None:
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        timings.update(read_s=t1 - t0, h2d_s=t2 - t1, decode_s=t3 - t2, compressed_tensors=len(items), h2d_bytes=int(blob.numel()),
+                       compressed_bytes=int(sum(it[0].numel() for it in items)), decoded_bytes=int(sum(it[5] for it in items)))
+    return out
+
+
+def _load_file_per_tensor(filename, dev, timings=None):
+    """load_file through safetensors' own reader, tensor by tensor (CPU targets, dtypes the container parser above does not know)."""
+    import time
+    from safetensors import safe_open
+    from . import _capi, codec
+
+    def _sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    out, host, meta = {}, [], []
     with safe_open(filename, "pt", "cpu") as f:
         infos = get_compressed_tensors_metadata(dict(f.metadata() or {}))
         for name in f.keys():
-            t = f.get_tensor(name)
-            if name not in infos:
-                out[name] = t.to(dev, non_blocking=True)
-                continue
-            znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
-            fp = znn.frame_params(t)
-            host_body = t.reshape(-1).view(torch.uint8)[fp["body_off"]:]
-            # (large bodies through the library's pinned multi-threaded transfer; small ones are not worth its threads)
-            body = codec.to_device(_capi.lib(), host_body.numpy(), dev) if host_body.numel() >= (2 << 20) and dev.type == "cuda" \
-                else host_body.to(dev, non_blocking=True)
-            items.append((body, fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"]))
-            meta.append((name, fp["torch_dtype"], fp["shape"]))
+            host.append((name, f.get_tensor(name)))
+    t1 = time.perf_counter()
+    items = []
+    for name, t in host:
+        if name not in infos:
+            out[name] = t.to(dev, non_blocking=True)
+            continue
+        znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
+        fp = znn.frame_params(t)
+        host_body = t.reshape(-1).view(torch.uint8)[fp["body_off"]:]
+        # (large bodies through the library's pinned multi-threaded transfer; small ones are not worth its threads)
+        body = codec.to_device(_capi.lib(), host_body.numpy(), dev) if host_body.numel() >= (2 << 20) and dev.type == "cuda" \
+            else host_body.to(dev, non_blocking=True)
+        items.append((body, fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"]))
+        meta.append((name, fp["torch_dtype"], fp["shape"]))
+    if timings is not None:
+        _sync()
+    t2 = time.perf_counter()
     flats = codec.decompress_device_batch(_capi.lib(), items)
     for (name, dtype, shape), flat in zip(meta, flats):
         out[name] = flat.view(dtype).reshape(shape) if flat.numel() else torch.empty(shape, dtype=dtype, device=dev)
+    if timings is not None:
+        _sync()
+        t3 = time.perf_counter()
+        timings.update(read_s=t1 - t0, h2d_s=t2 - t1, decode_s=t3 - t2, compressed_tensors=len(items),
+                       compressed_bytes=int(sum(it[0].numel() for it in items)), decoded_bytes=int(sum(it[5] for it in items)))
     return out
