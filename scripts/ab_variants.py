@@ -71,6 +71,10 @@ VARIANTS = {
     "r02": ("8959d1d", []),                         # the kernels of the round-2 final state
     "d33": (None, ["-DZN_F_DELTA0=33"]),
     "nmis1": (None, ["-DZN_F_NMIS=1"]),
+    "d44": (None, ["-DZN_F_DELTA0=44"]),
+    "d44c": (None, ["-DZN_F_DELTA0=44", "-DZN_F_DELTA_MAX=44"]),
+    "d33c": (None, ["-DZN_F_DELTA0=33", "-DZN_F_DELTA_MAX=44"]),
+    "d22c": (None, ["-DZN_F_DELTA_MAX=44"]),
     "nmis2": (None, ["-DZN_F_NMIS=2"]),
 }
 
@@ -109,7 +113,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "c1", "prev", "new", "notile0", "d33", "nmis1", "nmis2", "d33noah")
+ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2")
 
 
 def run(names):

@@ -135,10 +135,15 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
 #define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
 #endif
 #ifndef ZN_F_DELTA0
-#define ZN_F_DELTA0 22                   // initial sync run-in (bits): 22 / 33 / 44 = two / three / four whole groups ahead of the boundary step
+#define ZN_F_DELTA0 44                   // initial sync run-in (bits): 22 / 33 / 44 = two / three / four whole groups ahead of the boundary step.  Measured
+                                         // (profiles/r03_decode_experiments.txt): 44 from the start is neutral on bf16 / fp32 (fewer fix-ups pay for the two
+                                         // extra look-ups) and 2 % faster on the dense codes (fp16, fp8), whose streams end up there anyway
 #endif
 #ifndef ZN_F_DELTA_FAST
 #define ZN_F_DELTA_FAST 44               // longest run-in the unrolled sync handles (beyond it: the looping form)
+#endif
+#ifndef ZN_F_DELTA_MAX
+#define ZN_F_DELTA_MAX 1024              // the run-in never grows beyond this (and never beyond a sub-block)
 #endif
 #ifndef ZN_F_NMIS
 #define ZN_F_NMIS 3                      // tiles of a stream that needed a fix-up before its run-in is lengthened
@@ -485,7 +490,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   // a longer run-in for the rest of the stream once mismatches keep coming (the third tile that needs a fix-up): beyond
   // 22 bits the run-in takes the looping form, which costs every later tile of the stream several steps
   // (22 → 33 → 44 bits stay on the fast path above: one more group each; beyond that the run-in doubles and takes the looping form)
-  auto note_mismatch = [&]() { if (++nmis >= ZN_F_NMIS) { nmis = 0; delta = (delta < 22) ? 22 : (delta < ZN_F_DELTA_FAST) ? delta + 11 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; } };
+  auto note_mismatch = [&]() { if (++nmis >= ZN_F_NMIS) { nmis = 0; delta = (delta < 22) ? 22 : (delta < ZN_F_DELTA_FAST) ? delta + 11 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; if (delta > ZN_F_DELTA_MAX) delta = ZN_F_DELTA_MAX; } };
   // the incomplete last row (< UNIT symbols, at staging row `total_rows`) moves to the start of the staging buffer
   auto keep_remainder = [&](uint32_t total_rows) {
     const uint32_t i = (total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
