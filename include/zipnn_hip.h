@@ -186,6 +186,12 @@ int zn_copy_to_host(void* dst, const void* d_src, size_t n);
  * to fill every workgroup slot of the device with groups, fewer for small tensors).  Process-wide.  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_group(int chunks_per_workgroup);
 
+/* Tuning knob of the host-buffer entry points (zn_compress / zn_decompress): slices of the three-stage pipeline
+ * upload | code | download that large pageable buffers can go through (both PCIe directions busy at once).  0 (default) = automatic
+ * (compress: 4-8 slices from 192 MiB up; decompress: one shot — measured: no gain there), 1 = never, 2..64 = that many, both
+ * directions.  Process-wide.  Returns 0 or ZN_E_ARG. */
+int zn_set_host_slices(int slices);
+
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);
 

@@ -11,7 +11,9 @@ hdr = bytes(32)
 frame = lib.compress(hdr, x, 2, 1, 10, 262144, 0.95)
 back = lib.decompress(memoryview(frame)[32:], 2, 1, 10, 262144, n)
 assert bytes(back[:4096]) == x[:4096].tobytes() and len(back) == n
-for name, fn in (("compress", lambda: lib.compress(hdr, x, 2, 1, 10, 262144, 0.95)), ("decompress", lambda: lib.decompress(memoryview(frame)[32:], 2, 1, 10, 262144, n))):
+for slices, name, fn in [(sl, nm, f) for sl in (1, 0, 4, 8, 16) for nm, f in (("compress", lambda: lib.compress(hdr, x, 2, 1, 10, 262144, 0.95)), ("decompress", lambda: lib.decompress(memoryview(frame)[32:], 2, 1, 10, 262144, n)))]:
+    lib.set_host_slices(slices)
+    name = f"{name} [{'one shot' if slices == 1 else 'pipelined, automatic slices' if slices == 0 else f'pipelined, {slices} slices'}]"
     best = best_free = 1e9
     for _ in range(3):
         t0 = time.perf_counter(); r = fn(); t1 = time.perf_counter()      # the call, result kept alive
@@ -20,6 +22,7 @@ for name, fn in (("compress", lambda: lib.compress(hdr, x, 2, 1, 10, 262144, 0.9
     print(f"host-buffer {name}: 1 GiB bf16 in {best * 1e3:.1f} ms = {n / best / 1e9:.1f} GB/s (pageable host memory, PCIe both ways; "
           f"{best_free * 1e3:.1f} ms with the result buffer freed again)")
 
+lib.set_host_slices(0)
 # streaming `.znn` blob (1 MiB frames): batched compress and decompress, best of 3 (the first call of a process also
 # pays for the pinned bounce buffers and the allocator's first 256 MiB blocks)
 from zipnn_amd import ZipNN

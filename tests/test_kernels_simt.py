@@ -573,3 +573,34 @@ def test_multi_device_entries_with_the_tensor_resident_per_device(simt_lib, kind
     assert bytes(got) == ref
     with pytest.raises(ValueError):                          # a non-empty range without a destination
         simt_lib.decompress_multi_dev(ref[32:], P, rot, bm, chunk, n, devices, [0] * G)
+
+
+@pytest.fixture()
+def host_slices():
+    """Force the host path's pipeline slices (zn_set_host_slices) for one test; automatic again afterwards."""
+    used = []
+
+    def set_(lib, s):
+        lib.set_host_slices(s)
+        used.append(lib)
+    yield set_
+    for lib in used:
+        lib.set_host_slices(0)
+
+
+@pytest.mark.parametrize("kind,P,rot,bm,chunk,n", [("bf16", 2, 1, 10, C, 7 * C + 1234), ("fp32", 4, 1, 220, C, 5 * C + 4 * 77), ("fp8", 1, 1, 10, C // 2, 9 * (C // 2) + 5),
+                                                    ("bf16", 2, 1, 10, C, 2 * C), ("rand", 2, 1, 10, C, 6 * C + 1), ("const", 2, 1, 10, C, 4 * C)],
+                         ids=["bf16-7.x", "fp32-5.x", "fp8-9.x", "bf16-2-chunks", "incompressible", "rle"])
+@pytest.mark.parametrize("slices", [2, 3, 5, 64])
+def test_host_entry_points_pipelined_over_slices(simt_lib, host_slices, kind, P, rot, bm, chunk, n, slices):
+    """zn_compress / zn_decompress with the three-stage pipeline (upload | code | download over slices of the chunks) forced on
+    small inputs: the frame is the oracle's byte for byte — the slices' plane-0 payload placed as the slices finish, the later
+    planes at the end, cumSizes re-based — and any frame decodes back, slice by slice, into the caller's buffer."""
+    host_slices(simt_lib, slices)
+    d = gen_bytes(kind, n, 51)
+    ref = O.compress_frame(HDR, d, P, rot, bm, chunk)
+    got = simt_lib.compress(HDR, d, P, rot, bm, chunk, 0.95)
+    assert bytes(got) == ref
+    assert bytes(simt_lib.decompress(ref[32:], P, rot, bm, chunk, len(d))) == d
+    with pytest.raises(RuntimeError):                              # a truncated body is refused before any slice is uploaded
+        simt_lib.decompress(ref[32:len(ref) - 50], P, rot, bm, chunk, len(d))

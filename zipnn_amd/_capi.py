@@ -77,6 +77,8 @@ class ZnLib:
         L.zn_decompress_range_dev.argtypes = [vp, sz, ci, ci, ci, sz, sz, sz, sz, ci, vp]
         L.zn_merge_range_bodies.restype = ci
         L.zn_merge_range_bodies.argtypes = [vpp, ctypes.POINTER(sz), ctypes.POINTER(sz), ci, ci, vp, sz, ctypes.POINTER(sz)]
+        L.zn_set_host_slices.restype = ci
+        L.zn_set_host_slices.argtypes = [ci]
         L.zn_set_decode_group.restype = ci
         L.zn_set_decode_group.argtypes = [ci]
         L.zn_compress_dev.restype = ci
@@ -249,6 +251,10 @@ class ZnLib:
         out_len = ctypes.c_size_t(0)
         self._check(self._L.zn_merge_range_bodies(ptrs, lens, ks, n, num_buf, out.ctypes.data, cap, ctypes.byref(out_len)))
         return memoryview(out)[:out_len.value]
+
+    def set_host_slices(self, slices):
+        """Tuning knob (zn_set_host_slices): slices of the pipelined host path; 0 = automatic, 1 = one shot."""
+        self._check(self._L.zn_set_host_slices(int(slices)))
 
     def set_decode_group(self, chunks_per_workgroup):
         """Tuning knob (zn_set_decode_group): chunks per workgroup of the fused decoder, 1..4; 0 = automatic."""

@@ -7,6 +7,8 @@
 #include "zn_host_pipe.hpp"
 
 #include <mutex>
+#include <atomic>
+#include <condition_variable>
 #include <thread>
 #include <chrono>
 #include <string>
@@ -40,6 +42,8 @@ struct Workspace {
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
+  ZnHostPipe pipe2;              // a second one: the pipelined host path downloads slice i - 1 while it uploads slice i + 1
+  hipStream_t cstream = nullptr; // … and codes slice i on a stream of its own
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
 static_assert(WS_COUNT == 12, "Workspace::buf size");
@@ -388,6 +392,14 @@ int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stre
   } catch (...) { return ZN_E_ALLOC; }
 }
 
+// Large host buffers take a three-stage pipeline over slices of the chunks — upload slice i + 1 | code slice i | download slice i - 1 —
+// so that both directions of the PCIe link work at once (defined below, behind the range helpers).  0 = not applicable: the one-shot path.
+static int zn_host_slices(size_t n, size_t chunk, bool decompress);
+static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                                      size_t chunk, float threshold, int dev, int S, void* dst, size_t dst_cap, size_t* dst_len);
+static int zn_decompress_host_pipelined(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                                        size_t orig_size, int dev, int S, void* dst);
+
 int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const void* delta, size_t n, int num_buf, int bits_mode,
                       int bytes_mode, size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
   if (!dst_len || (hdr_len && !hdr) || (n && !src) || !dst) return ZN_E_ARG;
@@ -395,6 +407,16 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
   DeviceScope scope(device);              // (restored on every return path)
   if (!scope.ok) { t_hip_err = "hipSetDevice"; return ZN_E_HIP; }
   const size_t bound = zn_compress_bound(n, num_buf, chunk, 0);
+  if (!delta && (num_buf == 1 || num_buf == 2 || num_buf == 4) && chunk) {
+    const int S = zn_host_slices(n, chunk, false);
+    if (S >= 2) {
+      int dev_ = 0;
+      ZN_HIP(hipGetDevice(&dev_));
+      if (dev_ < 0 || dev_ >= 64) return ZN_E_ARG;
+      try { return zn_compress_host_pipelined(hdr, hdr_len, src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, dev_, S, dst, dst_cap, dst_len); }
+      catch (...) { return ZN_E_ALLOC; }
+    }
+  }
   // device staging for host buffers: cached with the workspace (grow-only), one host-path call at a time per device
   int dev = 0;
   ZN_HIP(hipGetDevice(&dev));
@@ -441,6 +463,13 @@ int zn_decompress_delta(const void* body, size_t body_len, const void* delta, in
   int dev = 0;
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  if (!delta && (num_buf == 1 || num_buf == 2 || num_buf == 4) && chunk) {
+    const int S = zn_host_slices(orig_size, chunk, true);
+    if (S >= 2) {
+      try { return zn_decompress_host_pipelined(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dev, S, dst); }
+      catch (...) { return ZN_E_ALLOC; }
+    }
+  }
   std::lock_guard<std::mutex> hk(g_host_mu[dev]);
   void* d_body = nullptr; void* d_dst = nullptr; void* d_delta = nullptr;
   {
@@ -694,6 +723,247 @@ int zn_compress_ranges(const void* hdr, size_t hdr_len, size_t n, int num_buf, i
 }  // namespace
 }  // extern "C++"
 
+// ---- the host-buffer entry points on ONE device, pipelined over slices of the chunks -------------------------------------------
+// zn_compress / zn_decompress hand over pageable host buffers: one shot = upload everything, code, download everything, each PCIe
+// direction idle while the other works (1 GiB bf16: ≈ 30 GB/s each way).  Here the chunks are cut into S contiguous slices and
+// three host threads run upload(i + 1) ‖ code(i) ‖ download(i - 1): two pinned pipes, the kernels on a stream of their own.
+// Decompress: slice i's sub-body is put together in HBM as in zn_decode_range.  Compress: a slice's plane-0 payload goes to its
+// place in the frame as soon as the slice is coded (its offset needs only the slices before it); the later planes follow when
+// the last slice is done (plane p starts behind ALL of plane p - 1).  Same bytes as the one-shot path, slice by slice.
+namespace {
+std::atomic<int> g_host_slices{0};               // zn_set_host_slices: 0 automatic, 1 never, 2..64 that many
+struct ZnGate {                                   // "stage X has finished n items" between two pipeline threads
+  std::mutex m; std::condition_variable cv; size_t done = 0; bool fail = false;
+  void publish(size_t n) { { std::lock_guard<std::mutex> lk(m); done = n; } cv.notify_all(); }
+  void abort() { { std::lock_guard<std::mutex> lk(m); fail = true; } cv.notify_all(); }
+  bool wait_for(size_t n) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done >= n || fail; }); return !fail; }
+};
+int zn_pipeline_streams(Workspace& w) {
+  if (!w.cstream) ZN_HIP(hipStreamCreateWithFlags(&w.cstream, hipStreamNonBlocking));
+  return ZN_OK;
+}
+}  // namespace
+
+// Measured (1 GiB bf16, MI355X box, profiles/r03_host_buffer_path.txt): the transfers are bound by the host-side staging copies
+// (pageable <-> pinned: 48-54 GB/s per direction with 8 threads, more threads do not help), and the two directions disturb each
+// other when they run at once: compress 36.9 -> 32.1 ms pipelined (4 slices), decompress 35.2 -> 35.5-38.7 ms.  So the automatic
+// choice pipelines compress only; zn_set_host_slices forces either.
+static int zn_host_slices(size_t n, size_t chunk, bool decompress) {
+  const size_t K = chunk ? (n + chunk - 1) / chunk : 0;
+  const int forced = g_host_slices.load(std::memory_order_relaxed);
+  size_t S;
+  if (forced == 1) return 0;
+  if (forced >= 2) S = (size_t)forced;
+  else if (decompress) return 0;
+  else { if (n < ((size_t)192 << 20)) return 0; S = n / ((size_t)256 << 20); if (S < 4) S = 4; if (S > 8) S = 8; }   // four to eight slices
+  if (S > K) S = K;
+  return S >= 2 ? (int)S : 0;
+}
+int zn_set_host_slices(int slices) {
+  if (slices < 0 || slices > 64) return ZN_E_ARG;
+  g_host_slices.store(slices, std::memory_order_relaxed);
+  return ZN_OK;
+}
+
+static int zn_decompress_host_pipelined(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
+                                        size_t orig_size, int dev, int S, void* dst) {
+  ZnBodyView v;
+  int rc = zn_body_view(body, body_len, num_buf, chunk, orig_size, &v);
+  if (rc) return rc;
+  const size_t P = v.P, K = v.K;
+  std::lock_guard<std::mutex> hk(g_host_mu[dev]);
+  std::vector<ZnRange> rg((size_t)S); std::vector<size_t> need((size_t)S), in_off((size_t)S);
+  size_t in_total = 0;
+  for (int i = 0; i < S; i++) { rg[(size_t)i] = zn_range_of(K, i, S); need[(size_t)i] = zn_sub_need(v, rg[(size_t)i]); in_off[(size_t)i] = in_total; in_total += (need[(size_t)i] + 16 + 255) & ~(size_t)255; }
+  uint8_t* d_in = nullptr; uint8_t* d_out = nullptr; hipStream_t cs = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+    Workspace& w = g_ws[dev];
+    if ((rc = ws_reserve(w, WS_HOST_IN, in_total + 16))) return rc;
+    if ((rc = ws_reserve(w, WS_HOST_OUT, orig_size))) return rc;
+    if ((rc = zn_pipeline_streams(w))) return rc;
+    d_in = (uint8_t*)w.buf[WS_HOST_IN]; d_out = (uint8_t*)w.buf[WS_HOST_OUT]; cs = w.cstream;
+  }
+  ZnGate up, dec;
+  int rc_up = ZN_OK, rc_down = ZN_OK, rc_dec = ZN_OK;
+  {
+    ZnWorkers wk;
+    wk.start([&]() {                                // upload: re-based size tables + the P payload slices of every slice
+      try {
+        if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
+        ZnHostPipe& pipe = g_ws[dev].pipe;
+        for (int i = 0; i < S; i++) {
+          const ZnRange r = rg[(size_t)i]; const size_t k = r.hi - r.lo;
+          std::vector<uint8_t> meta(9 * P * k);
+          std::vector<uint64_t> s0(P);
+          for (size_t p = 0; p < P; p++) {
+            s0[p] = zn_cum_before(v, p, r.lo);
+            memcpy(meta.data() + p * k, v.types + p * K + r.lo, k);
+            for (size_t j = 0; j < k; j++) { const uint64_t c = zn_rd64(v.cums + 8 * (p * K + r.lo + j)) - s0[p]; memcpy(meta.data() + P * k + 8 * (p * k + j), &c, 8); }
+          }
+          uint8_t* d = d_in + in_off[(size_t)i];
+          bool ok = zn_host_pipe_copy(pipe, d, meta.data(), meta.size(), true) == hipSuccess;
+          size_t at = meta.size();
+          for (size_t p = 0; ok && p < P; p++) {
+            const size_t m = (size_t)(zn_cum_before(v, p, r.hi) - s0[p]);
+            if (m) ok = zn_host_pipe_copy(pipe, d + at, const_cast<uint8_t*>(v.pay + v.base[p] + s0[p]), m, true) == hipSuccess;
+            at += m;
+          }
+          if (!ok || dec.fail) { if (!ok) { (void)hipGetLastError(); rc_up = ZN_E_HIP; } up.abort(); return; }
+          up.publish((size_t)i + 1);
+        }
+      } catch (...) { rc_up = ZN_E_ALLOC; up.abort(); }
+    });
+    wk.start([&]() {                                // download: slice i's bytes as soon as they are decoded
+      try {
+        if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
+        ZnHostPipe& pipe = g_ws[dev].pipe2;
+        for (int i = 0; i < S; i++) {
+          if (!dec.wait_for((size_t)i + 1)) return;
+          const ZnRange r = rg[(size_t)i];
+          const size_t off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
+          if (len && zn_host_pipe_copy(pipe, d_out + off, (uint8_t*)dst + off, len, false) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
+        }
+      } catch (...) { rc_down = ZN_E_ALLOC; }
+    });
+    if (wk.failed) { up.abort(); dec.abort(); wk.join(); return ZN_E_ALLOC; }
+    for (int i = 0; i < S; i++) {                   // decode, on this thread
+      if (!up.wait_for((size_t)i + 1)) { rc_dec = rc_up ? rc_up : ZN_E_HIP; break; }
+      const ZnRange r = rg[(size_t)i];
+      const size_t off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
+      rc_dec = zn_decompress_dev(d_in + in_off[(size_t)i], need[(size_t)i], num_buf, bits_mode, bytes_mode, chunk, len, d_out + off, cs, 1);
+      if (rc_dec) break;
+      dec.publish((size_t)i + 1);
+    }
+    if (rc_dec) { dec.abort(); up.abort(); }
+    wk.join();
+  }
+  return rc_dec ? rc_dec : rc_up ? rc_up : rc_down;
+}
+
+static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
+                                      size_t chunk, float threshold, int dev, int S, void* dst, size_t dst_cap, size_t* dst_len) {
+  const size_t P = (size_t)num_buf, K = (n + chunk - 1) / chunk;
+  if (hdr_len + 9 * P * K > dst_cap) return ZN_E_CAP;
+  std::lock_guard<std::mutex> hk(g_host_mu[dev]);
+  std::vector<ZnRange> rg((size_t)S); std::vector<size_t> boff((size_t)S), bcap((size_t)S), blen((size_t)S, 0);
+  size_t b_total = 0;
+  for (int i = 0; i < S; i++) {
+    rg[(size_t)i] = zn_range_of(K, i, S);
+    const size_t off = rg[(size_t)i].lo * chunk, len = (rg[(size_t)i].hi * chunk < n ? rg[(size_t)i].hi * chunk : n) - off;
+    bcap[(size_t)i] = zn_compress_bound(len, num_buf, chunk, 0) + 16; boff[(size_t)i] = b_total; b_total += (bcap[(size_t)i] + 255) & ~(size_t)255;
+  }
+  uint8_t* d_src = nullptr; uint8_t* d_body = nullptr; hipStream_t cs = nullptr;
+  int rc;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+    Workspace& w = g_ws[dev];
+    if ((rc = ws_reserve(w, WS_HOST_IN, n))) return rc;
+    if ((rc = ws_reserve(w, WS_HOST_OUT, b_total + 16))) return rc;
+    if ((rc = zn_pipeline_streams(w))) return rc;
+    d_src = (uint8_t*)w.buf[WS_HOST_IN]; d_body = (uint8_t*)w.buf[WS_HOST_OUT]; cs = w.cstream;
+  }
+  uint8_t* o = (uint8_t*)dst;
+  uint8_t* types = o + hdr_len; uint8_t* cums = types + P * K; uint8_t* pay = cums + 8 * P * K;
+  const size_t pay_cap = dst_cap - hdr_len - 9 * P * K;
+  struct Job { const uint8_t* d; uint8_t* h; size_t len; };
+  std::vector<Job> jobs; jobs.reserve((size_t)S + P);                 // (appended by this thread only, read by the downloader up to `queued.done`)
+  ZnGate up, queued; bool all_queued = false;
+  int rc_up = ZN_OK, rc_down = ZN_OK, rc_enc = ZN_OK;
+  std::vector<std::vector<uint8_t>> metas((size_t)S);
+  {
+    ZnWorkers wk;
+    wk.start([&]() {                                // upload the tensor slice by slice
+      try {
+        if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
+        for (int i = 0; i < S; i++) {
+          const size_t off = rg[(size_t)i].lo * chunk, len = (rg[(size_t)i].hi * chunk < n ? rg[(size_t)i].hi * chunk : n) - off;
+          if (len && zn_host_pipe_copy(g_ws[dev].pipe, d_src + off, const_cast<uint8_t*>((const uint8_t*)src + off), len, true) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
+          if (queued.fail) { up.abort(); return; }
+          up.publish((size_t)i + 1);
+        }
+      } catch (...) { rc_up = ZN_E_ALLOC; up.abort(); }
+    });
+    wk.start([&]() {                                // download the payload pieces in the order they are queued
+      try {
+        if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
+        size_t next = 0;
+        for (;;) {
+          size_t have; bool fin;
+          { std::unique_lock<std::mutex> lk(queued.m); queued.cv.wait(lk, [&] { return queued.done > next || queued.fail || all_queued; }); have = queued.done; fin = all_queued; if (queued.fail) return; }
+          for (; next < have; next++) {
+            const Job j = jobs[next];
+            if (j.len && zn_host_pipe_copy(g_ws[dev].pipe2, const_cast<uint8_t*>(j.d), j.h, j.len, false) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
+          }
+          if (fin && next >= have) { std::lock_guard<std::mutex> lk(queued.m); if (queued.done == next) return; }
+        }
+      } catch (...) { rc_down = ZN_E_ALLOC; }
+    });
+    if (wk.failed) { up.abort(); queued.abort(); wk.join(); return ZN_E_ALLOC; }
+    std::vector<uint64_t> tot((size_t)S * P, 0);
+    size_t pay0_at = 0;
+    for (int i = 0; i < S && !rc_enc; i++) {        // code slice i; its plane 0 can leave at once
+      if (!up.wait_for((size_t)i + 1)) { rc_enc = rc_up ? rc_up : ZN_E_HIP; break; }
+      const ZnRange r = rg[(size_t)i]; const size_t k = r.hi - r.lo;
+      const size_t off = r.lo * chunk, len = (r.hi * chunk < n ? r.hi * chunk : n) - off;
+      uint8_t* b = d_body + boff[(size_t)i];
+      rc_enc = zn_compress_dev(d_src + off, len, num_buf, bits_mode, bytes_mode, chunk, threshold, b, bcap[(size_t)i], &blen[(size_t)i], cs);
+      if (rc_enc) break;
+      metas[(size_t)i].resize(9 * P * k);
+      if (hipMemcpyAsync(metas[(size_t)i].data(), b, 9 * P * k, hipMemcpyDeviceToHost, cs) != hipSuccess || hipStreamSynchronize(cs) != hipSuccess) { (void)hipGetLastError(); rc_enc = ZN_E_HIP; break; }
+      for (size_t p = 0; p < P; p++) tot[(size_t)i * P + p] = zn_rd64(metas[(size_t)i].data() + P * k + 8 * (p * k + k - 1));
+      const size_t t0 = (size_t)tot[(size_t)i * P];
+      if (pay0_at + t0 > pay_cap) { rc_enc = ZN_E_CAP; break; }
+      jobs.push_back(Job{b + 9 * P * k, pay + pay0_at, t0});
+      pay0_at += t0;
+      queued.publish(jobs.size());
+    }
+    size_t total = 0;
+    if (!rc_enc) {                                  // every slice is coded: the later planes have their places now
+      std::vector<size_t> base(P, 0); size_t acc = 0;
+      for (size_t p = 0; p < P; p++) { base[p] = acc; for (int i = 0; i < S; i++) acc += (size_t)tot[(size_t)i * P + p]; }
+      if (acc > pay_cap) rc_enc = ZN_E_CAP;
+      else {
+        // planes 1.. are contiguous in the frame across the slices: their pieces are gathered on the device (into the input staging,
+        // which nothing reads any more) and leave as ONE transfer per plane instead of S small ones
+        size_t g_at = 0;
+        for (size_t p = 1; p < P && !rc_enc; p++) {
+          const size_t g0 = g_at;
+          for (int i = 0; i < S; i++) {
+            const size_t k = rg[(size_t)i].hi - rg[(size_t)i].lo;
+            size_t before = 0; for (size_t q = 0; q < p; q++) before += (size_t)tot[(size_t)i * P + q];
+            const size_t m = (size_t)tot[(size_t)i * P + p];
+            if (m && hipMemcpyAsync(d_src + g_at, d_body + boff[(size_t)i] + 9 * P * k + before, m, hipMemcpyDeviceToDevice, cs) != hipSuccess) { (void)hipGetLastError(); rc_enc = ZN_E_HIP; break; }
+            g_at += m;
+          }
+          if (!rc_enc) jobs.push_back(Job{d_src + g0, pay + base[p], g_at - g0});
+        }
+        if (!rc_enc && hipStreamSynchronize(cs) != hipSuccess) { (void)hipGetLastError(); rc_enc = ZN_E_HIP; }
+        total = hdr_len + 9 * P * K + acc;
+      }
+    }
+    if (rc_enc) { queued.abort(); up.abort(); }
+    else { { std::lock_guard<std::mutex> lk(queued.m); queued.done = jobs.size(); all_queued = true; } queued.cv.notify_all(); }
+    if (!rc_enc) {                                  // the size tables, re-based, while the last pieces are on their way
+      if (hdr_len) memcpy(o, hdr, hdr_len);
+      std::vector<uint64_t> run(P, 0);
+      for (int i = 0; i < S; i++) {
+        const ZnRange r = rg[(size_t)i]; const size_t k = r.hi - r.lo;
+        const uint8_t* m = metas[(size_t)i].data();
+        for (size_t p = 0; p < P; p++) {
+          memcpy(types + p * K + r.lo, m + p * k, k);
+          for (size_t j = 0; j < k; j++) { const uint64_t c = zn_rd64(m + P * k + 8 * (p * k + j)) + run[p]; memcpy(cums + 8 * (p * K + r.lo + j), &c, 8); }
+          run[p] += tot[(size_t)i * P + p];
+        }
+      }
+      if (hdr_len >= 32) { const uint64_t t64 = total; memcpy(o + 24, &t64, 8); }   // zipnn_core.c:121
+    }
+    wk.join();
+    if (!rc_enc && !rc_down) *dst_len = total;
+  }
+  return rc_enc ? rc_enc : rc_up ? rc_up : rc_down;
+}
+
 int zn_compress_multi(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
                       size_t chunk, float threshold, const int* devices, int ndev, void* dst, size_t dst_cap, size_t* dst_len) {
   if (!dst_len || (hdr_len && !hdr) || (n && !src) || !dst || !devices || ndev <= 0 || ndev > 64 || !chunk) return ZN_E_ARG;
@@ -869,7 +1139,7 @@ int zn_release_workspace(void) {
     std::lock_guard<std::mutex> hk(g_host_mu[d]);
     std::lock_guard<std::mutex> lk(g_dev_mu[d]);
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr || w.pipe2.pin[0] != nullptr || w.cstream != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -878,6 +1148,8 @@ int zn_release_workspace(void) {
     if (w.h_totals) { (void)hipHostFree(w.h_totals); w.h_totals = nullptr; w.h_totals_cap = 0; }
     if (w.h_total) { (void)hipHostFree(w.h_total); w.h_total = nullptr; w.h_status = nullptr; }
     zn_host_pipe_release(w.pipe);
+    zn_host_pipe_release(w.pipe2);
+    if (w.cstream) { (void)hipStreamSynchronize(w.cstream); (void)hipStreamDestroy(w.cstream); w.cstream = nullptr; }
     if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
   }
   if (prev >= 0) (void)hipSetDevice(prev);

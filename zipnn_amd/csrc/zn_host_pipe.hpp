@@ -76,7 +76,9 @@ inline hipError_t zn_host_pipe_init(ZnHostPipe& p) {
     e = hipHostMalloc(&p.pin[i], slice, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&p.ev[i], hipEventDisableTiming);
   }
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, 0);     // blocking: ordered against the null stream
+  // (non-blocking: a transfer is complete when zn_host_pipe_copy returns — nothing relies on stream order against the null stream —
+  //  and the pipelined host path runs two of these next to a kernel stream: none of them may wait for the others)
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking);
   if (e != hipSuccess) { zn_host_pipe_release(p); (void)hipGetLastError(); return e; }   // all or nothing
   p.slice = slice;
   return hipSuccess;
@@ -86,8 +88,13 @@ inline hipError_t zn_host_pipe_init(ZnHostPipe& p) {
 inline hipError_t zn_host_pipe_copy(ZnHostPipe& p, void* d, void* h, size_t n, bool to_device) {
   using namespace zn_host_pipe_detail;
   if (n == 0) return hipSuccess;
-  if (n < (2u << 20)) return to_device ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
   hipError_t e = zn_host_pipe_init(p);
+  if (n < (2u << 20)) {                         // small: one plain copy, on this pipe's stream (a null-stream copy would wait for the other pipe's transfers)
+    if (e != hipSuccess) return to_device ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
+    e = to_device ? hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, p.stream) : hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, p.stream);
+    const hipError_t e2 = hipStreamSynchronize(p.stream);
+    return e != hipSuccess ? e : e2;
+  }
   if (e != hipSuccess)                          // no pinned memory to be had: the plain, slower way
     return to_device ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
   const size_t S = p.slice, slices = (n + S - 1) / S;
