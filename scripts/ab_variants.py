@@ -113,7 +113,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2")
+ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg")
 
 
 def run(names):
