@@ -453,7 +453,9 @@ def test_register_resident_form_decodes_weights_like_tensors(simt_lib, kind, P, 
         assert tiles > 20 and looping * 20 <= tiles and groups == 0
     else:
         assert tiles > 20 and looping == 0 and groups == 0    # every tile took the register-resident form
-    assert fixups > 0                                         # … and some of them needed a fix-up iteration (22-bit run-in)
+    if kind == "fp16":
+        assert fixups > 0                                     # … and some of them needed a fix-up iteration: fp16's top-byte code re-synchronises
+                                                              # slowly (0.2-0.3 fix-ups per tile at the 44-bit run-in; bf16 / fp32: a few in 1000 tiles)
 
 
 @pytest.mark.parametrize("kind", ["skew", "burst", "fp8w", "sparse", "onebit"])
