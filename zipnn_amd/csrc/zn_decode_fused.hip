@@ -140,7 +140,7 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
                                          // extra look-ups) and 2 % faster on the dense codes (fp16, fp8), whose streams end up there anyway
 #endif
 #ifndef ZN_F_DELTA_FAST
-#define ZN_F_DELTA_FAST 88               // longest run-in the unrolled sync handles (a multiple of 11; beyond it: the looping form)
+#define ZN_F_DELTA_FAST 44               // longest run-in the unrolled sync handles (beyond it: the looping form)
 #endif
 #ifndef ZN_F_DELTA_MAX
 #define ZN_F_DELTA_MAX 1024              // the run-in never grows beyond this (and never beyond a sub-block)
@@ -465,24 +465,17 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     ZnChain c;
     c.pos = (lane > 0 && active) ? hi_k + delta : hi_k; c.stop = hi_k; c.n = 0; c.wpos = 0;
     if (delta <= ZN_F_DELTA_FAST) {
-      // short run-in: G = 2 .. 8 whole groups (≤ TL bits each) and the boundary step (a TL-bit look-up), unrolled, a window refill
-      // (≥ 33 valid bits = three look-ups) in front of every third look-up.  22 bits synchronise all but ≈ 0.2 % of the sub-blocks of a
+      // short run-in: G = 2, 3 or 4 whole groups (≤ TL bits each) and the boundary step (a TL-bit look-up), all from at most two
+      // window refills (a refill holds ≥ 33 valid bits = three look-ups).  22 bits synchronise all but ≈ 0.2 % of the sub-blocks of a
       // bf16 exponent stream; a tile with one lane that did not is decoded twice (a fix-up re-runs the whole pass: 14+ steps), so a
       // stream whose tiles keep mismatching gets one more group per tile instead (note_mismatch)
       const uint32_t sh = 32u - TL;
-      const int G = (delta + 10) / 11;                               // whole groups, 2 .. 8 (wave-uniform)
+      const int G = delta <= 22 ? 2 : delta <= 33 ? 3 : 4;          // (wave-uniform)
       uint64_t w = zn_window(in, c.pos - 1 - base_bit);
       auto group = [&]() { uint2 e = lut[(uint32_t)(w >> 32) >> sh]; if (!(c.pos > c.stop + (int32_t)TL - 1)) { e.x = 0; e.y = 0; } w <<= (e.y & 63u); c.pos -= (int32_t)ZN_M_NB(e.y); };
       group(); group();
-      // (a refill feeds three look-ups: one in front of every third group that has a successor, the boundary step included)
-#pragma unroll
-      for (int i = 2; i < ZN_F_DELTA_FAST / 11; i++) {
-        if (i >= G) break;
-        ZN_NO_IFCVT;
-        if (i % 3 == 0) w = zn_window(in, c.pos - 1 - base_bit);
-        group();
-      }
-      if (G % 3 == 0) w = zn_window(in, c.pos - 1 - base_bit);
+      if (G >= 3) { ZN_NO_IFCVT; group(); w = zn_window(in, c.pos - 1 - base_bit); }
+      if (G >= 4) { ZN_NO_IFCVT; group(); }
       { uint2 e = lut[(uint32_t)(w >> 32) >> sh]; if (!(c.pos > c.stop)) { e.x = 0; e.y = 0; } c.pos -= (int32_t)ZN_M_NB(zn_trim_group(e, c.pos - c.stop).y); }
       while (__any(c.pos > c.stop)) {
         w = zn_window(in, c.pos - 1 - base_bit);
@@ -496,8 +489,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   };
   // a longer run-in for the rest of the stream once mismatches keep coming (the third tile that needs a fix-up): beyond
   // 22 bits the run-in takes the looping form, which costs every later tile of the stream several steps
-  // (22 → 33 → 44 → 66 → 88 bits stay on the unrolled path above; beyond that the run-in doubles and takes the looping form)
-  auto note_mismatch = [&]() { if (++nmis >= ZN_F_NMIS) { nmis = 0; delta = (delta < 22) ? 22 : (delta < 44) ? delta + 11 : (delta < ZN_F_DELTA_FAST) ? delta + 22 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; if (delta > ZN_F_DELTA_MAX) delta = ZN_F_DELTA_MAX; } };
+  // (22 → 33 → 44 bits stay on the fast path above: one more group each; beyond that the run-in doubles and takes the looping form)
+  auto note_mismatch = [&]() { if (++nmis >= ZN_F_NMIS) { nmis = 0; delta = (delta < 22) ? 22 : (delta < ZN_F_DELTA_FAST) ? delta + 11 : 2 * delta; if (delta > 32 * Di) delta = 32 * Di; if (delta > ZN_F_DELTA_MAX) delta = ZN_F_DELTA_MAX; } };
   // the incomplete last row (< UNIT symbols, at staging row `total_rows`) moves to the start of the staging buffer
   auto keep_remainder = [&](uint32_t total_rows) {
     const uint32_t i = (total_rows * UNIT + (uint32_t)EPL * lane) >> 2;
