@@ -661,6 +661,24 @@ def test_multi_device_entry_points_on_the_one_gpu_here(lib, devices):
     assert torch.cuda.current_device() == 0
 
 
+@pytest.mark.parametrize("slices", [1, 2, 5])
+def test_host_entry_points_one_shot_and_pipelined_on_hardware(lib, slices):
+    """zn_compress / zn_decompress with pageable host buffers, as one shot and through the three-stage pipeline over chunk slices
+    (two pinned pipes + a kernel stream of its own, real DMA in both directions at once): the oracle's frame, the input back —
+    every dtype, ragged sizes, 40+ MiB so that the pipes cut the transfers into several slices of their own."""
+    lib.set_host_slices(slices)
+    try:
+        for kind, nb, P, rot, bm, chunk, seed in (("bf16", 161 * C + 4098, 2, 1, 10, C, 3), ("fp32", 97 * C + 4 * 33, 4, 1, 220, C, 4),
+                                                  ("fp8", 211 * (C // 2) + 7, 1, 1, 10, C // 2, 5), ("fp16", 64 * C, 2, 0, 10, C, 6)):
+            d = gen_bytes(kind, nb, seed)
+            want = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=8)
+            assert bytes(lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == want, (kind, slices)
+            assert bytes(lib.decompress(want[32:], P, rot, bm, chunk, nb)) == d, (kind, slices)
+        assert torch.cuda.current_device() == 0
+    finally:
+        lib.set_host_slices(0)
+
+
 def _device_lists():
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0
     lists = [[0, 0], [0, 0, 0]]
