@@ -72,6 +72,14 @@ VARIANTS = {
     "d33": (None, ["-DZN_F_DELTA0=33"]),
     "nmis1": (None, ["-DZN_F_NMIS=1"]),
     "d44": (None, ["-DZN_F_DELTA0=44"]),
+    # compiler scheduling options (same sources)
+    "ilp": (None, ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    "iter": (None, ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
+    "maxocc": (None, ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
+    "nopost": (None, ["-mllvm", "-enable-post-misched=0"]),
+    "bias100": (None, ["-mllvm", "-amdgpu-schedule-metric-bias=100"]),
+    "bias0": (None, ["-mllvm", "-amdgpu-schedule-metric-bias=0"]),
+    "o2": (None, ["-O2"]),
     "d44c": (None, ["-DZN_F_DELTA0=44", "-DZN_F_DELTA_MAX=44"]),
     "d33c": (None, ["-DZN_F_DELTA0=33", "-DZN_F_DELTA_MAX=44"]),
     "d22c": (None, ["-DZN_F_DELTA_MAX=44"]),
@@ -113,7 +121,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg")
+ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2")
 
 
 def run(names):

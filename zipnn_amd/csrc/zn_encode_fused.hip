@@ -254,7 +254,6 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
   for (int k = 0; k < 4; k++) {
     cnt[k] = 0;
     for (int q = 0; q < 4; q++) { qv[q][k] = D->qcount[q][lane + 64u * (uint32_t)k]; cnt[k] += qv[q][k]; }
-    L.S.count[lane + 64u * (uint32_t)k] = cnt[k];   // (the weight coder reuses S.count later, after the sort)
     const uint64_t m = __ballot(cnt[k] != 0);
     if (m) max_sv = 64u * (uint32_t)k + 63u - (uint32_t)__builtin_clzll(m);
   }

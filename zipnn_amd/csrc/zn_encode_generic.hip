@@ -158,6 +158,9 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnESeg one, const 
   const uint8_t* __restrict__ planes = planes_all + SG.slot0 * slot; uint8_t* __restrict__ enc = enc_all + SG.slot0 * slot;
   uint32_t* __restrict__ csize_out = csize_all + SG.pc0; uint8_t* __restrict__ type_out = type_all + SG.pc0;
   __shared__ ZnTabScratch S;
+  __shared__ uint32_t S_count[256];
+  if (threadIdx.x == 0) S.count = ZN_LDS_PTR(uint32_t, S_count);
+  __syncthreads();
   __shared__ ZnHNode nodes[513];
   __shared__ uint32_t sh_hdr, sh_go, sh_bits[4];
   __shared__ uint32_t sh_buf[ZN_G_BUF_DW];
@@ -172,16 +175,16 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnESeg one, const 
   uint8_t* dst = enc + pcl * slot;
   const uint64_t cap = g.chunk;   // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
 
-  for (uint32_t i = lane; i < 256u; i += ZN_WAVE) S.count[i] = 0;
+  for (uint32_t i = lane; i < 256u; i += ZN_WAVE) S_count[i] = 0;
   __syncthreads();
   {
     const uint32_t nv = n / 16u;                       // (scratch planes start 16-byte aligned)
     for (uint32_t v = lane; v < nv; v += ZN_WAVE) {
       const uint4 x = *(const uint4*)(src + 16u * v);
       const uint32_t d[4] = {x.x, x.y, x.z, x.w};
-      for (int k = 0; k < 4; k++) for (int b = 0; b < 4; b++) atomicAdd(&S.count[(d[k] >> (8 * b)) & 0xFFu], 1u);
+      for (int k = 0; k < 4; k++) for (int b = 0; b < 4; b++) atomicAdd(&S_count[(d[k] >> (8 * b)) & 0xFFu], 1u);
     }
-    for (uint32_t i = 16u * nv + lane; i < n; i += ZN_WAVE) atomicAdd(&S.count[src[i]], 1u);
+    for (uint32_t i = 16u * nv + lane; i < n; i += ZN_WAVE) atomicAdd(&S_count[src[i]], 1u);
   }
   __syncthreads();
 
@@ -193,8 +196,8 @@ __global__ __launch_bounds__(ZN_WAVE) void zn_k_encode_planes(ZnESeg one, const 
     else if (n > ZN_HUF_BLOCK_MAX) cs = 0xFFFFFFB8u;   // (size_t)-72 "srcSize_wrong" → fails the threshold test → raw
     else {
       uint32_t max_sv = 255, largest = 0;
-      while (S.count[max_sv] == 0) max_sv--;
-      for (uint32_t i = 0; i <= max_sv; i++) if (S.count[i] > largest) largest = S.count[i];
+      while (S_count[max_sv] == 0) max_sv--;
+      for (uint32_t i = 0; i <= max_sv; i++) if (S_count[i] > largest) largest = S_count[i];
       if (largest == n) { dst[0] = src[0]; cs = 1; }
       else if (largest <= (n >> 7) + 4u) cs = 0;
       else {

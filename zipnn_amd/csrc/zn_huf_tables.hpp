@@ -16,7 +16,8 @@
 struct ZnHNode { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nb; };
 
 struct ZnTabScratch {
-  uint32_t count[256];       // byte histogram (encoder)
+  uint32_t* count;           // byte histogram, 256 entries, OWNED BY THE CALLER (the generic encoder's; the fused table kernel sorts from registers and has none:
+                             // 1 KB of LDS less per table job = 26 instead of 22 jobs resident per CU)
   uint8_t  weights[256];     // huff0 weights written into the tree description
   uint8_t  nbits[256];       // code length per symbol (encoder)
   uint16_t vals[256];        // code value per symbol (encoder)
