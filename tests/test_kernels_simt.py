@@ -606,3 +606,35 @@ def test_host_entry_points_pipelined_over_slices(simt_lib, host_slices, kind, P,
     assert bytes(simt_lib.decompress(ref[32:], P, rot, bm, chunk, len(d))) == d
     with pytest.raises(RuntimeError):                              # a truncated body is refused before any slice is uploaded
         simt_lib.decompress(ref[32:len(ref) - 50], P, rot, bm, chunk, len(d))
+
+
+def test_range_entry_points_reject_bad_arguments_and_damaged_tables(simt_lib):
+    """zn_decompress_range_dev / zn_decompress_multi_dev / zn_merge_range_bodies validate before they copy: chunk ranges outside the
+    tensor, size tables that decrease or point past the payload, parts shorter than their own tables or whose cumSizes disagree with
+    their length — errors, never an out-of-bounds copy on the host."""
+    d = gen_bytes("bf16", 6 * C + 100, 61)
+    body = O.compress_frame(b"", d, 2, 1, 10, C)
+    K = 7
+    out = torch.zeros(len(d), dtype=torch.uint8)
+    for lo, hi in ((3, 2), (0, K + 1), (K + 1, K + 2)):
+        with pytest.raises(ValueError):
+            simt_lib.decompress_range_dev(body, 2, 1, 10, C, len(d), lo, hi, 0, out.data_ptr())
+    simt_lib.decompress_range_dev(body, 2, 1, 10, C, len(d), 2, 2, 0, 0)                 # an empty range needs no destination
+    bad = bytearray(body); bad[2 * K + 8 * 3: 2 * K + 8 * 4] = (1 << 50).to_bytes(8, "little")
+    with pytest.raises(RuntimeError):
+        simt_lib.decompress_range_dev(bytes(bad), 2, 1, 10, C, len(d), 0, 3, 0, out.data_ptr())
+    with pytest.raises(RuntimeError):
+        simt_lib.decompress_multi_dev(bytes(bad), 2, 1, 10, C, len(d), [0, 1], [out.data_ptr(), out.data_ptr()])
+    with pytest.raises(RuntimeError):
+        simt_lib.decompress_range_dev(bytes(body[:40]), 2, 1, 10, C, len(d), 0, 3, 0, out.data_ptr())
+    from zipnn_amd import sharding
+    parts = sharding.split_body(body, 2, C, len(d), 2)
+    ks = [hi - lo for lo, hi in sharding.chunk_ranges(K, 2)]
+    good = [(parts[0][0], ks[0]), (parts[1][0], ks[1])]
+    assert bytes(simt_lib.merge_range_bodies(good, 2)) == body
+    with pytest.raises(ValueError):                                                       # a part shorter than its own size tables
+        simt_lib.merge_range_bodies([(parts[0][0][:10], ks[0]), good[1]], 2)
+    with pytest.raises(RuntimeError):                                                     # … or whose payload is not what its cumSizes say
+        simt_lib.merge_range_bodies([(parts[0][0][:-5], ks[0]), good[1]], 2)
+    with pytest.raises(ValueError):
+        simt_lib.merge_range_bodies(good, 3)
