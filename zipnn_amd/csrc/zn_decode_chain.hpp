@@ -96,10 +96,23 @@ __device__ __forceinline__ void zn_chain_apply(ZnChain& c, uint2 e, uint32_t* st
   if (MODE == 1) c.n += ZN_M_CNT(e.y);
   c.pos -= (int32_t)ZN_M_NB(e.y);
 }
+// U (wave-uniform): whole-group steps that NO lane of the wave can take too far — every lane that matters still owns at least
+// 11 U + 10 bits (a step consumes ≤ TL ≤ 11; the caller derives U from the sub-block size or the run-in length, 0 = none).  They run
+// without the per-step boundary test and its two selects: 4 instead of 9 vector instructions per step.  Lanes whose result the caller
+// discards (fix-up iterations re-run the pass for a few lanes only) may run past their boundary there; MODE 2 callers pass U > 0
+// only when every lane of the wave is writing.
 template <int MODE>
-__device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* in, int32_t base_bit, uint32_t TL, ZnChain& c, uint32_t* stage) {
+__device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* in, int32_t base_bit, uint32_t TL, ZnChain& c, uint32_t* stage, int U = 0) {
   const uint32_t sh = 32u - TL;
   const int32_t mb = c.stop + (int32_t)TL - 1;
+  for (int u = 0; u + 3 <= U; u += 3) {
+    uint64_t w = zn_window(in, c.pos - 1 - base_bit);
+    for (int s = 0; s < 3; s++) {
+      const uint2 e = lut[(uint32_t)(w >> 32) >> sh];
+      w <<= (e.y & 63u);
+      zn_chain_apply<MODE>(c, e, stage);
+    }
+  }
   while (__any(c.pos > mb)) {                // whole groups while the group provably starts above `stop`
     uint64_t w = zn_window(in, c.pos - 1 - base_bit);
     for (int s = 0; s < 3; s++) {

@@ -461,7 +461,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 
   // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it; returns the
   // position the lane's own decode starts from (lane 0: the true position carried over from the previous tile)
-  auto sync_run = [&](int32_t base_bit, int32_t hi_k, bool active) -> int32_t {
+  auto sync_run = [&](int32_t base_bit, int32_t hi_k, bool active, bool regular_tile) -> int32_t {
     ZnChain c;
     c.pos = (lane > 0 && active) ? hi_k + delta : hi_k; c.stop = hi_k; c.n = 0; c.wpos = 0;
     if (delta <= ZN_F_DELTA_FAST) {
@@ -483,7 +483,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         c.pos -= (int32_t)ZN_M_NB(zn_trim_group(e, c.pos - c.stop).y);
       }
     } else {
-      zn_fused_run<0>(lut, in, base_bit, TL, c, nullptr);
+      zn_fused_run<0>(lut, in, base_bit, TL, c, nullptr, regular_tile ? (delta - 21) / 11 : 0);
     }
     return (lane > 0) ? c.pos : carry;
   };
@@ -539,7 +539,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     if (TF > 0) {
       ZN_PRIO(ZN_F_PRIO_SYNC);
       if (DC) ZN_ASM_MARK("ZN_MARK sync");
-      int32_t s = sync_run(base_bit, hi_k, active);
+      int32_t s = sync_run(base_bit, hi_k, active, regular);
       ZN_PRIO(ZN_F_PRIO_COUNT);
       ZN_PT(5);   // sync run-in
       if (DC) ZN_ASM_MARK("ZN_MARK pass1");
@@ -626,13 +626,15 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       ZN_PT_COUNT(22, 1);                    // tiles that took the looping form
       ZN_DBG_COUNT(1);
       ZN_PRIO(ZN_F_PRIO_SYNC);
-      int32_t s = sync_run(base_bit, hi_k, active);
+      int32_t s = sync_run(base_bit, hi_k, active, regular);
       ZN_PRIO(ZN_F_PRIO_COUNT);
       ZnChain A; A.wpos = 0;
+      // (whole-group steps no lane of a regular tile can take too far: see zn_fused_run)
+      const int U_blk = regular ? (int)zn_uniform((uint32_t)((32 * Di - 31) / 11)) : 0;
       int32_t e = s; uint32_t n = 0; bool need = active, chained = false;
       for (int it = 0; it < 66; it++) {
         A.pos = need ? s : stop; A.stop = stop; A.n = 0;
-        zn_fused_run<1>(lut, in, base_bit, TL, A, nullptr);
+        zn_fused_run<1>(lut, in, base_bit, TL, A, nullptr, U_blk);
         if (need) { e = A.pos; n = A.n; }
         const int32_t e_prev = __shfl_up(e, 1u);
         const bool mism = active && lane > 0 && e_prev != s;
@@ -663,7 +665,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         ZN_PRIO(ZN_F_PRIO_WRITE);
         const bool mine = active && lane >= lane_lo && lane < lane_hi;
         A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
-        zn_fused_run<2>(lut, in, base_bit, TL, A, ring);
+        zn_fused_run<2>(lut, in, base_bit, TL, A, ring, (lane_lo == 0u && lane_hi >= 64u) ? U_blk : 0);
         __builtin_amdgcn_wave_barrier();
         ZN_PRIO(0);
         J += nsub; wdone = wend; lane_lo = lane_hi;
