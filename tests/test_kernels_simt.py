@@ -435,40 +435,43 @@ def _tile_counters(reset=True):
 
 
 @pytest.mark.parametrize("kind,P,rot,bm,chunk", [("bf16", 2, 1, 10, 256 * 1024), ("fp32", 4, 1, 220, 256 * 1024), ("bf16", 2, 1, 10, 128 * 1024),
-                                                    ("fp16", 2, 0, 10, 256 * 1024)],
-                         ids=["bf16-256k", "fp32-256k", "bf16-128k", "fp16-256k-dense-code-capped"])
+                                                    ("fp16", 2, 0, 10, 256 * 1024), ("fp8", 1, 0, 10, 128 * 1024)],
+                         ids=["bf16-256k", "fp32-256k", "bf16-128k", "fp16-256k-dense-code", "fp8-128k-dense-code"])
 def test_register_resident_form_decodes_weights_like_tensors(simt_lib, kind, P, rot, bm, chunk):
     """The fast form of the fused decoder (decode once into registers, compact): weights-like tensors at the default
     chunk size must go through it tile for tile (counters of the emulated build), including its fix-up iterations,
     and decode to the input bit for bit."""
     g = torch.Generator().manual_seed(11)
     n = 3 * chunk
-    x = (torch.randn(n // (4 if kind == "fp32" else 2), generator=g) * 0.02).to({"fp32": torch.float32, "fp16": torch.float16}.get(kind, torch.bfloat16))
+    if kind == "fp8":
+        x = (torch.randn(n, generator=g) * 0.02).to(torch.float8_e4m3fn)
+    else:
+        x = (torch.randn(n // (4 if kind == "fp32" else 2), generator=g) * 0.02).to({"fp32": torch.float32, "fp16": torch.float16}.get(kind, torch.bfloat16))
     d = x.view(torch.uint8).numpy().tobytes()
     ref = O.compress_frame(HDR, d, P, rot, bm, chunk)
     _tile_counters()
     assert bytes(simt_lib.decompress(ref[32:], P, rot, bm, chunk, len(d))) == d
     tiles, looping, fixups, groups = _tile_counters()[:4]
-    if kind == "fp16":     # a dense code (5.5 bits a symbol): sub-blocks capped at the compile-time size; a few tiles overflow the step slots
-        assert tiles > 20 and looping * 20 <= tiles and groups == 0
+    if kind in ("fp16", "fp8"):     # dense codes (5-6 bits a symbol, none shorter than 4): 6-dword sub-blocks in the packed-record instance (two steps
+        assert tiles > 20 and looping * 20 <= tiles and groups == 0      # to a register); a few tiles may overflow the step slots and take the looping form
     else:
         assert tiles > 20 and looping == 0 and groups == 0    # every tile took the register-resident form
-    if kind == "fp16":
+    if kind in ("fp16", "fp8"):
         assert fixups > 0                                     # … and some of them needed a fix-up iteration: fp16's top-byte code re-synchronises
                                                               # slowly (0.2-0.3 fix-ups per tile at the 44-bit run-in; bf16 / fp32: a few in 1000 tiles)
 
 
-@pytest.mark.parametrize("kind", ["skew", "burst", "fp8w", "sparse", "onebit"])
+@pytest.mark.parametrize("kind", ["skew", "burst", "dense3", "sparse", "onebit"])
 def test_looping_form_still_decodes_what_the_fast_form_leaves(simt_lib, kind):
-    """Distributions whose sub-block size is not the compile-time one (short codes, dense tiles, 5-bit codes) and tiles
-    denser than one staging buffer go through the looping form (and its lane groups): same bytes."""
+    """Distributions whose sub-block size is not a compile-time one (short codes, dense tiles, long sub-blocks with a short code) and
+    tiles denser than one staging buffer go through the looping form (and its lane groups): same bytes."""
     chunk = 256 * 1024
     r = np.random.default_rng(3)
     if kind in ("skew", "burst"):
         d = _gen2(kind, 2 * chunk, 3); P, rot = 2, 0      # (one plane of 256 KiB would exceed huff0's 128 KiB block: stored raw)
-    elif kind == "fp8w":
-        g = torch.Generator().manual_seed(5)
-        d = (torch.randn(2 * chunk, generator=g) * 0.02).to(torch.float8_e4m3fn).view(torch.uint8).numpy().tobytes(); P, rot = 1, 0; chunk = 128 * 1024
+    elif kind == "dense3":   # ≈ 5 bits a symbol but with one 3-bit code: wants long sub-blocks, is not "dense" (three symbols fit a window): run-time D, looping form
+        probs = np.array([0.14] + [0.86 / 60] * 60); probs /= probs.sum()
+        d = r.choice(np.arange(61, dtype=np.uint8), 2 * chunk, p=probs).tobytes(); P, rot = 1, 0; chunk = 128 * 1024
     elif kind == "sparse":
         b = np.zeros(2 * chunk, dtype=np.uint8); m = r.random(2 * chunk) < 0.08; b[m] = r.integers(0, 255, int(m.sum())); d = b.tobytes(); P, rot = 2, 1
     else:

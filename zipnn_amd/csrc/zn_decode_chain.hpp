@@ -163,14 +163,22 @@ template <int G> __device__ __forceinline__ uint32_t& zn_rec_c(ZnRec& r) {
   if constexpr (G == 0) return r.c0; else if constexpr (G == 1) return r.c1; else if constexpr (G == 2) return r.c2;
   else if constexpr (G == 3) return r.c3; else if constexpr (G == 4) return r.c4; else if constexpr (G == 5) return r.c5; else return r.c6;
 }
-// record step I: symbols, and the count byte of `meta` into its byte of the packed counts (one v_perm_b32)
-template <int I> __device__ __forceinline__ void zn_rec_put(ZnRec& r, uint32_t syms, uint32_t meta) {
-  zn_rec_s<I>(r) = syms;
+// record step I: symbols, and the count byte of `meta` into its byte of the packed counts (one v_perm_b32).
+// DENSE (a code whose shortest length is ≥ 4 bits: an 11-bit window holds at most TWO symbols): two steps share a symbol register,
+// step I in half I % 2 of register I / 2 — 14 + 7 registers for 28 steps instead of 28 + 7, which is what lets 6-dword sub-blocks
+// (fp8, fp16's top byte) take the register-resident form without spilling.
+template <int I, bool DENSE = false> __device__ __forceinline__ void zn_rec_put(ZnRec& r, uint32_t syms, uint32_t meta) {
+  if constexpr (DENSE) { uint32_t& sr = zn_rec_s<I / 2>(r); if constexpr (I % 2 == 0) sr = syms; else sr = __builtin_amdgcn_perm(syms, sr, 0x05040100u); }     // (≤ 2 symbols: the upper half of `syms` is zero)
+  else zn_rec_s<I>(r) = syms;
   constexpr uint32_t sel = (I % 4 == 0) ? 0x03020105u : (I % 4 == 1) ? 0x03020500u : (I % 4 == 2) ? 0x03050100u : 0x05020100u;
   uint32_t& c = zn_rec_c<I / 4>(r);
   c = __builtin_amdgcn_perm(meta, c, sel);
 }
 template <int I> __device__ __forceinline__ uint32_t zn_rec_cnt(ZnRec& r) { return (zn_rec_c<I / 4>(r) >> (8 * (I % 4))) & 7u; }
+template <int I, bool DENSE> __device__ __forceinline__ uint32_t zn_rec_sym(ZnRec& r) {
+  if constexpr (DENSE) return (I % 2 == 0) ? (zn_rec_s<I / 2>(r) & 0xFFFFu) : (zn_rec_s<I / 2>(r) >> 16);
+  else return zn_rec_s<I>(r);
+}
 template <int N> struct ZnIdx { static constexpr int v = N; };
 template <int I, int N, typename F> __device__ __forceinline__ void zn_static_for(F&& f) {
   if constexpr (I < N) { f(ZnIdx<I>{}); zn_static_for<I + 1, N>(f); }
@@ -183,7 +191,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void zn_static_fo
 // Returns false when TF steps did not bring every lane to its boundary (the caller falls back to the looping form).
 // A fix-up iteration (some lane started from a wrong position) simply runs the whole pass again from the corrected
 // starts: the lanes run in lock-step, so decoding all of them costs what decoding the wrong ones would.
-template <int TF, int TB, int U>
+template <int TF, int TB, int U, bool DENSE = false>
 __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, int32_t base_bit, uint32_t TL, int32_t pos0, int32_t stop,
                                          bool own, ZnRec& rec, uint32_t& acc_out, int& nfull, int& nbnd) {
   static_assert(TF + TB <= ZN_REC_MAX, "more record slots than ZnRec has");
@@ -209,7 +217,7 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
         if (checked && !act) { e.x = 0; e.y = 0; }
         w <<= (e.y & 63u);
         acc += e.y;
-        zn_rec_put<t>(rec, e.x, e.y);
+        zn_rec_put<t, DENSE>(rec, e.x, e.y);
         ZN_STEP_FENCE();
       }
     }
@@ -227,7 +235,7 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
         if (!(rem > 0)) { e.x = 0; e.y = 0; }
         e = zn_trim_group(e, rem);
         acc += e.y;
-        zn_rec_put<TF + b>(rec, e.x, e.y);
+        zn_rec_put<TF + b, DENSE>(rec, e.x, e.y);
         ZN_STEP_FENCE();
       }
     }
@@ -248,7 +256,7 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
 // shift: its source would be a register PAIR per step with a zero upper half, twice the registers.)
 // `hook(ZnIdx<t>)` runs after step t (the caller spreads its HBM requests for the flush over the pass there: their
 // destination registers come into use as the record registers fall out of it).
-template <int TF, int TB, typename HOOK>
+template <int TF, int TB, bool DENSE = false, typename HOOK>
 __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& rec, int nfull, int nbnd, HOOK&& hook) {
   uint32_t wm1 = wpos - 1u;                                // (wpos == 0: the pair starts one dword below the buffer and that dword gets a zero)
   auto put = [&](uint32_t cnt, uint32_t sv) {
@@ -266,7 +274,7 @@ __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& 
     wm1 += cnt;
     ZN_STEP_FENCE();
   };
-  zn_static_for<0, TF>([&](auto I) { constexpr int t = decltype(I)::v; if (t < nfull) { put(zn_rec_cnt<t>(rec), zn_rec_s<t>(rec)); hook(I); } });
-  zn_static_for<0, TB>([&](auto I) { constexpr int b = decltype(I)::v; if (b < nbnd) { put(zn_rec_cnt<TF + b>(rec), zn_rec_s<TF + b>(rec)); hook(ZnIdx<TF + b>{}); } });
+  zn_static_for<0, TF>([&](auto I) { constexpr int t = decltype(I)::v; if (t < nfull) { put(zn_rec_cnt<t>(rec), zn_rec_sym<t, DENSE>(rec)); hook(I); } });
+  zn_static_for<0, TB>([&](auto I) { constexpr int b = decltype(I)::v; if (b < nbnd) { put(zn_rec_cnt<TF + b>(rec), zn_rec_sym<TF + b, DENSE>(rec)); hook(ZnIdx<TF + b>{}); } });
 }
 

@@ -75,6 +75,17 @@
 #ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
 #endif
+// The second compile-time size: the DENSE-code instance (fp8, fp16's top byte: 5-6 bits a symbol want 6-dword sub-blocks).  Round 2
+// had it off — 25 + 3 record slots spilled in every instance.  Round 3: a code whose shortest length is ≥ 4 bits puts at most two
+// symbols into an 11-bit window, so two steps share a record register (zn_rec_put<I, DENSE>): 14 + 7 registers for 28 steps, fewer
+// than the 4-dword instance's 20 + 5, and the tiles of such streams take the register-resident form (no second decode for the
+// write pass).  Instantiated for one- and two-plane tensors; 0 = off.
+#ifndef ZN_F_DCONST2
+#define ZN_F_DCONST2 6
+#endif
+#ifndef ZN_F_DENSE_LMIN
+#define ZN_F_DENSE_LMIN 4                // shortest code length (bits) from which a stream counts as dense
+#endif
 // dwords 0 (look-ahead below the tile) .. 64 D (its top) of a stream tile, + spare
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
 #ifndef ZN_F_TF
@@ -290,6 +301,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   // A sub-block of D dwords needs about 32 D / 9.6 steps (a step consumes 9-10 of its ≤ 11 window bits on every
   // dtype's data, or 4 symbols when the codes are short); lanes that need more send the tile to the looping form.
   constexpr int TF = DC ? ZN_F_TF(DC) : 0, TB = 3;      // (the run-time-D instance only has the looping form)
+  // the second compile-time size is the dense-code instance: its caller guarantees a shortest code of ≥ 4 bits (≤ 2 symbols per
+  // window), and its records are packed two steps to a register (zn_rec_put)
+  constexpr bool DENSE = (ZN_F_DCONST2 != 0) && (DC == ZN_F_DCONST2);
   constexpr int UF = DC ? (32 * DC - 31) / 11 : 0;
   ZN_PT_SHARED;
 
@@ -549,8 +563,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       bool took = true, chained = false;
       for (int it = 0; it < 4; it++) {
         // (one call site per instance: the unchecked-head one for regular tiles, the checked one for a stream's last tile)
-        if (regular) took = zn_pass1<TF, TB, UF>(lut, in, base_bit, TL, s, stop, true, rec, acc, nfull, nbnd);
-        else took = zn_pass1<TF, TB, 0>(lut, in, base_bit, TL, s, stop, active, rec, acc, nfull, nbnd);
+        if (regular) took = zn_pass1<TF, TB, UF, DENSE>(lut, in, base_bit, TL, s, stop, true, rec, acc, nfull, nbnd);
+        else took = zn_pass1<TF, TB, 0, DENSE>(lut, in, base_bit, TL, s, stop, active, rec, acc, nfull, nbnd);
         if (!took) break;
         e = s - (int32_t)(acc & 0xFFu); n = (acc >> 8) & 0xFFu;
         const int32_t e_prev = __shfl_up(e, 1u);
@@ -593,7 +607,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           // (lanes without a sub-block hold zero records.)  The raw rows RH.. are requested after step TF/2 - 1: the records of
           // the steps before it are dead by then, so the rows' registers do not add to the peak at the start of the compaction.
           bool late_rows = (RH < RB);
-          if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB>(ring, base + o_k, rec, nf, nb_, [&](auto I) {
+          if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB, DENSE>(ring, base + o_k, rec, nf, nb_, [&](auto I) {
             if constexpr (RH < RB && decltype(I)::v == TF / 2 - 1) { for (int r = RH; r < RB; r++) if (r < first) fetch_row(JF, r); late_rows = false; }
           });
           if (late_rows) for (int r = RH; r < RB; r++) if (r < first) fetch_row(JF, r);     // (a tile of fewer steps than that)
@@ -946,15 +960,15 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     // carried remainder, at this stream's average code length (8 slen / seg bits per symbol)
     uint32_t Du = ((ZN_F_RING_BYTES - UNIT - 128u) * slen) / (256u * seg);
     Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
-    if (ZN_F_DCAP && Du > ZN_F_DCAP && zn_uniform(L.st[j].dom) < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
+    // (dense code: ≥ 5 dwords wanted and no code shorter than 4 bits — the packed-record instance; otherwise the cap of round 2)
+    const bool dense = ZN_F_DCONST2 && !X && P <= 2 && Du > ZN_F_DCAP && zn_uniform(L.st[j].lmin) >= ZN_F_DENSE_LMIN;
+    if (dense) Du = ZN_F_DCONST2;
+    else if (ZN_F_DCAP && Du > ZN_F_DCAP && zn_uniform(L.st[j].dom) < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
 #define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
-#ifndef ZN_F_DCONST2
-#define ZN_F_DCONST2 0                   // a second compile-time sub-block size (0 = none; 6 = what dense codes — fp8, fp16, ~5.4 bits a symbol — use).  Off: its 28 record slots spill in every instance of the kernel, and dense codes need a longer run-in than 22 bits to synchronise (fix-ups in 40-100 % of the tiles: profiles/r02_decode_experiments.txt)
-#endif
 #define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) \
-                            : (ZN_F_DCONST2 && !X && Du == ZN_F_DCONST2) ? zn_fused_wave<P, H_, (X ? 0 : ZN_F_DCONST2), X>(ZN_WAVE_ARGS) \
+                            : (dense) ? zn_fused_wave<P, H_, ((X || P > 2 || !ZN_F_DCONST2) ? 0 : ZN_F_DCONST2), X>(ZN_WAVE_ARGS) \
                             : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
     // (one instance per Huffman plane index that exists for this P — nothing is instantiated twice)
 #ifdef ZN_F_ONLY_HOT      // (developer probe: the common instance alone, to read its register use off the compiler's remarks)
