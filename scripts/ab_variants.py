@@ -81,6 +81,15 @@ VARIANTS = {
     "bias0": (None, ["-mllvm", "-amdgpu-schedule-metric-bias=0"]),
     "o2": (None, ["-O2"]),
     "d44c": (None, ["-DZN_F_DELTA0=44", "-DZN_F_DELTA_MAX=44"]),
+    "dmax88": (None, ["-DZN_F_DELTA_MAX=88"]),
+    "dd44": (None, ["-DZN_F_DELTA0_DENSE=44"]),
+    "dd66": (None, ["-DZN_F_DELTA0_DENSE=66"]),
+    "dd132": (None, ["-DZN_F_DELTA0_DENSE=132"]),
+    "dd192": (None, ["-DZN_F_DELTA0_DENSE=192"]),
+    "dmax66": (None, ["-DZN_F_DELTA_MAX=66"]),
+    "d88": (None, ["-DZN_F_DELTA0=88"]),
+    "tf23": (None, ["-DZN_F_TF(D)=((D)==6?23:(D)*4+1)"]),
+    "tf21": (None, ["-DZN_F_TF(D)=((D)==6?21:(D)*4+1)"]),
     "d33c": (None, ["-DZN_F_DELTA0=33", "-DZN_F_DELTA_MAX=44"]),
     "d22c": (None, ["-DZN_F_DELTA_MAX=44"]),
     "nmis2": (None, ["-DZN_F_NMIS=2"]),
@@ -121,7 +130,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2")
+ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192")
 
 
 def run(names):

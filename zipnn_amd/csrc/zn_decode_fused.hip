@@ -150,6 +150,9 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
                                          // (profiles/r03_decode_experiments.txt): 44 from the start is neutral on bf16 / fp32 (fewer fix-ups pay for the two
                                          // extra look-ups) and 2 % faster on the dense codes (fp16, fp8), whose streams end up there anyway
 #endif
+#ifndef ZN_F_DELTA0_DENSE
+#define ZN_F_DELTA0_DENSE 88             // … of the dense-code instance (fp8 +2 %, fp16 +1.3 % over 44; bf16 would lose 4 % to it)
+#endif
 #ifndef ZN_F_DELTA_FAST
 #define ZN_F_DELTA_FAST 44               // longest run-in the unrolled sync handles (beyond it: the looping form)
 #endif
@@ -429,7 +432,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   int32_t carry = __builtin_amdgcn_readfirstlane(b0 + (int32_t)(8u * (slen - 1u)) + (int32_t)zn_hb32(last));   // (wave-uniform)
   int32_t hi_dw = (carry + 31) >> 5;
   const int32_t Di = DC ? DC : (int32_t)Du, TD = 64 * Di;             // dwords per sub-block / per tile
-  int32_t delta = (ZN_F_DELTA0 < 32 * Di) ? ZN_F_DELTA0 : 32 * Di;
+  // (a dense code re-synchronises slowly: its streams start with the longer run-in they would grow into anyway)
+  int32_t delta = (DENSE ? ZN_F_DELTA0_DENSE : ZN_F_DELTA0) < 32 * Di ? (DENSE ? ZN_F_DELTA0_DENSE : ZN_F_DELTA0) : 32 * Di;
   int nmis = 0;                               // tiles of this stream that needed a fix-up since the run-in was last lengthened
 
   // stream-tile prefetch registers: dword (lo_dw - 1 + lane + 64 i) of the NEXT tile, i = 0..D-1, and (lane 0) the
