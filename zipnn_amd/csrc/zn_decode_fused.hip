@@ -227,7 +227,7 @@ struct __attribute__((aligned(16))) ZnFusedLds {
 // Decode tables of one huff0 block, by the whole workgroup: the canonical single-symbol LUT (u16, aliased into
 // staging buffer 0, idle at this point), then the multi-symbol LUT.  j = which of the group's symbol orders.
 // Contains one __syncthreads(); the caller syncs again before the staging buffers are used.
-__device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, uint32_t TL, uint32_t j) {
+__device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, uint32_t TL, uint32_t j, uint32_t lmin = 1) {
   uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
   {
     const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
@@ -239,7 +239,10 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
     const uint32_t mask = (1u << TL) - 1u;
     uint32_t pos[8], cnt[8], syms[8], ef[8];
     for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; }
+    // (a window of TL bits holds at most TL / lmin symbols: a dense code's table needs two rounds of look-ups, not four)
+    const int rounds = (int)zn_uniform(lmin ? (TL / lmin > 4u ? 4u : TL / lmin) : 4u);
     for (int step = 0; step < 4; step++) {
+      if (step >= rounds) break;
       for (int k = 0; k < 8; k++) {
         const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
         if (u <= mask && cnt[k] == (uint32_t)step) {
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       const ZnWaveStats st = L.st[j];
       const int hs = (int)zn_uniform((uint32_t)st.hs); TL = zn_uniform(st.tl);
       if (!((ZN_F_ABL & 16) && j > 0))
-      zn_fused_fill_luts(L, tid, TL, j);
+      zn_fused_fill_luts(L, tid, TL, j, zn_uniform(st.lmin));
       // jump table → this wave's stream
       const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
       const uint32_t l1 = zn_uniform(zn_ld16(js)), l2 = zn_uniform(zn_ld16(js + 2)), l3 = zn_uniform(zn_ld16(js + 4));
