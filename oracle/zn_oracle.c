@@ -82,6 +82,11 @@ unsigned zo_optimal_table_log(unsigned max_log, size_t src_size, unsigned max_sv
   return t;
 }
 
+/* how often the secondary normalisation ran (tests use it to show that their inputs reach that path; not thread-safe,
+   so a lower bound when zo_compress_frame runs on several threads) */
+static unsigned long g_m2_calls;
+unsigned long zo_debug_m2_calls(void) { return g_m2_calls; }
+
 /* secondary normalisation (FSE_normalizeM2) */
 static size_t fse_normalize_m2(short* norm, unsigned tl, const unsigned* count, size_t total,
                                unsigned max_sv, short low_prob) {
@@ -158,7 +163,9 @@ size_t zo_fse_normalize_count(short* norm, unsigned tl, const unsigned* count, s
     norm[s] = p; still -= p;
   }
   if (-still >= (norm[largest] >> 1)) {
-    size_t e = fse_normalize_m2(norm, tl, count, total, max_sv, low_prob);
+    size_t e;
+    g_m2_calls++;
+    e = fse_normalize_m2(norm, tl, count, total, max_sv, low_prob);
     if (zo_huf_is_error(e)) return e;
   } else {
     norm[largest] += (short)still;

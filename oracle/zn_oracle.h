@@ -68,6 +68,7 @@ size_t zo_fse_normalize_count(short* norm, unsigned table_log, const unsigned* c
  * FiniteStateEntropy huff0 that the reference's PyPI wheels bundle).  Process-wide; set before compressing. */
 void zo_set_weight_low_prob(int v);
 int zo_get_weight_low_prob(void);
+unsigned long zo_debug_m2_calls(void);   /* secondary normalisations so far (test coverage probe) */
 
 /* ---- byte-plane transforms (one chunk) ---- */
 /* In-place sign-bit rotate over len/4 words, as the reference does it (a trailing

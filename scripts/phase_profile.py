@@ -73,7 +73,7 @@ def main():
     jobs = acc[18] or 1
     print(f"encode: stats kernel (per chunk, {ch} chunks) / tables kernel (per table, {jobs} tables)")
     for i, nm, d in ((0, "stats: zero + 4 quarter histograms", ch), (1, "stats: decisions + counts out", ch), (2, "tables: counts + rank sort", jobs),
-                     (5, "tables: tree + code lengths (serial)", jobs), (9, "tables: values + weights (parallel)", jobs), (6, "tables: tree description (serial)", jobs), (7, "tables: hand-over", jobs), (8, "tables: stream sizes", jobs), (3, "tables: descriptor out", jobs)):
+                     (5, "tables: tree + code lengths (serial)", jobs), (9, "tables: values + weights (parallel)", jobs), (6, "tables: tree description (wave, uniform chain)", jobs), (8, "tables: stream sizes", jobs), (3, "tables: descriptor out", jobs)):
         print(f"  {nm:36s} {acc[i] / d:10.0f} cyc")
 
 if __name__ == "__main__":

@@ -59,6 +59,7 @@ def lib():
         L.zo_set_weight_low_prob.restype = None
         L.zo_set_weight_low_prob.argtypes = [ctypes.c_int]
         L.zo_get_weight_low_prob.restype = ctypes.c_int
+        L.zo_debug_m2_calls.restype = ctypes.c_ulong
         _LIB = L
     return _LIB
 

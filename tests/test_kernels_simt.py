@@ -641,3 +641,83 @@ def test_range_entry_points_reject_bad_arguments_and_damaged_tables(simt_lib):
         simt_lib.merge_range_bodies([(parts[0][0][:-5], ks[0]), good[1]], 2)
     with pytest.raises(ValueError):
         simt_lib.merge_range_bodies(good, 3)
+
+
+def _varied_planes(nchunks, chunk, seed):
+    """One byte plane per chunk, every chunk with its own symbol statistics (alphabet size, shape, which byte values):
+    what drives the tree description through its cases — FSE-coded weights with few / many weight classes, the
+    secondary normalisation, raw 4-bit weights, descriptions that are not kept."""
+    rng = np.random.default_rng(seed)
+    out = np.empty(nchunks * chunk, dtype=np.uint8)
+    for c in range(nchunks):
+        shape = c % 6
+        A = int(rng.integers(2, 257))
+        syms = rng.permutation(256)[:A] if (c % 3) else np.arange(A) + int(rng.integers(0, 257 - A))
+        if shape == 0:                                   # geometric
+            p = float(rng.uniform(0.5, 0.98)) ** np.arange(A)
+        elif shape == 1:                                 # power law
+            p = 1.0 / (np.arange(A) + 1.0) ** float(rng.uniform(0.6, 2.5))
+        elif shape == 2:                                 # near uniform
+            p = np.ones(A) + rng.uniform(0, 0.3, A)
+        elif shape == 3:                                 # a few heavy symbols + a long tail of rare ones
+            p = np.full(A, 1e-4); p[: max(1, A // 16)] = 1.0
+        elif shape == 4:                                 # two plateaus
+            p = np.where(np.arange(A) < A // 2, 8.0, 1.0)
+        else:                                            # gaussian bump (an exponent plane)
+            p = np.exp(-0.5 * ((np.arange(A) - A / 2) / max(1.0, A / float(rng.uniform(4, 12)))) ** 2) + 1e-6
+        p = p / p.sum()
+        out[c * chunk:(c + 1) * chunk] = syms[rng.choice(A, size=chunk, p=p)].astype(np.uint8)
+    return out.tobytes()
+
+
+def _dyadic_plane(lengths, absent, chunk, seed):
+    """A plane whose Huffman code lengths are exactly `lengths` (a complete code: Σ 2^-l = 1; symbol i occurs
+    chunk · 2^-l_i times), over ascending byte values with `absent` unused values in between — the weight histogram
+    of its tree description is then known in advance."""
+    rng = np.random.default_rng(seed)
+    A = len(lengths)
+    assert sum(chunk >> l for l in lengths) == chunk
+    gaps = set(rng.choice(np.arange(1, A + absent - 1), size=absent, replace=False).tolist()) if absent else set()
+    vals = [v for v in range(A + absent) if v not in gaps]
+    order = rng.permutation(A)                                      # which byte value gets which length ...
+    order = np.concatenate([order[order != np.argmax(lengths)], [np.argmax(lengths)]])   # ... the highest value one of the longest
+    plane = np.concatenate([np.full(chunk >> lengths[i], vals[j], dtype=np.uint8) for j, i in enumerate(order)])
+    return rng.permutation(plane).tobytes()
+
+
+def test_tree_descriptions_written_by_the_wave_match_the_oracle(simt_lib):
+    """The fused table kernel writes the tree description with the whole wave (zn_wave_write_ctable); the oracle is the
+    serial statement of HUF_writeCTable.  Planes with different statistics, frames compared byte for byte; the inputs
+    are shown to reach the FSE form, the raw 4-bit form and the secondary normalisation (FSE_normalizeM2: codes
+    whose weight classes hold one symbol each, found by search over weight histograms with the oracle)."""
+    from zipnn_amd import sharding
+    chunk = 16384
+    rng = np.random.default_rng(9)
+    parts = [_varied_planes(180, chunk, 5)]
+    for k in (7, 8, 9, 10, 11):                                      # lengths 1, 2, …, k, k with a few unused values: reaches M2
+        for absent in (2, 3):
+            parts.append(_dyadic_plane(list(range(1, k + 1)) + [k], absent, chunk, 100 + 10 * k + absent))
+    parts.append(_dyadic_plane([1, 3, 3, 3, 4, 5, 6, 7, 9, 10, 10, 10, 11, 11, 11, 11, 11, 11], 4, chunk, 7))
+    parts.append(_dyadic_plane([1, 2, 3, 4, 5, 6, 8, 9, 9, 9, 9, 10, 11, 11, 11, 11, 11, 11], 4, chunk, 8))
+    for i in range(40):                                              # small alphabets: raw 4-bit weights
+        A = int(rng.integers(3, 40)); lo = int(rng.integers(0, 90))
+        p = rng.uniform(0.2, 1.0, A) ** float(rng.uniform(1, 4)); p /= p.sum()
+        parts.append((lo + rng.choice(A, size=chunk, p=p)).astype(np.uint8).tobytes())
+    d = b"".join(parts)
+    nchunks = len(d) // chunk
+    m2_before = O.lib().zo_debug_m2_calls()
+    want = O.compress_frame(HDR, d, 1, 0, 10, chunk, threads=1)
+    m2 = O.lib().zo_debug_m2_calls() - m2_before
+    got = simt_lib.compress(HDR, d, 1, 0, 10, chunk, 0.95)
+    assert bytes(got) == want
+    assert "zn_k_encode_tables" in simt_lib.last_kernels()
+    types, cum, payload = sharding._parse(np.frombuffer(want[32:], dtype=np.uint8), 1, nchunks)
+    kinds = {"fse": 0, "raw4": 0, "stored": 0}
+    for c in range(nchunks):
+        start = int(cum[0, c - 1]) if c else 0
+        if types[0, c] == 0:
+            kinds["stored"] += 1
+        else:
+            kinds["fse" if payload[start] < 128 else "raw4"] += 1
+    assert kinds["fse"] >= 100 and kinds["raw4"] >= 20 and m2 >= 3, (kinds, m2)
+    assert bytes(simt_lib.decompress(bytes(got)[32:], 1, 0, 10, chunk, len(d))) == d

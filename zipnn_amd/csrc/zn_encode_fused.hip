@@ -228,7 +228,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
 struct ZnTablesLds {
   ZnTabScratch S;
   ZnHNode nodes[513];
-  uint32_t go, hdr, cs, hl;
+  uint32_t hl;
 };
 
 __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
@@ -305,9 +305,10 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
   }
   __syncthreads();
   // parallel: canonical values (symbols of one length in symbol order), huff0 weights and their histogram
+  uint32_t wc[13];
   {
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
-    uint32_t run[13], wc[13];
+    uint32_t run[13];
     for (int v = 0; v < 13; v++) { run[v] = 0; wc[v] = 0; }
     for (int k = 0; k < 4; k++) {
       const uint32_t sym = lane + 64u * (uint32_t)k;
@@ -326,22 +327,20 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
   }
   __syncthreads();
   ZN_PT(9);   // values + weights
-  // serial: the tree description
-  if (lane == 0) {
-    const int h = zn_huf_write_ctable(&L.S, max_sv, huff_log, true);
-    ZN_PT(6);   // tree description
-    uint32_t go = 0, cs = 0;
+  // the tree description: the whole wave, its serial chain on wave-uniform values (zn_wave_write_ctable)
+  uint32_t cs = 0, hdr_len = 0; bool go = false;
+  {
+    const int h = zn_wave_write_ctable(&L.S, max_sv, wc, lane);
     if (h < 0) cs = 0xFFFFFFFFu;               // huff0 error → fails the threshold test → raw
     else if ((uint32_t)h + 12u >= n) cs = 0;
     else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u) cs = 0;
-    else go = 1;
-    L.go = go; L.hdr = (uint32_t)(h > 0 ? h : 0); L.cs = cs;
+    else go = true;
+    hdr_len = (uint32_t)(h > 0 ? h : 0);
   }
   __syncthreads();
-  ZN_PT(7);   // hand-over from the serial lane
-  uint32_t cs = L.cs;
+  ZN_PT(6);   // tree description
   uint32_t sz[4] = {0, 0, 0, 0};
-  if (L.go) {
+  if (go) {
     // stream q's bit count = Σ_symbols count_q[s] · len[s], + 1 for the end mark
     uint32_t bits[4];
     for (int q = 0; q < 4; q++) {
@@ -350,7 +349,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
       for (int d = 32; d >= 1; d >>= 1) b += __shfl_xor(b, d);
       bits[q] = b + 1u;
     }
-    uint32_t pos = L.hdr + 6u; bool fail = false;
+    uint32_t pos = hdr_len + 6u; bool fail = false;
     for (int k = 0; k < 4; k++) {              // BIT_closeCStream's capacity rule, stream by stream
       const uint64_t cap_rem = cap - pos;
       if (cap_rem <= 8u || (uint64_t)(bits[k] >> 3) >= cap_rem - 8u) { fail = true; sz[k] = 0; break; }
@@ -364,8 +363,8 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
   const bool keep = cs != 0 && (double)cs < (double)n * (double)threshold;
   if (keep) {
     for (int k = 0; k < 4; k++) { const uint32_t s = lane + 64u * (uint32_t)k; D->code[s] = (uint32_t)L.S.vals[s] | ((uint32_t)L.S.nbits[s] << 16); }
-    for (uint32_t i = lane; i < 136u; i += 64u) D->hdr[i] = (i < L.hdr) ? L.S.hdr[i] : 0;
-    if (lane == 0) { D->hdr_len = L.hdr; for (int k = 0; k < 4; k++) D->ssize[k] = sz[k]; }
+    for (uint32_t i = lane; i < 136u; i += 64u) D->hdr[i] = (i < hdr_len) ? L.S.hdr[i] : 0;
+    if (lane == 0) { D->hdr_len = hdr_len; for (int k = 0; k < 4; k++) D->ssize[k] = sz[k]; }
   }
   if (lane == 0) { type_out[pc] = keep ? 1 : 0; csize_out[pc] = keep ? cs : n; }
   ZN_PT(3);   // sizes + descriptor

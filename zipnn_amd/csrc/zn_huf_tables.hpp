@@ -348,3 +348,172 @@ __device__ inline int zn_huf_write_ctable(ZnTabScratch* S, uint32_t max_sv, uint
   for (uint32_t n = 0; n < max_sv; n += 2) op[n / 2 + 1] = (uint8_t)((w[n] << 4) + w[n + 1]);
   return (int)(((max_sv + 1u) / 2u) + 1u);
 }
+
+// ---------------------------------------------------------------------------
+// The same tree description by ONE WAVE (the fused table kernel; round 3).
+//
+// HUF_compressWeights is a serial state chain over ≤255 weights; on one lane every step is three dependent LDS round
+// trips (weight → its transform → next state), 300 cycles a weight, 75 k cycles a table — more than the rest of the
+// table job together.  Here the whole wave runs the chain on wave-uniform values, the mirror image of the decoder's
+// parser (zn_huf_wave.hpp): the FSE state table lives in one VGPR (lane u = entry u), the per-symbol transforms in two
+// (lane s = weight value s), the weights themselves as nibbles in a fourth (lane l = weights 8l … 8l+7), the output
+// bytes in a fifth (lane d = dword d); every access is a v_readlane with a uniform index, so the chain is scalar-ALU
+// code with no memory latency in it.  The normalised counts, the symbol spread, the state table and the transforms are
+// built lane-parallel.  Same bytes and return codes as zn_huf_compress_weights / zn_huf_write_ctable above (the generic
+// encoder keeps those; tests compare both against the oracle).
+//
+// All 64 lanes must call these together (uniform control flow).  S->weights[0..nw) and S->wcount[0..13] are filled.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t zn_trl(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
+
+__device__ inline int zn_wave_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint32_t (&wc)[13], uint32_t nw, uint32_t lane) {
+  if (nw <= 1) return 0;
+  uint32_t max_sv = 0, max_c = 0;
+  for (uint32_t v = 0; v < 13u; v++) { if (wc[v]) max_sv = v; if (wc[v] > max_c) max_c = wc[v]; }
+  if (max_c == nw) return 1;
+  if (max_c == 1) return 0;
+  const uint32_t tl = zn_optimal_table_log(ZN_WEIGHT_FSE_LOG, nw, max_sv, 2);
+  const uint32_t size = 1u << tl;
+
+  // ---- FSE_normalizeCount, lane s = weight value s; the correction of the largest count in symbol order on uniform values ----
+  uint32_t normv = 0;
+  {
+    uint32_t cl = 0;
+    for (uint32_t v = 0; v < 13u; v++) cl = (lane == v) ? wc[v] : cl;
+    const uint64_t scale = 62 - tl, step = (1ULL << 62) / nw, vstep = 1ULL << (scale - 20);
+    const uint32_t low_thr = nw >> tl;
+    uint32_t p = 0, pn = 0;                         // pn: p of the counts that went through the proportional rule
+    if (lane <= max_sv && cl != 0) {
+      if (cl <= low_thr) p = 1;
+      else {
+        p = (uint32_t)(((uint64_t)cl * step) >> scale);
+        if (p < 8u) { const uint64_t beat = vstep * ZN_RTB(p); p += ((uint64_t)cl * step) - ((uint64_t)p << scale) > beat ? 1u : 0u; }
+        pn = p;
+      }
+    }
+    int still = (int)size; uint32_t largest = 0, largest_p = 0;
+    for (uint32_t s = 0; s < 13u; s++) {
+      still -= (int)zn_trl(p, s);
+      const uint32_t q = zn_trl(pn, s);
+      if (q > largest_p) { largest_p = q; largest = s; }
+    }
+    const int nl = (int)zn_trl(p, largest);
+    if (-still < (nl >> 1)) normv = (lane == largest) ? (uint32_t)(nl + still) : p;
+    else {
+      // secondary normalisation (rare): the serial builder on one lane
+      if (lane == 0) { const int r = zn_fse_normalize(S->norm, tl, S->wcount, nw, max_sv); S->cumul[0] = (uint32_t)r; }
+      __builtin_amdgcn_wave_barrier();
+      const int r = (int)S->cumul[0];
+      if (r != 0) return r == 1 ? 0 : -1;
+      normv = (lane <= max_sv) ? (uint32_t)(int)S->norm[lane] : 0u;
+    }
+  }
+
+  // ---- FSE_writeNCount (uniform; the counts are never -1 here) ----
+  uint32_t off = 0;
+  {
+    const int table_size = 1 << tl;
+    int nb_bits = (int)tl + 1, remaining = table_size + 1, threshold = table_size;
+    uint32_t bits = 0; int nbit = 0; uint32_t sym = 0; const uint32_t alpha = max_sv + 1; int prev0 = 0;
+    bits += (tl - ZN_FSE_LOG_MIN) << nbit; nbit += 4;
+#define ZN_NC_FLUSH16() do { if (lane == 0) { dst[off] = (uint8_t)bits; dst[off + 1] = (uint8_t)(bits >> 8); } off += 2; bits >>= 16; } while (0)
+    while (sym < alpha && remaining > 1) {
+      if (prev0) {
+        uint32_t start = sym;
+        while (sym < alpha && !zn_trl(normv, sym)) sym++;
+        if (sym == alpha) break;
+        while (sym >= start + 24) { start += 24; bits += 0xFFFFu << nbit; ZN_NC_FLUSH16(); }
+        while (sym >= start + 3) { start += 3; bits += 3u << nbit; nbit += 2; }
+        bits += (sym - start) << nbit; nbit += 2;
+        if (nbit > 16) { ZN_NC_FLUSH16(); nbit -= 16; }
+      }
+      {
+        int c = (int)zn_trl(normv, sym); sym++;
+        const int mx = (2 * threshold - 1) - remaining;
+        remaining -= c;
+        c++;
+        if (c >= threshold) c += mx;
+        bits += (uint32_t)c << nbit; nbit += nb_bits; nbit -= (c < mx);
+        prev0 = (c == 1);
+        if (remaining < 1) return -1;
+        while (remaining < threshold) { nb_bits--; threshold >>= 1; }
+      }
+      if (nbit > 16) { ZN_NC_FLUSH16(); nbit -= 16; }
+    }
+    if (remaining != 1) return -1;
+    if (lane == 0) { dst[off] = (uint8_t)bits; dst[off + 1] = (uint8_t)(bits >> 8); }
+    off += (uint32_t)(nbit + 7) / 8u;
+#undef ZN_NC_FLUSH16
+  }
+  if (nw <= 2) return 0;
+
+  // ---- FSE_buildCTable, lane-parallel: lane = table position (spread, state table) and lane = weight value (transforms) ----
+  uint32_t statev, ttnb, ttfs;
+  {
+    const uint32_t mask = size - 1u, stepc = (size >> 1) + (size >> 3) + 3u;
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
+    uint32_t cum = 0, run = 0, symj = 0;            // cum: Σ norm of the weight values below this lane's
+    for (uint32_t s = 0; s < 13u; s++) { const uint32_t ns = zn_trl(normv, s); cum += (lane > s) ? ns : 0u; run += ns; symj += (run <= lane) ? 1u : 0u; }
+    if (lane < size) S->cell[(lane * stepc) & mask] = (uint8_t)symj;       // the j-th visited cell belongs to the j-th entry in symbol order
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t cs = (lane < size) ? (uint32_t)S->cell[lane] : 255u;
+    uint32_t idx = 0;
+    for (uint32_t s = 0; s < 13u; s++) {
+      const uint64_t m = __ballot(cs == s);
+      const uint32_t c0 = zn_trl(cum, s);
+      if (cs == s) idx = c0 + (uint32_t)__popcll(m & lt);
+    }
+    if (lane < size) S->state[idx] = (uint16_t)(size + lane);
+    __builtin_amdgcn_wave_barrier();
+    statev = (lane < size) ? (uint32_t)S->state[lane] : 0u;
+    const uint32_t f = normv;
+    if (f == 0) { ttnb = ((tl + 1u) << 16) - size; ttfs = 0; }
+    else if (f == 1) { ttnb = (tl << 16) - size; ttfs = cum - 1u; }
+    else { const uint32_t mbo = tl - zn_hb32(f - 1u); ttnb = (mbo << 16) - (f << mbo); ttfs = cum - f; }
+  }
+
+  // ---- FSE_compress_usingCTable: two states, weights walked backwards, everything wave-uniform ----
+  uint32_t pk = 0;                                  // lane l < 32: weights 8l … 8l+7 as nibbles
+  if (lane < 32u) for (uint32_t k = 0; k < 8u; k++) pk |= ((uint32_t)S->weights[8u * lane + k] & 15u) << (4u * k);
+  uint64_t acc = 0; uint32_t nacc = 0, widx = 0, outv = 0;
+#define ZN_TW(i_) ((zn_trl(pk, (i_) >> 3) >> (4u * ((i_) & 7u))) & 15u)
+#define ZN_TEMIT(v_, nb_) do { const uint32_t n_ = (nb_); acc |= (uint64_t)((v_) & ((1u << n_) - 1u)) << nacc; nacc += n_; \
+    if (nacc >= 32u) { outv = (lane == widx) ? (uint32_t)acc : outv; widx++; acc >>= 32; nacc -= 32u; } } while (0)
+#define ZN_TINIT(y_) ({ const uint32_t t_ = zn_trl(ttnb, (y_)); const uint32_t nb_ = (t_ + (1u << 15)) >> 16; const uint32_t v_ = (nb_ << 16) - t_; \
+    zn_trl(statev, (uint32_t)((int)(v_ >> nb_) + (int)zn_trl(ttfs, (y_))) & 63u); })
+#define ZN_TENC(st_, y_) do { const uint32_t nb_ = ((st_) + zn_trl(ttnb, (y_))) >> 16; ZN_TEMIT((st_), nb_); \
+    st_ = zn_trl(statev, (uint32_t)((int)((st_) >> nb_) + (int)zn_trl(ttfs, (y_))) & 63u); } while (0)
+  uint32_t i = nw, s1, s2;
+  if (nw & 1u) { i--; s1 = ZN_TINIT(ZN_TW(i)); i--; s2 = ZN_TINIT(ZN_TW(i)); i--; { const uint32_t y = ZN_TW(i); ZN_TENC(s1, y); } }
+  else         { i--; s2 = ZN_TINIT(ZN_TW(i)); i--; s1 = ZN_TINIT(ZN_TW(i)); }
+  while (i > 0) {
+    i--; { const uint32_t y = ZN_TW(i); ZN_TENC(s2, y); }
+    i--; { const uint32_t y = ZN_TW(i); ZN_TENC(s1, y); }
+  }
+  ZN_TEMIT(s2, tl); ZN_TEMIT(s1, tl);
+  ZN_TEMIT(1u, 1u);
+  const uint32_t c = 4u * widx + (nacc + 7u) / 8u;
+  if (nacc) outv = (lane == widx) ? (uint32_t)acc : outv;
+#undef ZN_TW
+#undef ZN_TEMIT
+#undef ZN_TINIT
+#undef ZN_TENC
+  if (c > cap - off) return 1000;                   // longer than any description huff0 would keep (needs < maxSV/2 ≤ 127)
+  for (uint32_t b = 0; b < 4u; b++) if (4u * lane + b < c) dst[off + 4u * lane + b] = (uint8_t)(outv >> (8u * b));
+  return (int)(off + c);
+}
+
+// HUF_writeCTable by one wave: S->weights / S->wcount (+ the same histogram, wave-uniform, in wc) -> S->hdr.
+// Returns the header size, or -1 (the caller stores the plane raw).  S->hdr is complete after the caller's next barrier.
+__device__ inline int zn_wave_write_ctable(ZnTabScratch* S, uint32_t max_sv, const uint32_t (&wc)[13], uint32_t lane) {
+  const int h = zn_wave_compress_weights(S, S->hdr + 1, 140, wc, max_sv, lane);
+  if (h < 0) return -1;
+  if (h > 1 && (uint32_t)h < max_sv / 2u) { if (lane == 0) S->hdr[0] = (uint8_t)h; return h + 1; }
+  if (max_sv > 128u) return -1;
+  if (lane == 0) S->hdr[0] = (uint8_t)(128u + (max_sv - 1u));
+  for (uint32_t n = 2u * lane; n < max_sv; n += 128u) {
+    const uint32_t w0 = S->weights[n], w1 = (n + 1u < max_sv) ? (uint32_t)S->weights[n + 1u] : 0u;
+    S->hdr[n / 2u + 1u] = (uint8_t)((w0 << 4) + w1);
+  }
+  return (int)(((max_sv + 1u) / 2u) + 1u);
+}
