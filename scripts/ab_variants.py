@@ -82,6 +82,11 @@ VARIANTS = {
     "o2": (None, ["-O2"]),
     "d44c": (None, ["-DZN_F_DELTA0=44", "-DZN_F_DELTA_MAX=44"]),
     "dmax88": (None, ["-DZN_F_DELTA_MAX=88"]),
+    "pp3": (None, ["-DZN_F_PRIO_PARSE=3"]),
+    "pp2": (None, ["-DZN_F_PRIO_PARSE=2"]),
+    "pf3": (None, ["-DZN_F_PRIO_FILL=3"]),
+    "pp3f3": (None, ["-DZN_F_PRIO_PARSE=3", "-DZN_F_PRIO_FILL=3"]),
+    "pp3f1": (None, ["-DZN_F_PRIO_PARSE=3", "-DZN_F_PRIO_FILL=1"]),
     "ps2": (None, ["-DZN_F_PRIO_SYNC=2"]),
     "ps3": (None, ["-DZN_F_PRIO_SYNC=3"]),
     "ps0": (None, ["-DZN_F_PRIO_SYNC=0"]),
@@ -136,7 +141,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0")
+ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
 
 
 def run(names):

@@ -116,6 +116,12 @@
 #ifndef ZN_F_PRIO_WRITE
 #define ZN_F_PRIO_WRITE 3
 #endif
+#ifndef ZN_F_PRIO_PARSE          // the tree descriptions at the head of a workgroup (every wave parses one; the workgroup waits for the slowest)
+#define ZN_F_PRIO_PARSE 0
+#endif
+#ifndef ZN_F_PRIO_FILL           // the LUT fill of a chunk
+#define ZN_F_PRIO_FILL 0
+#endif
 #if (ZN_F_PRIO_SYNC || ZN_F_PRIO_COUNT || ZN_F_PRIO_WRITE) && !defined(ZN_SIMT_EMULATOR)
 #define ZN_PRIO(v) __builtin_amdgcn_s_setprio(v)
 #else
@@ -895,6 +901,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
   ZN_PT(0);   // metadata
 
   // ---- wave j: is chunk j ours, and if it has a Huffman plane, its tree description ----
+  if (ZN_F_PRIO_PARSE) ZN_PRIO(ZN_F_PRIO_PARSE);
   if (wave < nc) {
     int h = -1; uint32_t nhuf = 0;
     bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
@@ -915,6 +922,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     }
     if (lane == 0) { L.st[wave] = st; L.what[wave] = elig ? (uint32_t)(h + 2) : 0u; }   // 0: not ours, 1: no Huffman plane, 2+h
   }
+  if (ZN_F_PRIO_PARSE) ZN_PRIO(0);
   __syncthreads();
   ZN_PT(1);   // tree descriptions (one per wave)
 
@@ -942,8 +950,10 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       const uint8_t* src = body + h_off;
       const ZnWaveStats st = L.st[j];
       const int hs = (int)zn_uniform((uint32_t)st.hs); TL = zn_uniform(st.tl);
+      if (ZN_F_PRIO_FILL) ZN_PRIO(ZN_F_PRIO_FILL);
       if (!((ZN_F_ABL & 16) && j > 0))
       zn_fused_fill_luts(L, tid, TL, j, zn_uniform(st.lmin));
+      if (ZN_F_PRIO_FILL) ZN_PRIO(0);
       // jump table → this wave's stream
       const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
       const uint32_t l1 = zn_uniform(zn_ld16(js)), l2 = zn_uniform(zn_ld16(js + 2)), l3 = zn_uniform(zn_ld16(js + 4));
