@@ -136,6 +136,23 @@ __device__ inline int zn_wave_fse_weights(const ZnWaveHdr& H, uint32_t isz, uint
   ZN_WTAKE(tl, s2);
   if (pos < 0) return -1;
   int o = 0;
+  // Fast part: eight weights a round while the stream still holds the 48 bits they can take at most (no end tests inside; the two
+  // states' look-ups are independent and issue back to back; the eight nibbles are collected in a scalar and enter the vector
+  // register once).  The tail below finishes with the end tests of FSE_decompress_usingDTable.
+  while (pos >= 48 && o + 8 <= 254) {
+    if (avail < 48) ZN_WREFILL();
+    uint32_t sacc = 0, used = 0;
+#define ZN_WFAST2(k_) do { const uint32_t e1_ = zn_rl(entry, s1 & 63u), e2_ = zn_rl(entry, s2 & 63u); \
+      sacc |= ((e1_ & 0xFu) << (8 * (k_))) | ((e2_ & 0xFu) << (8 * (k_) + 4)); \
+      const uint32_t n1_ = (e1_ >> 8) & 0xFFu, n2_ = (e2_ >> 8) & 0xFFu; \
+      const uint32_t v1_ = (uint32_t)((win >> 1) >> (63u - n1_)); win <<= n1_; \
+      const uint32_t v2_ = (uint32_t)((win >> 1) >> (63u - n2_)); win <<= n2_; \
+      s1 = (e1_ >> 16) + v1_; s2 = (e2_ >> 16) + v2_; used += n1_ + n2_; } while (0)
+    ZN_WFAST2(0); ZN_WFAST2(1); ZN_WFAST2(2); ZN_WFAST2(3);
+#undef ZN_WFAST2
+    wv = (lane == ((uint32_t)o >> 3)) ? sacc : wv;
+    avail -= (int32_t)used; pos -= (int32_t)used; o += 8;
+  }
   for (;;) {
     if (o >= 254) return -1;
     { const uint32_t e = zn_rl(entry, s1 & 63u); ZN_WPUT(e); uint32_t v; ZN_WTAKE((e >> 8) & 0xFFu, v); s1 = (e >> 16) + v; }
@@ -162,6 +179,8 @@ struct ZnWaveStats { int hs; uint32_t nsym, tl, lmin, dom; };   // dom: code spa
 //   sh_rank_start[14]: first LUT cell of each weight class, [13] = total cells;
 //   sh_sym_start[14]: first symlist index of each weight class; sh_cell: 64 bytes scratch.
 // Returns hs < 0 on malformed input.
+// (A real function: its LDS pointers arrive as generic pointers — FLAT loads and stores.  Measured in round 3: telling it that they are
+//  LDS (ds_ operations, which queue behind the decode passes of the CU's other workgroups) costs 1 % on bf16; inlining it gains 0.4 %.)
 __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t csize, const uint8_t* body_end, uint32_t lane,
                                                  uint8_t* sh_w, uint8_t* sh_symlist, uint32_t* sh_rank_start,
                                                  uint32_t* sh_sym_start, uint8_t* sh_cell) {
