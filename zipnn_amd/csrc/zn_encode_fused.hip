@@ -315,12 +315,14 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
       const uint32_t nb = (sym <= max_sv) ? (uint32_t)L.S.nbits[sym] : 0xFFu;
       const uint32_t w = (sym < max_sv) ? (nb ? huff_log + 1u - nb : 0u) : 0xFFu;     // the last symbol's weight is implied
       if (sym < max_sv) L.S.weights[sym] = (uint8_t)w;
+      uint32_t val = 0;
       for (uint32_t v = 0; v < 13u; v++) {
         const uint64_t m = __ballot(nb == v);
-        if (nb == v) L.S.vals[sym] = (uint16_t)((uint32_t)L.S.val_rank[v] + run[v] + (uint32_t)__popcll(m & lt));
+        val = (nb == v) ? (uint32_t)L.S.val_rank[v] + run[v] + (uint32_t)__popcll(m & lt) : val;
         run[v] += (uint32_t)__popcll(m);
         wc[v] += (uint32_t)__popcll(__ballot(w == v));
       }
+      if (nb <= 12u) L.S.vals[sym] = (uint16_t)val;
     }
     for (uint32_t v = 0; v < 13u; v++) if (lane == v) L.S.wcount[v] = wc[v];
     if (lane == 13u) L.S.wcount[13] = 0;

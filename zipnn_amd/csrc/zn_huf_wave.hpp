@@ -251,11 +251,13 @@ __device__ inline ZnWaveStats zn_wave_read_stats(const uint8_t* src, uint32_t cs
   const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
   for (uint32_t q = 0; q < 256u; q += 64u) {
     const uint32_t s = q + lane; const uint32_t w = (s < nsym) ? sh_w[s] : 0u;
+    uint32_t at = 0;                                   // (the position is selected class by class, the byte stored once: one LDS store a round, not twelve predicated ones)
     for (uint32_t v = 1; v <= 12; v++) {
       const uint64_t m = __ballot(w == v);
-      if (w == v) sh_symlist[ss[v] + run[v] + (uint32_t)__popcll(m & lt)] = (uint8_t)s;
+      at = (w == v) ? ss[v] + run[v] + (uint32_t)__popcll(m & lt) : at;
       run[v] += (uint32_t)__popcll(m);
     }
+    if (w != 0u) sh_symlist[at] = (uint8_t)s;
   }
   __builtin_amdgcn_wave_barrier();
   ZN_WT(15);   // canonical order
