@@ -54,6 +54,23 @@ EDGE = [("skew", 4 * C, 1, 1, 10, 128 * KB, 8), ("skew", 4 * C, 2, 0, 10, C, 4),
         ("burst16", 8 * C, 2, 0, 10, C, 8), ("u11", 8 * C, 2, 1, 10, C, 8), ("burst16", 3 * 65536, 2, 0, 10, 65536, 3)]
 
 
+@pytest.mark.gpu
+def test_tree_descriptions_written_by_the_wave_on_hardware(lib):
+    """The encoder's table kernel writes the tree description with the whole wave (v_readlane + scalar ALU chain,
+    zn_wave_write_ctable): 236 planes of different statistics — FSE-coded weights, raw 4-bit weights, the secondary
+    normalisation, equal weights, descriptions huff0 gives up on — frame identical to the oracle's (the serial
+    HUF_writeCTable), and decoded back by the fused kernel, whose parser reads what the wave wrote."""
+    from test_kernels_simt import _tree_description_planes
+    chunk = 16384
+    d = _tree_description_planes(chunk)
+    want = O.compress_frame(HDR, d, 1, 0, 10, chunk, threads=4)
+    got = bytes(lib.compress(HDR, d, 1, 0, 10, chunk, 0.95))
+    assert got == want
+    assert "zn_k_encode_tables" in lib.last_kernels()
+    assert bytes(lib.decompress(got[32:], 1, 0, 10, chunk, len(d))) == d
+    assert "zn_k_decode_fused" in lib.last_kernels()
+
+
 @pytest.mark.parametrize("case", EDGE, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
 def test_fused_kernels_on_hostile_distributions(lib, case):
     """1-bit codes, tiles far denser than the stream average (staging buffer flushed in lane groups), 11-bit

@@ -685,13 +685,8 @@ def _dyadic_plane(lengths, absent, chunk, seed):
     return rng.permutation(plane).tobytes()
 
 
-def test_tree_descriptions_written_by_the_wave_match_the_oracle(simt_lib):
-    """The fused table kernel writes the tree description with the whole wave (zn_wave_write_ctable); the oracle is the
-    serial statement of HUF_writeCTable.  Planes with different statistics, frames compared byte for byte; the inputs
-    are shown to reach the FSE form, the raw 4-bit form and the secondary normalisation (FSE_normalizeM2: codes
-    whose weight classes hold one symbol each, found by search over weight histograms with the oracle)."""
-    from zipnn_amd import sharding
-    chunk = 16384
+def _tree_description_planes(chunk=16384):
+    """Planes (one per chunk, P = 1) that take the tree description through its forms: see the test below."""
     rng = np.random.default_rng(9)
     parts = [_varied_planes(180, chunk, 5)]
     for k in (7, 8, 9, 10, 11):                                      # lengths 1, 2, …, k, k with a few unused values: reaches M2
@@ -703,7 +698,22 @@ def test_tree_descriptions_written_by_the_wave_match_the_oracle(simt_lib):
         A = int(rng.integers(3, 40)); lo = int(rng.integers(0, 90))
         p = rng.uniform(0.2, 1.0, A) ** float(rng.uniform(1, 4)); p /= p.sum()
         parts.append((lo + rng.choice(A, size=chunk, p=p)).astype(np.uint8).tobytes())
-    d = b"".join(parts)
+    # every weight the same (HUF_compressWeights returns 1): 16 and 128 values equally often take the raw 4-bit form; all 256 (more than
+    # 128 weights, no FSE form) make HUF_writeCTable fail — the plane is stored; and a code with one symbol per weight class (returns 0)
+    for A in (16, 128, 256):
+        parts.append(rng.permutation(np.repeat(np.arange(A, dtype=np.uint8), chunk // A)).tobytes())
+    parts.append(_dyadic_plane([1, 2, 3, 4, 5, 6, 7, 8, 8], 0, chunk, 3))
+    return b"".join(parts)
+
+
+def test_tree_descriptions_written_by_the_wave_match_the_oracle(simt_lib):
+    """The fused table kernel writes the tree description with the whole wave (zn_wave_write_ctable); the oracle is the
+    serial statement of HUF_writeCTable.  Planes with different statistics, frames compared byte for byte; the inputs
+    are shown to reach the FSE form, the raw 4-bit form and the secondary normalisation (FSE_normalizeM2: codes
+    whose weight classes hold one symbol each, found by search over weight histograms with the oracle)."""
+    from zipnn_amd import sharding
+    chunk = 16384
+    d = _tree_description_planes(chunk)
     nchunks = len(d) // chunk
     m2_before = O.lib().zo_debug_m2_calls()
     want = O.compress_frame(HDR, d, 1, 0, 10, chunk, threads=1)
