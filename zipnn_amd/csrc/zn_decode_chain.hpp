@@ -274,7 +274,32 @@ __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& 
     wm1 += cnt;
     ZN_STEP_FENCE();
   };
-  zn_static_for<0, TF>([&](auto I) { constexpr int t = decltype(I)::v; if (t < nfull) { put(zn_rec_cnt<t>(rec), zn_rec_sym<t, DENSE>(rec)); hook(I); } });
-  zn_static_for<0, TB>([&](auto I) { constexpr int b = decltype(I)::v; if (b < nbnd) { put(zn_rec_cnt<TF + b>(rec), zn_rec_sym<TF + b, DENSE>(rec)); hook(ZnIdx<TF + b>{}); } });
+#ifndef ZN_F_P2_PAIRS
+#define ZN_F_P2_PAIRS 1       // dense records: the two steps of a register leave together
+#endif
+  if constexpr (DENSE && ZN_F_P2_PAIRS) {
+    // The two steps that share a record register (≤ 2 + 2 bytes) are written as ONE group: the second step's bytes are moved down
+    // next to the first's (one v_perm_b32, selector by the first step's count), one pair of dwords instead of two — half the
+    // ds_or_b32 of a dense stream's compaction, whose LDS time they are.  A slot that did not run in this pass (beyond nfull /
+    // nbnd: its count byte is stale, its half of the register zero or stale) counts zero bytes and is dropped by the selector.
+    zn_static_for<0, (TF + TB + 1) / 2>([&](auto R_) {
+      constexpr int r = decltype(R_)::v, a = 2 * r, b = 2 * r + 1;
+      const bool va = a < TF ? a < nfull : (a - TF) < nbnd;                                       // (uniform)
+      const bool vb = b < TF + TB && (b < TF ? b < nfull : (b - TF) < nbnd);
+      if (va || vb) {
+        uint32_t ca = 0, cb = 0;
+        if (va) ca = zn_rec_cnt<a>(rec);
+        if constexpr (b < TF + TB) { if (vb) cb = zn_rec_cnt<b>(rec); }
+        const uint32_t sr = zn_rec_s<r>(rec);
+        const uint32_t sel = (ca >= 2u) ? 0x03020100u : (ca == 1u) ? 0x0c030200u : 0x0c0c0302u;
+        put(ca + cb, __builtin_amdgcn_perm(sr, sr, sel));
+        if (va) hook(ZnIdx<a>{});
+        if constexpr (b < TF + TB) { if (vb) hook(ZnIdx<b>{}); }
+      }
+    });
+  } else {
+    zn_static_for<0, TF>([&](auto I) { constexpr int t = decltype(I)::v; if (t < nfull) { put(zn_rec_cnt<t>(rec), zn_rec_sym<t, DENSE>(rec)); hook(I); } });
+    zn_static_for<0, TB>([&](auto I) { constexpr int b = decltype(I)::v; if (b < nbnd) { put(zn_rec_cnt<TF + b>(rec), zn_rec_sym<TF + b, DENSE>(rec)); hook(ZnIdx<TF + b>{}); } });
+  }
 }
 
