@@ -7,5 +7,5 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 SRC="$HERE/../../zipnn_amd/csrc"
 FILES=""
 for f in "$SRC"/*.hip; do FILES="$FILES -x c++ $f"; done
-g++ -O1 -g -std=c++17 -fPIC -shared -w -I"$HERE" -DZN_SIMT_EMUL=1 $FILES -o "$HERE/libzipnn_simt.so"
+g++ -O1 -g -std=c++17 -fPIC -shared -w -I"$HERE" -DZN_SIMT_EMUL=1 ${ZN_SIMT_EXTRA:-} $FILES -o "$HERE/libzipnn_simt.so"      # (ZN_SIMT_EXTRA: -D switches of a variant under test)
 echo "built $HERE/libzipnn_simt.so"
