@@ -269,12 +269,16 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     uint64_t nzm[4];
     for (int k = 0; k < 4; k++) { nzm[k] = __ballot(cnt[k] != 0); nz_total += (uint32_t)__popcll(nzm[k]); }
     uint32_t rank[4] = {0, 0, 0, 0};
+    // one key per symbol — count << 8 | 255 - symbol (a plane of a fused chunk has ≤ 2^17 bytes) —: "u sorts before sym" is key(u) > key(sym),
+    // one compare and one add-with-carry per pair
+    uint32_t key[4];
+    for (int k = 0; k < 4; k++) key[k] = (cnt[k] << 8) | (255u - (lane + 64u * (uint32_t)k));
     for (int k2 = 0; k2 < 4; k2++) {
       uint64_t m = nzm[k2];
       while (m) {
         const uint32_t j = (uint32_t)__builtin_ctzll(m); m &= m - 1;
-        const uint32_t cu = (uint32_t)__builtin_amdgcn_readlane((int)cnt[k2], (int)j), u = j + 64u * (uint32_t)k2;
-        for (int k = 0; k < 4; k++) { const uint32_t sym = lane + 64u * (uint32_t)k; rank[k] += (cu > cnt[k] || (cu == cnt[k] && u < sym)) ? 1u : 0u; }
+        const uint32_t ku = (uint32_t)__builtin_amdgcn_readlane((int)key[k2], (int)j);
+        for (int k = 0; k < 4; k++) rank[k] += (ku > key[k]) ? 1u : 0u;
       }
     }
     const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64u - lane));
@@ -289,14 +293,11 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
   }
   __syncthreads();
   ZN_PT(2);   // counts + sort
-  // serial: the tree over the sorted leaves, code lengths, first code value of every length
-  if (lane == 0) {
-    const uint32_t hl0 = zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1);
-    L.hl = zn_huf_tree_from_sorted(&L.S, L.nodes, (int)nz_total - 1, hl0);
-  }
+  // the tree over the sorted leaves (serial on lane 0: the merge and the internal depths), code lengths and the first code value of
+  // every length (lane-parallel): zn_wave_tree_from_sorted
+  const uint32_t huff_log = zn_wave_tree_from_sorted(&L.S, L.nodes, (int)nz_total - 1, zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1), lane);
   __syncthreads();
   ZN_PT(5);   // tree + code lengths
-  const uint32_t huff_log = L.hl;
   // parallel: code length of every symbol (sorted position → symbol), zero beyond the highest symbol
   for (int k = 0; k < 4; k++) {
     const uint32_t i = lane + 64u * (uint32_t)k;

@@ -350,6 +350,67 @@ __device__ inline int zn_huf_write_ctable(ZnTabScratch* S, uint32_t max_sv, uint
 }
 
 // ---------------------------------------------------------------------------
+// zn_huf_tree_from_sorted by ONE WAVE (the fused table kernel; round 3): what is serial in it — the two-queue merge and the depths
+// of the internal nodes, one step per symbol each — stays on lane 0; the three other walks over the symbols (sentinel counts of the
+// internal nodes, depths of the leaves, the histogram of code lengths) are lane-parallel.  For fp8 / fp16 planes (100-250 symbols
+// that occur) the serial tree was the largest part of a table job.  Same results as the serial function (tests: frames == oracle).
+// All 64 lanes call it together; `tab0` = the 513 nodes in LDS with the sorted leaves in tab0[1 ..]; returns the maximum code length.
+// ---------------------------------------------------------------------------
+__device__ inline uint32_t zn_wave_tree_from_sorted(ZnTabScratch* S, ZnHNode* tab0, int non_null, uint32_t max_nb_bits, uint32_t lane) {
+  const int START = 256;
+  ZnHNode* node = tab0 + 1;
+  const int root = START + non_null - 1;
+  for (int n = START + (int)lane; n <= root; n += 64) node[n].count = 1u << 30;      // internal nodes not made yet: larger than any sum
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    int low_s = non_null, node_nb = START, low_n = START;
+    node[node_nb].count = node[low_s].count + node[low_s - 1].count;
+    node[low_s].parent = node[low_s - 1].parent = (uint16_t)node_nb;
+    node_nb++; low_s -= 2;
+    tab0[0].count = 1u << 31;   // node[-1]: barrier below the smallest leaf
+    while (node_nb <= root) {
+      const int n1 = (node[low_s].count < node[low_n].count) ? low_s-- : low_n++;
+      const int n2 = (node[low_s].count < node[low_n].count) ? low_s-- : low_n++;
+      node[node_nb].count = node[n1].count + node[n2].count;
+      node[n1].parent = node[n2].parent = (uint16_t)node_nb;
+      node_nb++;
+    }
+    node[root].nb = 0;
+    for (int n = root - 1; n >= START; n--) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int n = (int)lane; n <= non_null; n += 64) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
+  __builtin_amdgcn_wave_barrier();
+  uint32_t largest = node[non_null].nb;                                // (the smallest count has the longest code)
+  __builtin_amdgcn_wave_barrier();                                     // (every lane has read it before lane 0 may change it)
+  if (largest > max_nb_bits) {                                         // HUF_setMaxHeight: rare, serial
+    if (lane == 0) S->rk_base[0] = zn_huf_limit_height(S, node, (uint32_t)non_null, max_nb_bits);
+    __builtin_amdgcn_wave_barrier();
+    largest = S->rk_base[0];
+  }
+  // code lengths' histogram (ballots) -> first code value of every length
+  uint32_t per_rank[ZN_HUF_LOG_MAX + 1];
+  for (uint32_t v = 0; v <= ZN_HUF_LOG_MAX; v++) per_rank[v] = 0;
+  for (int q = 0; q < 256; q += 64) {
+    const int n = q + (int)lane;
+    const uint32_t nb = (n <= non_null) ? (uint32_t)node[n].nb : 0xFFu;
+    for (uint32_t v = 0; v <= ZN_HUF_LOG_MAX; v++) per_rank[v] += (uint32_t)__popcll(__ballot(nb == v));
+  }
+  {
+    uint32_t mn = 0, mine = 0, pr = per_rank[0];
+    for (int n = (int)ZN_HUF_LOG_MAX; n > 0; n--) {
+      const uint32_t vr = ((uint32_t)n <= largest) ? mn : 0u;
+      if ((uint32_t)n <= largest) { mn = (mn + per_rank[n]) & 0xFFFFu; mn >>= 1; }
+      mine = (lane == (uint32_t)n) ? vr : mine;
+      pr = (lane == (uint32_t)n) ? per_rank[n] : pr;
+    }
+    if (lane <= ZN_HUF_LOG_MAX) { S->val_rank[lane] = (uint16_t)mine; S->per_rank[lane] = (uint16_t)pr; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return largest;
+}
+
+// ---------------------------------------------------------------------------
 // The same tree description by ONE WAVE (the fused table kernel; round 3).
 //
 // HUF_compressWeights is a serial state chain over ≤255 weights; on one lane every step is three dependent LDS round
