@@ -104,6 +104,19 @@ VARIANTS = {
     "d33c": (None, ["-DZN_F_DELTA0=33", "-DZN_F_DELTA_MAX=44"]),
     "d22c": (None, ["-DZN_F_DELTA_MAX=44"]),
     "nmis2": (None, ["-DZN_F_NMIS=2"]),
+    # round 4: wave specialisation (four decode waves + a mover per workgroup)
+    "r03": ("3c0f9d7", []),                         # the kernels of the round-3 final state
+    "nospec": (None, ["-DZN_F_SPEC=0"]),
+    "q2": (None, ["-DZN_F_MOVER_Q2=2"]),
+    "q8": (None, ["-DZN_F_MOVER_Q2=8"]),
+    "q6": (None, ["-DZN_F_MOVER_Q2=6"]),
+    "nopers": (None, ["-DZN_F_PERSIST=0"]),
+    "pers": (None, ["-DZN_F_PERSIST=1"]),         # the specialised form, one workgroup per chunk group (no persistent workgroups)
+    "sw4": (None, ["-DZN_F_SPEC_WAVES=4"]),
+    "sw5": (None, ["-DZN_F_SPEC_WAVES=5"]),         # the specialised form with 128 registers: at most three workgroups (15 waves) per CU
+    "free": (None, ["-DZN_F_ABL=96"]),              # timing only: neither side of the hand-over waits (decode waves and mover run free)
+    "freedec": (None, ["-DZN_F_ABL=32"]),           # timing only: the decode waves never wait for room
+    "freemov": (None, ["-DZN_F_ABL=64"]),           # timing only: the mover never waits for rows
 }
 
 
@@ -141,7 +154,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
+ALLD = ("r01", "r02", "r03", "nospec", "q2", "q8", "q6", "nopers", "sw4", "sw5", "pers", "free", "freedec", "freemov", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
 
 
 def run(names):

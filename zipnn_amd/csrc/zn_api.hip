@@ -334,7 +334,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if ((rc = ws_acquire(w, stream))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   w.last_K = all_k; w.last_tails = all_tail;
-  ZN_HIP(hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream));     // status + the three "left to the generic kernels" counters
+  ZN_HIP(hipMemsetAsync(d_status, 0, 8 * sizeof(uint32_t), stream));     // status + the three "left to the generic kernels" counters + the three work counters of the persistent fused kernels
   if (all_tail) ZN_HIP(hipMemsetAsync(w.buf[WS_META_A], 0, all_tail, stream));
   if (table) {
     // the previous batched call may still be reading the pinned staging: wait for it on the host

@@ -108,61 +108,113 @@ def _read_layout(filename):
     return meta, layout, 8 + n
 
 
-def load_file(filename, device="cuda:0", timings=None):
-    """Load a (possibly ZipNN-compressed) safetensors file straight onto `device`: the file's data section crosses PCIe ONCE, as it
-    lies on disk (compressed tensors compressed), through the library's pinned multi-threaded transfer; every compressed tensor is
-    then decoded by ONE batched launch (zn_decompress_batch_dev) from where its frame landed in HBM, so a file of many small tensors
-    moves at the PCIe rate and decodes at the rate of one large tensor.  -> {name: tensor}.  The batched counterpart of looping
-    SafeOpen.get_tensor (reference zipnn.py:1592-1626, scripts/zipnn_decompress_safetensors.py:75-120).
-    timings: an optional dict that receives the seconds spent mapping the file and parsing its header (`read_s`), moving the data
-    section to the device (`h2d_s`) and decoding (`decode_s`), each ended by a device sync."""
+def _contiguous_strides(shape):
+    st, acc = [], 1
+    for d in reversed(shape):
+        st.append(acc)
+        acc *= max(int(d), 1)
+    return tuple(reversed(st))
+
+
+def decode_file_on_device(filename, device, compressed_only=False, timings=None):
+    """The batched loader behind load_file and behind the plugin's read-ahead (SafeOpen.get_tensor): the file's data section
+    crosses PCIe ONCE, as it lies on disk, through the library's pinned multi-threaded transfer; every compressed tensor is then
+    decoded by ONE batched launch (zn_decompress_batch_dev) from where its frame landed in HBM into one output arena (every
+    tensor at a 256-byte boundary of it).  All frame headers are parsed from the host mapping before anything moves — one pass over
+    the mmap with zipnn.fast_frame_params, no ZipNN object and no device read-back per tensor — and the bodies and destinations
+    go to the library as plain addresses.  -> {name: tensor} (with compressed_only: the compressed tensors alone), or None when the
+    container names a dtype this parser does not know.
+    The uncompressed tensors of the file are COPIED out of the uploaded section, so that nothing keeps the compressed bytes
+    resident once the decode has run; the decoded tensors share the arena (they live and die together in a model load; set
+    ZIPNN_AMD_LOAD_ARENA=0 for one allocation per tensor)."""
+    import contextlib
     import mmap
     import time
     from . import _capi, codec
+    from .zipnn import fast_frame_params
     dev = torch.device(device)
     lay = _read_layout(filename)
     if lay is None:
-        return _load_file_per_tensor(filename, dev, timings)
+        return None
     lib = _capi.lib()
     t0 = time.perf_counter()
     metadata, layout, data_start = lay
     infos = get_compressed_tensors_metadata(dict(metadata))
-    out, items, meta = {}, [], []
     with open(filename, "rb") as f:
         size = os.fstat(f.fileno()).st_size
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
-    t1 = time.perf_counter()
+    view = memoryview(mm) if mm is not None else None
+    head_len = 32 + 1 + 9 * 255                        # header + the largest shape extension (zipnn._frame_head)
+    use_arena = os.environ.get("ZIPNN_AMD_LOAD_ARENA", "1") != "0"
     try:
-        blob = codec.to_device(lib, memoryview(mm)[data_start:], dev) if (mm is not None and size > data_start) else torch.empty(0, dtype=torch.uint8, device=dev)
+        # ---- host side: one pass over the mapping ----
+        plan, total = [], 0                            # (name, lo + body_off, hi, fp, arena offset)
+        for name, (dt, shape, lo, hi) in layout.items():
+            if name in infos:
+                fp = fast_frame_params(view[data_start + lo: data_start + min(hi, lo + head_len)])
+                plan.append((name, lo + fp[0], hi, fp, total))
+                total += (fp[5] + 255) & ~255
+        t1 = time.perf_counter()
+        blob = codec.to_device(lib, view[data_start:], dev) if (view is not None and size > data_start) else torch.empty(0, dtype=torch.uint8, device=dev)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         t2 = time.perf_counter()
-        head_len = 32 + 1 + 9 * 8                     # header + the shape extension of up to 8 dimensions (zipnn._frame_head)
+    finally:
+        if view is not None:
+            view.release()
+        if mm is not None:
+            with contextlib.suppress(BufferError):     # (a traceback may still hold slices of the mapping: the real error must not be replaced by this one)
+                mm.close()
+    out = {}
+    if plan:
+        arena = torch.empty(max(total, 16), dtype=torch.uint8, device=dev) if use_arena else None
+        outs = [None] * len(plan) if use_arena else [torch.empty(fp[5], dtype=torch.uint8, device=dev) for (_, _, _, fp, _) in plan]
+        base_in, base_out = blob.data_ptr(), (arena.data_ptr() if use_arena else 0)
+        with torch.cuda.device(dev) if dev.type == "cuda" else codec._nullctx():
+            lib.decompress_batch_dev(((base_in + b0, hi - b0, fp[1], fp[2], fp[3], fp[4], fp[5],
+                                       ((base_out + off) if use_arena else outs[i].data_ptr()) if fp[5] else 0)
+                                      for i, (_, b0, hi, fp, off) in enumerate(plan)), codec._stream_handle(blob), True)
+        # (views while the kernels run: one typed view of the arena per dtype, one as_strided per tensor)
+        typed = {}
+        for i, (name, _, _, fp, off) in enumerate(plan):
+            n, dt, shape = fp[5], fp[6], tuple(fp[7]) if fp[7] is not None else None
+            if n == 0:
+                out[name] = torch.empty(shape if shape is not None else (0,), dtype=dt, device=dev)
+                continue
+            if use_arena:
+                ta = typed.get(dt)
+                if ta is None:
+                    ta = typed[dt] = arena.view(dt)
+                es = ta.element_size()
+                shp = shape if shape is not None else (n // es,)
+                out[name] = torch.as_strided(ta, shp, _contiguous_strides(shp), off // es)
+            else:
+                out[name] = outs[i].view(dt).reshape(shape) if shape is not None else outs[i].view(dt)
+    if not compressed_only:
         for name, (dt, shape, lo, hi) in layout.items():
             if name not in infos:
-                piece = blob[lo:hi]
-                es = torch.empty(0, dtype=dt).element_size()
-                if (piece.data_ptr() % es) != 0:      # (a view needs the element alignment the file did not give this tensor)
-                    piece = piece.clone()
-                out[name] = piece.view(dt).reshape(shape) if hi > lo else torch.empty(shape, dtype=dt, device=dev)
-                continue
-            # the frame header is parsed from the HOST mapping (no device read-back per tensor); the body stays where it landed
-            znn = ZipNN(input_format="torch", bytearray_dtype=COMPRESSED_DTYPE, method=COMPRESSION_METHOD)
-            fp = znn.frame_params(memoryview(mm)[data_start + lo: data_start + min(hi, lo + head_len + 9 * 255)])
-            items.append((blob[lo + fp["body_off"]:hi], fp["num_buf"], fp["bits_mode"], fp["bytes_mode"], fp["chunk"], fp["orig_size"]))
-            meta.append((name, fp["torch_dtype"], fp["shape"]))
-    finally:
-        if mm is not None:
-            mm.close()
-    flats = codec.decompress_device_batch(lib, items)
-    for (name, dtype, shape), flat in zip(meta, flats):
-        out[name] = flat.view(dtype).reshape(shape) if flat.numel() else torch.empty(shape, dtype=dtype, device=dev)
+                # (a copy, not a view: one surviving int tensor would otherwise pin the whole uploaded section — all compressed frames — in HBM)
+                out[name] = blob[lo:hi].clone().view(dt).reshape(shape) if hi > lo else torch.empty(shape, dtype=dt, device=dev)
     if timings is not None:
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         t3 = time.perf_counter()
-        timings.update(read_s=t1 - t0, h2d_s=t2 - t1, decode_s=t3 - t2, compressed_tensors=len(items), h2d_bytes=int(blob.numel()),
-                       compressed_bytes=int(sum(it[0].numel() for it in items)), decoded_bytes=int(sum(it[5] for it in items)))
+        timings.update(read_s=t1 - t0, h2d_s=t2 - t1, decode_s=t3 - t2, compressed_tensors=len(plan), h2d_bytes=int(blob.numel()),
+                       compressed_bytes=int(sum(hi - b0 for (_, b0, hi, _, _) in plan)), decoded_bytes=int(sum(p[3][5] for p in plan)))
+    return out
+
+
+def load_file(filename, device="cuda:0", timings=None):
+    """Load a (possibly ZipNN-compressed) safetensors file straight onto `device` -> {name: tensor}: one transfer of the file's data
+    section, one batched decode (decode_file_on_device).  The batched counterpart of looping SafeOpen.get_tensor (reference
+    zipnn.py:1592-1626, scripts/zipnn_decompress_safetensors.py:75-120) — and what SafeOpen itself uses behind get_tensor for a
+    device target.  timings: an optional dict that receives the seconds spent mapping the file and parsing every header (`read_s`),
+    moving the data section to the device (`h2d_s`) and decoding (`decode_s`), each ended by a device sync."""
+    dev = torch.device(device)
+    out = decode_file_on_device(filename, dev, timings=timings)
+    if out is None:
+        return _load_file_per_tensor(filename, dev, timings)
+    # (file order, as safetensors' own load_file returns it)
     return out
 
 

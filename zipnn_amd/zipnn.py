@@ -496,6 +496,22 @@ class ZipNN:
 _HEAD_WINDOW = HEADER_LEN + 1 + 9 * 8       # header + the shape extension of a tensor of up to 8 dimensions
 
 
+def fast_frame_params(mv):
+    """What ZipNN.frame_params returns, straight from the head of one frame (host bytes: header + shape extension) and without
+    a ZipNN instance — the batched loaders parse hundreds of frames per file (same fields as ZipNN._retrieve_header,
+    reference zipnn.py:396-438).  -> (body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape)"""
+    if mv[0] != 0x5A or mv[1] != 0x4E:
+        raise ValueError("Header should start with ZN")
+    dt = dtype_from_code(mv[15])
+    chunk = 1 << mv[14]
+    if dt.planes == 1 and chunk > FP8_CHUNK_CAP:
+        chunk = FP8_CHUNK_CAP
+    shape, ext = None, 0
+    if mv[8] in (EnumFormat.TORCH.value, EnumFormat.NUMPY.value):
+        shape, ext = unpack_shape(mv[HEADER_LEN:])
+    return (HEADER_LEN + ext, dt.planes, mv[6], mv[5], chunk, int.from_bytes(mv[16:24], "little"), dt.torch, shape)
+
+
 def _frame_head(frame):
     """Header (+ shape extension) of one frame as host bytes.  A frame that lives in a tensor (possibly in HBM) is read
     with ONE small copy: a fixed window that holds the shape extension of up to 8 dimensions; the extension exists only in
@@ -521,7 +537,7 @@ def _delta_bytes(delta):
     mv = memoryview(delta)
     if mv.nbytes == 0:
         return None
-    return mv.cast("B") if mv.contiguous else memoryview(mv.tobytes())
+    return mv.cast("B") if mv.c_contiguous else memoryview(mv.tobytes())      # (cast() needs C order: a Fortran-ordered array is "contiguous" too)
 
 
 def _xor(a, b):
@@ -590,6 +606,28 @@ class SafeOpen:
         self._host = None
         self._filename, self._framework, self._kwargs = filename, framework, kwargs
         self.compressed_tensors_metadata = get_compressed_tensors_metadata(self._f.metadata())
+        self._ahead = None                 # read-ahead cache {name: decoded tensor}; False = not applicable for this file
+
+    def _read_ahead(self):
+        """Device targets: the first get_tensor of a compressed name ships the file's data section to the device ONCE and decodes
+        every compressed tensor of the file with ONE batched launch (safetensors_io.decode_file_on_device); get_tensor then
+        serves from the cache, dropping each entry as it is handed out.  A consumer that walks the file through the reference's
+        API (zipnn.py:1592-1626: one decompress per get_tensor) gets the batched path's speed.  Files larger than
+        ZIPNN_AMD_READAHEAD_BYTES (default 32 GiB; 0 switches it off) and containers the batched loader does not parse keep the
+        per-tensor path."""
+        import os
+        from . import safetensors_io
+        self._ahead = False
+        try:
+            limit = int(os.environ.get("ZIPNN_AMD_READAHEAD_BYTES", str(32 << 30)))
+            if limit <= 0 or os.path.getsize(self._filename) > limit:
+                return
+            dev = self._device if not isinstance(self._device, int) else f"cuda:{self._device}"
+            got = safetensors_io.decode_file_on_device(self._filename, dev, compressed_only=True)
+            if got is not None:
+                self._ahead = got
+        except (OSError, ValueError, KeyError):
+            self._ahead = False                # (anything odd about the container: the per-tensor path reports it properly)
 
     def _host_reader(self):
         if str(self._device) == "cpu":
@@ -603,6 +641,13 @@ class SafeOpen:
         if name not in self.compressed_tensors_metadata:
             return self._f.get_tensor(name)
         dev = "cpu" if str(self._device) == "cpu" else (self._device if not isinstance(self._device, int) else f"cuda:{self._device}")
+        if dev != "cpu":
+            if self._ahead is None:
+                self._read_ahead()
+            if self._ahead:
+                t = self._ahead.pop(name, None)
+                if t is not None:
+                    return t
         return decompress_safetensors_tensor(self._host_reader().get_tensor(name), device=dev)
 
     def get_slice(self, name):
@@ -623,6 +668,7 @@ class SafeOpen:
                 pass
 
     def __exit__(self, exc_type, exc_value, traceback):
+        self._ahead = False                    # (what was not asked for goes back to the allocator)
         self._close_host(exc_type, exc_value, traceback)
         return self._f.__exit__(exc_type, exc_value, traceback)
 
