@@ -86,6 +86,73 @@ def time_events(fn, steps):
     return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
+def rank_spread(td, device, my_ms, world):
+    """Every rank's wall milliseconds per step, gathered: {min, max, all}."""
+    mine = torch.tensor([my_ms], device=device, dtype=torch.float64)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    td.all_gather(allv, mine)
+    v = [round(float(t.item()), 4) for t in allv]
+    return {"min": min(v), "max": max(v), "all": v}
+
+
+def size_sweep(lib, codec, device, steps):
+    """Decode GB/s by tensor size (bf16, device-resident, event-timed): small tensors are bound by the ~100 us a workgroup needs per chunk
+    group and by the launch, not by HBM."""
+    out = {}
+    for mib in (64, 256, 1024):
+        n = mib << 20
+        x = make_tensor(n, device, 99 + mib)
+        flat = codec.flat_bytes(x)
+        body = codec.compress_device(lib, flat, P, ROT, BMODE, CHUNK, THR).clone()
+        dst = torch.empty(n, dtype=torch.uint8, device=device)
+        for _ in range(8):
+            codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n, out=dst, check=False)
+        d = stats(time_events(lambda: codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n, out=dst, check=False), steps))
+        c = stats(time_events(lambda: codec.compress_device(lib, flat, P, ROT, BMODE, CHUNK, THR), max(2, steps // 2)))
+        torch.cuda.synchronize()
+        out[f"{mib}MiB"] = {"decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "compress_GBps": round(n / c["avg"] / 1e6, 1),
+                            "compress_ms": round(c["avg"], 4), "exact": bool(torch.equal(dst, flat))}
+        del x, flat, body, dst
+    torch.cuda.empty_cache()
+    return out
+
+
+def multi_dev_inprocess(lib, codec, n_bytes=1 << 30):
+    """device_count() > 1 only: ONE process driving every visible GPU through the library's own fan-out (zn_decompress_multi_dev: one host
+    thread, stream and pinned pipe per device; the frame is a host buffer, the tensor ends up resident, chunk range i on device i).
+    PCIe-bound by construction (the compressed body crosses it), reported beside the per-rank numbers; never part of `value`."""
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        return None
+    try:
+        dev0 = torch.device("cuda", 0)
+        x = make_tensor(n_bytes, dev0, 777)
+        flat = codec.flat_bytes(x)
+        body = codec.compress_device(lib, flat, P, ROT, BMODE, CHUNK, THR).cpu().numpy().tobytes()
+        devices = list(range(nd))
+        parts = []
+        for i in devices:
+            off, ln = lib.multi_range(n_bytes, CHUNK, nd, i)
+            parts.append(torch.empty(max(ln, 16), dtype=torch.uint8, device=torch.device("cuda", i)))
+        for i in devices:
+            torch.cuda.synchronize(i)
+        best = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            lib.decompress_multi_dev(body, P, ROT, BMODE, CHUNK, n_bytes, devices, [t.data_ptr() for t in parts])
+            for i in devices:
+                torch.cuda.synchronize(i)
+            best = min(best, time.perf_counter() - t0)
+        ok = True
+        for i in devices:
+            off, ln = lib.multi_range(n_bytes, CHUNK, nd, i)
+            ok = ok and bool(torch.equal(parts[i][:ln].cpu(), flat[off:off + ln].cpu()))
+        return {"devices": nd, "GiB": n_bytes / (1 << 30), "seconds": round(best, 4), "GBps": round(n_bytes / best / 1e9, 2), "exact": ok,
+                "what": "zn_decompress_multi_dev from a host frame, chunk range i resident on device i (PCIe-inclusive)"}
+    except Exception as e:                                 # (never let the optional leg take the bench line down)
+        return {"devices": nd, "error": repr(e)[:300]}
+
+
 def host_info():
     """What BASELINE.md §3 wants next to every CPU number."""
     info = {"nproc": os.cpu_count() or 1, "cpu_model": None, "numa_nodes": None,
@@ -144,6 +211,8 @@ def cpu_baseline(raw, want_body):
     parity = bool(fb.size == want_body.size and np.array_equal(fb, want_body)) if want_body is not None else None
     gb = raw.size / 1e9
     out = {"value": round(gb / best_d, 3), "unit": "GB/s", "cores": t_ref, "kind": kind,
+           "huff0": "libzstd 1.4.8 substitute: the reference's FiniteStateEntropy submodule is un-vendored, its csrc/ is compiled against zstd 1.4.8's huff0 "
+                    "(same published algorithm; PyPI wheels write the tree description's low-probability counts as -1, this build as +1; both decode both)",
            "compress_GBps": round(gb / best_c, 3),
            "sample": f"the first {raw.size >> 20} MiB of the same tensor (all of it when that is its size), decompress best of {reps}, {t_ref} threads",
            "gpu_frame_equals_cpu_frame": parity, "frame_compare_bytes": int(raw.size),
@@ -158,15 +227,32 @@ def cpu_baseline(raw, want_body):
     return out
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (zipnn_amd/csrc/*, sorted by name): what profiles/traffic_pmc.json was measured on must be what runs."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "zipnn_amd", "csrc", "*"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_of(kind, n_bytes):
     """HBM bytes per decode launch of `kind` from the committed PMC pass (profiles/traffic_pmc.json: FETCH_SIZE x 2 on gfx950 +
     WRITE_SIZE, per GiB; scripts/pmc_traffic.py writes it from a rocprofv3 --pmc run of the kernels named there), scaled to this
-    size; the source file and the commit of the kernels it was measured on travel with the number."""
+    size; the source file and the digest of the kernel sources it was measured on travel with the number.  A record measured on
+    OTHER kernel sources than the ones in the tree is refused: traffic = null and the reason on the line (there is no .git on the
+    GPU box, so the check is a digest of zipnn_amd/csrc, not a commit)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic_pmc.json")) as f:
             t = json.load(f)
         e = t["decode"][kind]
-        return int(e["hbm_bytes_per_gib_launch"] * (n_bytes / (1 << 30))), {"file": "profiles/traffic_pmc.json", "from": e.get("from"), "kernels_commit": t.get("kernels_commit")}
+        src = {"file": "profiles/traffic_pmc.json", "from": e.get("from"), "kernels_commit": t.get("kernels_commit"), "csrc_sha256_16": t.get("csrc_sha256_16")}
+        now = csrc_digest()
+        if t.get("csrc_sha256_16") != now:
+            src["stale"] = f"measured on kernel sources {t.get('csrc_sha256_16')}, the tree has {now}: re-run scripts/gpu_pmc_dtypes.sh + scripts/pmc_traffic.py"
+            return None, src
+        return int(e["hbm_bytes_per_gib_launch"] * (n_bytes / (1 << 30))), src
     except Exception:
         return None, None
 
@@ -283,7 +369,8 @@ def plugin_gpt2(lib, device):
                 exact = exact and check(loaded)
                 del loaded
             res["plugin_safe_open"] = {"seconds": round(best, 4), "GBps": round(raw_bytes / best / 1e9, 2), "bit_exact": exact,
-                                       "note": "zipnn_safetensors() + safetensors.safe_open(device=cuda) + get_tensor per tensor: one decode launch set per tensor"}
+                                       "note": "zipnn_safetensors() + safetensors.safe_open(device=cuda) + get_tensor per tensor — served by the read-ahead: one transfer of "
+                                               "the data section and ONE batched decode of every compressed tensor at the first compressed name (SafeOpen._read_ahead)"}
         finally:
             safetensors.torch.safe_open, safetensors.safe_open = orig_a, orig_b
             _Z._patches_applied.pop(_Z._zipnn_safetensors, None)
@@ -397,7 +484,9 @@ def run_llama8b(args, lib, codec, device, world, rank, dist, td, sample_oracle=F
     barrier()
     c_elapsed = time.perf_counter() - t1
     exact = exact and all(bool(torch.equal(o, it[0])) for o, it in zip(outs, items))
+    rank_ms = None
     if dist:
+        rank_ms = rank_spread(td, device, elapsed / args.steps * 1e3, world)
         tt = torch.tensor([elapsed, c_elapsed, float(not exact)], device=device, dtype=torch.float64)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed, c_elapsed, bad = tt.tolist()
@@ -419,26 +508,32 @@ def run_llama8b(args, lib, codec, device, world, rank, dist, td, sample_oracle=F
                            "tensors_per_rank": len(items), "parallelism": f"chunk-range-sharded x{world}, no collectives"},
                 "compress_GBps": round(total_bytes * csteps / c_elapsed / 1e9, 2), "compress_ms_per_step": round(c_elapsed / csteps * 1e3, 3),
                 "ratio": round(c_bytes / total_bytes, 5), "bit_exact_roundtrip": exact,
-                "rank0_decode_ms": {k: round(v, 4) for k, v in d.items()},
+                "rank0_decode_ms": {k: round(v, 4) for k, v in d.items()}, "rank_ms_per_step": rank_ms,
                 "kernels": {"decompress": decode_kernels, "compress": encode_kernels}}
         if c_payload is not None:                     # (N + C) / t on rank 0's event-timed launches, as a fraction of 8 TB/s
             line["decompress_roofline_frac"] = round((total_bytes + c_payload) / (d["avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
         if world == 1 and sample_oracle:
-            # a sample of the batched bodies against the CPU oracle's frames of the same tensors: the smallest, the largest that the
-            # oracle codes in about a second, one fp8 tensor and one bf16 tensor with a ragged tail
+            # the batched bodies against the CPU oracle's frames of the same tensors: the FIRST tensor of every (size, dtype) class of the
+            # model — embedding, q/o, k/v, gate/up, down, a norm vector, as bf16 and (the linears) as fp8 — and the last tensor (lm_head)
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib as O
-            order = sorted(range(len(items)), key=lambda i: items[i][0].numel())
-            pick = {order[0], order[len(order) // 2]}
-            pick |= {next(i for i in order if items[i][1] == 1 and items[i][0].numel() >= (8 << 20))} if any(it[1] == 1 for it in items) else set()
-            pick |= {next(i for i in reversed(order) if items[i][0].numel() <= (128 << 20))}
-            same, nbytes = True, 0
-            for i in sorted(pick):
+            seen, pick = set(), []
+            for i, it in enumerate(items):
+                key = (it[0].numel(), it[1])
+                if key not in seen:
+                    seen.add(key); pick.append(i)
+            if len(items) - 1 not in pick:
+                pick.append(len(items) - 1)
+            same, nbytes, bad = True, 0, []
+            for i in pick:
                 f, nb, rot, bm, chunk, th = items[i]
                 want = O.compress_frame(b"", f.cpu().numpy(), nb, rot, bm, chunk, th, threads=min(os.cpu_count() or 1, 16))
-                same = same and bodies[i].cpu().numpy().tobytes() == want
+                ok_i = bodies[i].cpu().numpy().tobytes() == want
+                same = same and ok_i
+                if not ok_i:
+                    bad.append(i)
                 nbytes += f.numel()
-            line["bodies_equal_oracle"] = {"tensors": len(pick), "bytes": int(nbytes), "equal": same}
+            line["bodies_equal_oracle"] = {"tensors": len(pick), "classes": len(seen), "bytes": int(nbytes), "equal": same, "differing_items": bad}
     return line
 
 
@@ -546,7 +641,9 @@ def main():
     same_body = used[0] == body.numel() and bool(torch.equal(body_buf[:used[0]], body))
     encode_kernels = lib.last_kernels()
 
+    rank_ms = None
     if dist:
+        rank_ms = rank_spread(td, device, elapsed / args.steps * 1e3, world)
         tt = torch.tensor([elapsed, c_elapsed, float(not (exact and same_body))], device=device, dtype=torch.float64)
         td.all_reduce(tt, op=td.ReduceOp.MAX)
         elapsed, c_elapsed, bad = tt.tolist()
@@ -585,6 +682,7 @@ def main():
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},
         }
         line["rccl_ranks"] = rccl_ranks
+        line["rank_ms_per_step"] = rank_ms          # every rank's own wall time per step (a straggler shows as max >> min); null without torch.distributed
     # ---- BASELINE.json configs[4] on the same line, at every N (every rank takes part; strong scaling) ----
     del x, flat, body_buf, out
     torch.cuda.empty_cache()
@@ -598,8 +696,12 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_other_dtypes:
             line["other_dtypes"] = other_dtypes(lib, codec, device, max(4, min(args.steps, 20)))
+        if world == 1 and not args.no_other_dtypes:
+            line["sizes"] = size_sweep(lib, codec, device, max(4, min(args.steps, 20)))
         if world == 1 and not args.no_plugin:
             line["plugin_gpt2"] = plugin_gpt2(lib, device)
+        if world == 1:
+            line["multi_dev_inprocess"] = multi_dev_inprocess(lib, codec)
         if world == 1 and not args.no_cpu_baseline:
             sample = min(args.cpu_sample_mib << 20, n_bytes) // CHUNK * CHUNK
             if sample:

@@ -195,6 +195,13 @@ int zn_set_host_slices(int slices);
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);
 
+/* The device-side verdict of the last zn_decompress*_dev call made on the current device with check = 0 (no read-back, asynchronous):
+ * waits for `stream` and returns ZN_OK / ZN_E_TYPE / ZN_E_CORRUPT exactly as that call would have with check = 1.  For callers that
+ * overlap host work with the decode (a checkpoint loader builds its tensor views while the kernels run) — the reference's
+ * combine_dtype (csrc/zipnn_core.c:881) is synchronous and reports through its return value at once.  Valid until the next decode call
+ * on this device. */
+int zn_decode_status(void* stream);
+
 /* Names of the kernels the last *_dev call launched, ';'-separated (for profiles). */
 const char* zn_last_kernels(void);
 

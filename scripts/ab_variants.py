@@ -40,23 +40,23 @@ VARIANTS = {
     "dcap4": (None, ["-DZN_F_DCAP=4"]),
     "dcap3": (None, ["-DZN_F_DCAP=3", "-DZN_F_DCONST2=3"]),
     "dcap5": (None, ["-DZN_F_DCAP=5", "-DZN_F_DCONST2=5"]),
-    "e_abl1": (None, ["-DZN_E_ABL=1"]),
-    "e_abl2": (None, ["-DZN_E_ABL=2"]),
-    "e_abl2na": (None, ["-DZN_E_ABL=2", "-DZN_E_STATS_AHEAD=0"]),
+    "e_abl1": ("3c0f9d7", ["-DZN_E_ABL=1"]),
+    "e_abl2": ("3c0f9d7", ["-DZN_E_ABL=2"]),
+    "e_abl2na": ("3c0f9d7", ["-DZN_E_ABL=2", "-DZN_E_STATS_AHEAD=0"]),
     "e_noahead": (None, ["-DZN_E_STATS_AHEAD=0"]),
     "e_fwd": (None, ["-DZN_E_EMIT_REVERSE=0"]),
     "e_old": (None, ["-DZN_E_STATS_AHEAD=0", "-DZN_E_EMIT_REVERSE=0"]),
     "rb5": (None, ["-DZN_F_RB2=5"]),
     "nod6": (None, ["-DZN_F_DCONST2=0"]),
     "rb6": (None, ["-DZN_F_RB2=6"]),
-    "nopass2": (None, ["-DZN_F_ABL=1"]),
-    "noraw": (None, ["-DZN_F_ABL=2"]),
-    "nostore": (None, ["-DZN_F_ABL=4"]),
-    "nomem": (None, ["-DZN_F_ABL=6"]),
-    "nofix": (None, ["-DZN_F_ABL=8"]),
-    "nolut": (None, ["-DZN_F_ABL=16"]),
-    "nop2mem": (None, ["-DZN_F_ABL=7"]),
-    "noall": (None, ["-DZN_F_ABL=31"]),
+    "nopass2": ("3c0f9d7", ["-DZN_F_ABL=1"]),
+    "noraw": ("3c0f9d7", ["-DZN_F_ABL=2"]),
+    "nostore": ("3c0f9d7", ["-DZN_F_ABL=4"]),
+    "nomem": ("3c0f9d7", ["-DZN_F_ABL=6"]),
+    "nofix": ("3c0f9d7", ["-DZN_F_ABL=8"]),
+    "nolut": ("3c0f9d7", ["-DZN_F_ABL=16"]),
+    "nop2mem": ("3c0f9d7", ["-DZN_F_ABL=7"]),
+    "noall": ("3c0f9d7", ["-DZN_F_ABL=31"]),
     "nofence": (None, ["-DZN_F_NO_SCHED_FENCE"]),
     "w3": (None, ["-DZN_F_WAVES_PER_SIMD=3"]),      # 3 waves per SIMD: 168 VGPRs
     "w2": (None, ["-DZN_F_WAVES_PER_SIMD=2"]),
@@ -104,19 +104,12 @@ VARIANTS = {
     "d33c": (None, ["-DZN_F_DELTA0=33", "-DZN_F_DELTA_MAX=44"]),
     "d22c": (None, ["-DZN_F_DELTA_MAX=44"]),
     "nmis2": (None, ["-DZN_F_NMIS=2"]),
-    # round 4: wave specialisation (four decode waves + a mover per workgroup)
+    # round 4: wave specialisation (four decode waves + mover waves per workgroup) — the code lives in commit b49b217 only (profiles/r04_decode_experiments.txt)
     "r03": ("3c0f9d7", []),                         # the kernels of the round-3 final state
-    "nospec": (None, ["-DZN_F_SPEC=0"]),
-    "q2": (None, ["-DZN_F_MOVER_Q2=2"]),
-    "q8": (None, ["-DZN_F_MOVER_Q2=8"]),
-    "q6": (None, ["-DZN_F_MOVER_Q2=6"]),
-    "nopers": (None, ["-DZN_F_PERSIST=0"]),
-    "pers": (None, ["-DZN_F_PERSIST=1"]),         # the specialised form, one workgroup per chunk group (no persistent workgroups)
-    "sw4": (None, ["-DZN_F_SPEC_WAVES=4"]),
-    "sw5": (None, ["-DZN_F_SPEC_WAVES=5"]),         # the specialised form with 128 registers: at most three workgroups (15 waves) per CU
-    "free": (None, ["-DZN_F_ABL=96"]),              # timing only: neither side of the hand-over waits (decode waves and mover run free)
-    "freedec": (None, ["-DZN_F_ABL=32"]),           # timing only: the decode waves never wait for room
-    "freemov": (None, ["-DZN_F_ABL=64"]),           # timing only: the mover never waits for rows
+    "spec8": ("b49b217", []),                       # 8-wave workgroups (4 decode + 4 movers), 80 VGPRs
+    "spec8w5": ("b49b217", ["-DZN_F_SPEC_WAVES=5"]),   # … 96 VGPRs: two workgroups per CU
+    "spec8free": ("b49b217", ["-DZN_F_ABL=96"]),    # … timing only: neither side of the hand-over waits
+    "spec8pers": ("b49b217", ["-DZN_F_PERSIST=1"]), # … persistent workgroups
 }
 
 
@@ -154,7 +147,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "r03", "nospec", "q2", "q8", "q6", "nopers", "sw4", "sw5", "pers", "free", "freedec", "freemov", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
+ALLD = ("r01", "r02", "r03", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
 
 
 def run(names):

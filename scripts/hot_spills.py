@@ -26,13 +26,12 @@ kern = None; depth = 0; hot = {}
 for i, l in enumerate(L):
     m = re.match(r"^(_Z\w+):", l)
     if m: kern = m.group(1); depth = 0
-    if "ZN_HOT_TILE_BEGIN" in l: depth += 1; hot.setdefault(kern, []).append([i, None, [], ""])
-    elif "ZN_SPEC_FORM" in l and hot.get(kern): hot[kern][-1][3] = " (specialised form)"
+    if "ZN_HOT_TILE_BEGIN" in l: depth += 1; hot.setdefault(kern, []).append([i, None, []])
     elif "ZN_HOT_TILE_END" in l and hot.get(kern) and hot[kern][-1][1] is None: hot[kern][-1][1] = i; depth = 0
     elif depth and "scratch_" in l and hot.get(kern): hot[kern][-1][2].append((i + 1, l.strip()))
 for k, v in res.items():
     if "decode_fused" not in k: continue
     print(k[:40], v)
-    for b, e, sc, form in hot.get(k, []):
-        print(f"   tile loop lines {b + 1}-{(e or 0) + 1}{form}: {len(sc)} scratch ops textually inside")
+    for b, e, sc in hot.get(k, []):
+        print(f"   tile loop lines {b + 1}-{(e or 0) + 1}: {len(sc)} scratch ops textually inside")
         for n, t in sc[:12]: print(f"      {n}: {t}")

@@ -6,10 +6,12 @@ reads (MI355X_MICROARCH.md §HBM; calibrated on our own access widths in profile
     python scripts/pmc_traffic.py gpurun_out/r03a_pmc r03a"""
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def main(src, prefix):
     out = {"unit": "bytes per 1 GiB tensor per launch", "fetch_correction": 2.0, "decode": {}, "encode": {},
+           "csrc_sha256_16": __import__("importlib").import_module("bench").csrc_digest(),
            "kernels_commit": subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "zipnn_amd/csrc"], capture_output=True, text=True).stdout.strip()}
     for kind in sorted(os.listdir(src)):
         f = os.path.join(src, kind, "summary.txt")

@@ -290,11 +290,3 @@ enum { hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)(uintptr_t)2; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-
-// a spin-wait between the waves of a block (the producer / consumer hand-over of the specialised decode workgroups): the fiber stays
-// runnable and lets the others go on.  A wait that never ends is a bug in the protocol: reported instead of hanging.
-static inline void zn_simt_spin_yield() {
-  static thread_local unsigned long long spins = 0;
-  if (++spins > (1ull << 33)) { fprintf(stderr, "zn_simt: a spin-wait did not end\n"); abort(); }
-  zn_simt::yield_to_sched(zn_simt::RUN);
-}

@@ -248,3 +248,64 @@ def test_zipnn_devices_keyword_spreads_host_input_over_gpus(use_simt):
     assert back.dtype == t.dtype and back.shape == t.shape and torch.equal(back, t)
     a = (np.random.default_rng(1).standard_normal(300001) * 0.02).astype(np.float32)
     assert (ZipNN(input_format="numpy", devices=[0, 1]).decompress(ZipNN(input_format="numpy", devices=[1, 0]).compress(a)) == a).all()
+
+
+def test_plugin_read_ahead_decodes_the_whole_file_with_one_batched_launch(use_simt, tmp_path):
+    """SafeOpen's read-ahead (what get_tensor uses for a device target): the first compressed name ships the data section once and
+    decodes EVERY compressed tensor of the file with one batched launch; get_tensor then serves from the cache and drops what it hands
+    out.  Under the emulator the 'device' is CPU memory, so the read-ahead is started by hand."""
+    from safetensors.torch import save_file
+    from zipnn_amd import zipnn as Z
+    from zipnn_amd.safetensors_io import compress_safetensors_file
+    tensors = _model(11)
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    out = compress_safetensors_file(src)
+    with Z.SafeOpen(out, framework="pt", device="cpu") as f:
+        names = set(f.compressed_tensors_metadata)
+        assert len(names) >= 3
+        f._read_ahead()
+        assert isinstance(f._ahead, dict) and set(f._ahead) == names
+        kernels = use_simt.last_kernels()
+        assert kernels.count("zn_k_decode_fused") + kernels.count("zn_k_decode_planes") >= 1      # one launch set for all of them
+        for k in sorted(names):
+            got = f._ahead.pop(k)
+            v = tensors[k]
+            assert got.dtype == v.dtype and got.shape == v.shape
+            assert got.contiguous().view(torch.uint8).numpy().tobytes() == v.contiguous().view(torch.uint8).numpy().tobytes(), k
+        assert f._ahead == {}
+        # a name asked for twice falls back to the per-tensor path
+        k = sorted(names)[0]
+        assert torch.equal(f.get_tensor(k).view(torch.uint8), tensors[k].contiguous().view(torch.uint8))
+    assert f._ahead is False
+
+
+def test_load_file_copies_plain_tensors_out_of_the_uploaded_section(use_simt, tmp_path):
+    """an uncompressed tensor must not keep the whole uploaded data section (all compressed frames) alive."""
+    from safetensors.torch import save_file
+    from zipnn_amd.safetensors_io import compress_safetensors_file, load_file
+    tensors = _model(5)
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    out = compress_safetensors_file(src)
+    loaded = load_file(out, device="cpu")
+    ids = loaded["ids"]
+    assert torch.equal(ids, tensors["ids"])
+    assert ids.untyped_storage().nbytes() <= ids.numel() * ids.element_size() + 64
+
+
+def test_corrupt_frame_header_in_a_file_reports_the_real_error(use_simt, tmp_path):
+    """a frame with a damaged header must surface as the header error, not as BufferError from closing the mapping."""
+    from safetensors.torch import save_file
+    from zipnn_amd.safetensors_io import compress_safetensors_file, load_file, _read_layout
+    tensors = _model(6)
+    src = os.path.join(tmp_path, "m.safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    out = compress_safetensors_file(src)
+    meta, layout, data_start = _read_layout(out)
+    lo = layout["w_bf16"][2]
+    blob = bytearray(open(out, "rb").read())
+    blob[data_start + lo] = ord("X")                      # "ZN" -> "XN"
+    open(out, "wb").write(blob)
+    with pytest.raises(ValueError, match="Header should start with ZN"):
+        load_file(out, device="cpu")

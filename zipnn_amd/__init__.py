@@ -7,3 +7,18 @@ repository's scope and raises NotImplementedError.
 from .zipnn import ZipNN, SafeOpen, zipnn_safetensors, zipnn_hf, decompress_safetensors_tensor  # noqa: F401
 
 __all__ = ["ZipNN", "SafeOpen", "zipnn_safetensors", "zipnn_hf", "decompress_safetensors_tensor"]
+
+
+def install_as_zipnn():
+    """Make `import zipnn` / `from zipnn import ZipNN, zipnn_safetensors` / `import zipnn.zipnn` resolve to this package inside the
+    running process (a sys.modules hook; the path-based form is the `compat/` directory of the repository).  Refuses to replace a
+    different `zipnn` that is already imported — the reference package and this one cannot both own the name in one process."""
+    import sys
+    from . import zipnn as _impl
+    this = sys.modules[__name__]
+    other = sys.modules.get("zipnn")
+    if other is not None and other is not this and getattr(other, "ZipNN", None) is not ZipNN:
+        raise RuntimeError("another `zipnn` package is already imported in this process")
+    sys.modules["zipnn"] = this
+    sys.modules["zipnn.zipnn"] = _impl
+    return this

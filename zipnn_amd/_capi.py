@@ -33,6 +33,10 @@ class ZnBatchItem(ctypes.Structure):
                 ("bytes_mode", ctypes.c_int), ("chunk", ctypes.c_size_t), ("d_delta", ctypes.c_void_p)]
 
 
+ZN_BATCH_ITEM_FMT = "<QQQQiii4xQQ"          # struct zn_batch_item as struct.pack sees it (64 bytes)
+assert ctypes.sizeof(ZnBatchItem) == 64
+
+
 class ZnCBatchItem(ctypes.Structure):
     """struct zn_cbatch_item of include/zipnn_hip.h"""
     _fields_ = [("d_src", ctypes.c_void_p), ("n", ctypes.c_size_t), ("num_buf", ctypes.c_int), ("bits_mode", ctypes.c_int),
@@ -100,6 +104,8 @@ class ZnLib:
         L.zn_copy_to_device.restype = ci; L.zn_copy_to_device.argtypes = [vp, vp, sz]
         L.zn_copy_to_host.restype = ci; L.zn_copy_to_host.argtypes = [vp, vp, sz]
         L.zn_release_workspace.restype = ci
+        L.zn_decode_status.restype = ci
+        L.zn_decode_status.argtypes = [vp]
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
         L.zn_last_tail_planes.restype = ctypes.c_longlong
         self._L = L
@@ -298,6 +304,17 @@ class ZnLib:
             arr[i].d_body = bp; arr[i].body_len = bl; arr[i].d_dst = dp; arr[i].orig_size = n
             arr[i].num_buf = nb; arr[i].bits_mode = bi; arr[i].bytes_mode = by; arr[i].chunk = ch
         self._check(self._L.zn_decompress_batch_dev(arr, len(items), stream, 1 if check else 0))
+
+    def decompress_batch_dev_packed(self, packed, count, stream=0, check=True):
+        """zn_decompress_batch_dev over items already laid out as `struct zn_batch_item` (64 bytes each:
+        struct.pack(ZN_BATCH_ITEM_FMT, d_body, body_len, d_dst, orig_size, num_buf, bits_mode, bytes_mode, chunk, d_delta or 0)) —
+        for loaders that hand over hundreds of tensors per call."""
+        buf = (ctypes.c_char * len(packed)).from_buffer_copy(packed)
+        self._check(self._L.zn_decompress_batch_dev(ctypes.cast(buf, ctypes.POINTER(ZnBatchItem)), count, stream, 1 if check else 0))
+
+    def decode_status(self, stream=0):
+        """zn_decode_status: wait for `stream`, raise what the last check=False decode call on this device would have raised."""
+        self._check(self._L.zn_decode_status(ctypes.c_void_p(stream or None)))
 
     def last_fused_chunks(self):
         """Chunks of the last decompress_dev call that took the fused single-pass kernel."""

@@ -334,7 +334,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if ((rc = ws_acquire(w, stream))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   w.last_K = all_k; w.last_tails = all_tail;
-  ZN_HIP(hipMemsetAsync(d_status, 0, 8 * sizeof(uint32_t), stream));     // status + the three "left to the generic kernels" counters + the three work counters of the persistent fused kernels
+  ZN_HIP(hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream));     // status + the three "left to the generic kernels" counters
   if (all_tail) ZN_HIP(hipMemsetAsync(w.buf[WS_META_A], 0, all_tail, stream));
   if (table) {
     // the previous batched call may still be reading the pinned staging: wait for it on the host
@@ -626,6 +626,22 @@ int zn_assemble_ranges(const void* hdr, size_t hdr_len, const std::vector<const 
   // where every (plane, range) piece goes and what re-bases its cumSizes
   std::vector<size_t> dst_at(G * P, 0), c0(G, 0); std::vector<uint64_t> rebase(G * P, 0);
   { size_t c = 0; for (size_t g = 0; g < G; g++) { c0[g] = c; c += ks[g]; } }
+  // every part by itself: its cumSizes non-decreasing inside each plane and its plane totals adding up to ITS OWN payload length — a
+  // global sum alone lets a part that is short by what another one is long through, and the copies below then read past its end
+  for (size_t g = 0; g < G; g++) {
+    const size_t k = ks[g];
+    if (!k) continue;
+    const uint8_t* c = part[g] + P * k;
+    const size_t own = plen[g] - 9 * P * k;
+    size_t sum = 0;
+    for (size_t p = 0; p < P; p++) {
+      uint64_t prev = 0;
+      for (size_t i = 0; i < k; i++) { const uint64_t v = zn_rd64(c + 8 * (p * k + i)); if (v < prev) return ZN_E_CORRUPT; prev = v; }
+      if (prev > own - sum) return ZN_E_CORRUPT;
+      sum += (size_t)prev;
+    }
+    if (sum != own) return ZN_E_CORRUPT;
+  }
   size_t pay_at = 0;
   for (size_t p = 0; p < P; p++) {
     uint64_t run = 0;                              // bytes the earlier ranges put into plane p
@@ -733,10 +749,18 @@ int zn_compress_ranges(const void* hdr, size_t hdr_len, size_t n, int num_buf, i
 namespace {
 std::atomic<int> g_host_slices{0};               // zn_set_host_slices: 0 automatic, 1 never, 2..64 that many
 struct ZnGate {                                   // "stage X has finished n items" between two pipeline threads
-  std::mutex m; std::condition_variable cv; size_t done = 0; bool fail = false;
+  std::mutex m; std::condition_variable cv; size_t done = 0; std::atomic<bool> fail{false};     // (fail is also read without the mutex)
   void publish(size_t n) { { std::lock_guard<std::mutex> lk(m); done = n; } cv.notify_all(); }
   void abort() { { std::lock_guard<std::mutex> lk(m); fail = true; } cv.notify_all(); }
   bool wait_for(size_t n) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return done >= n || fail; }); return !fail; }
+};
+// Declared BEHIND the ZnWorkers of a pipelined call: when the coordinating thread leaves the scope by an exception (std::bad_alloc from a
+// vector), this aborts the gates before ~ZnWorkers joins the threads — which would otherwise wait on a gate for ever.
+struct ZnGateGuard {
+  ZnGate* a; ZnGate* b; bool armed = true;
+  ZnGateGuard(ZnGate* a_, ZnGate* b_) : a(a_), b(b_) {}
+  void disarm() { armed = false; }
+  ~ZnGateGuard() { if (armed) { a->abort(); b->abort(); } }
 };
 int zn_pipeline_streams(Workspace& w) {
   if (!w.cstream) ZN_HIP(hipStreamCreateWithFlags(&w.cstream, hipStreamNonBlocking));
@@ -786,8 +810,9 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
   }
   ZnGate up, dec;
   int rc_up = ZN_OK, rc_down = ZN_OK, rc_dec = ZN_OK;
-  {
+  try {
     ZnWorkers wk;
+    ZnGateGuard guard(&up, &dec);
     wk.start([&]() {                                // upload: re-based size tables + the P payload slices of every slice
       try {
         if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
@@ -836,8 +861,9 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
       dec.publish((size_t)i + 1);
     }
     if (rc_dec) { dec.abort(); up.abort(); }
+    guard.disarm();
     wk.join();
-  }
+  } catch (...) { return ZN_E_ALLOC; }
   return rc_dec ? rc_dec : rc_up ? rc_up : rc_down;
 }
 
@@ -871,8 +897,9 @@ static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const voi
   ZnGate up, queued; bool all_queued = false;
   int rc_up = ZN_OK, rc_down = ZN_OK, rc_enc = ZN_OK;
   std::vector<std::vector<uint8_t>> metas((size_t)S);
-  {
+  try {
     ZnWorkers wk;
+    ZnGateGuard guard(&up, &queued);
     wk.start([&]() {                                // upload the tensor slice by slice
       try {
         if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
@@ -958,9 +985,10 @@ static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const voi
       }
       if (hdr_len >= 32) { const uint64_t t64 = total; memcpy(o + 24, &t64, 8); }   // zipnn_core.c:121
     }
+    guard.disarm();
     wk.join();
     if (!rc_enc && !rc_down) *dst_len = total;
-  }
+  } catch (...) { return ZN_E_ALLOC; }
   return rc_enc ? rc_enc : rc_up ? rc_up : rc_down;
 }
 
@@ -1067,6 +1095,29 @@ int zn_decompress_multi_dev(const void* body, size_t body_len, int num_buf, int 
   for (int g = 0; g < ndev; g++) { const ZnRange r = zn_range_of(K, g, ndev); if (r.hi > r.lo && !d_dst[g]) return ZN_E_ARG; }
   try { return zn_decompress_ranges(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, devices, ndev, nullptr, d_dst); }
   catch (...) { return ZN_E_ALLOC; }
+}
+
+// The device-side status of the last decode call on the current device that was made with check = 0: waits for `stream`, reads the
+// status word that call left in the workspace.  A loader launches its batched decode without the read-back, builds its tensor views
+// while the kernels run, and asks here once at the end.
+int zn_decode_status(void* stream_) {
+  try {
+    int dev = 0;
+    ZN_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return ZN_E_ARG;
+    std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
+    Workspace& w = g_ws[dev];
+    if (!w.buf[WS_WORDS]) return ZN_OK;              // nothing has run on this device yet
+    int rc;
+    if ((rc = ws_host_words(w))) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    ZN_HIP(hipMemcpyAsync(w.h_status, (uint32_t*)w.buf[WS_WORDS] + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ZN_HIP(hipStreamSynchronize(stream));
+    const uint32_t st = *w.h_status;
+    if (st & ZN_DEV_BAD_TYPE) return ZN_E_TYPE;
+    if (st & ZN_DEV_CORRUPT) return ZN_E_CORRUPT;
+    return ZN_OK;
+  } catch (...) { return ZN_E_ALLOC; }
 }
 
 long long zn_last_fused_chunks(void) {

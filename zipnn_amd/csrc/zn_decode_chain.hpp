@@ -84,11 +84,11 @@ struct ZnChain {
   uint32_t n;                 // MODE 1: symbols counted
   uint32_t wpos;              // MODE 2: byte offset in the staging buffer of the next symbol
 };
-template <int MODE, uint32_t AMASK = ~3u>
+template <int MODE>
 __device__ __forceinline__ void zn_chain_apply(ZnChain& c, uint2 e, uint32_t* stage) {
   if (MODE == 2) {
     const uint64_t sp = (uint64_t)e.x << ((c.wpos & 3u) << 3);
-    uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & AMASK));      // (AMASK: see zn_pass2 — a circular staging buffer with a mirror dword)
+    uint32_t* d = (uint32_t*)((uint8_t*)stage + (c.wpos & ~3u));
     if ((uint32_t)sp) atomicOr(d, (uint32_t)sp);
     if ((uint32_t)(sp >> 32)) atomicOr(d + 1, (uint32_t)(sp >> 32));
     c.wpos += ZN_M_CNT(e.y);
@@ -101,7 +101,7 @@ __device__ __forceinline__ void zn_chain_apply(ZnChain& c, uint2 e, uint32_t* st
 // without the per-step boundary test and its two selects: 4 instead of 9 vector instructions per step.  Lanes whose result the caller
 // discards (fix-up iterations re-run the pass for a few lanes only) may run past their boundary there; MODE 2 callers pass U > 0
 // only when every lane of the wave is writing.
-template <int MODE, uint32_t AMASK = ~3u>
+template <int MODE>
 __device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* in, int32_t base_bit, uint32_t TL, ZnChain& c, uint32_t* stage, int U = 0) {
   const uint32_t sh = 32u - TL;
   const int32_t mb = c.stop + (int32_t)TL - 1;
@@ -110,7 +110,7 @@ __device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* i
     for (int s = 0; s < 3; s++) {
       const uint2 e = lut[(uint32_t)(w >> 32) >> sh];
       w <<= (e.y & 63u);
-      zn_chain_apply<MODE, AMASK>(c, e, stage);
+      zn_chain_apply<MODE>(c, e, stage);
     }
   }
   while (__any(c.pos > mb)) {                // whole groups while the group provably starts above `stop`
@@ -119,14 +119,14 @@ __device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* i
       uint2 e = lut[(uint32_t)(w >> 32) >> sh];
       if (!(c.pos > mb)) { e.x = 0; e.y = 0; }
       w <<= (e.y & 63u);
-      zn_chain_apply<MODE, AMASK>(c, e, stage);
+      zn_chain_apply<MODE>(c, e, stage);
     }
   }
   while (__any(c.pos > c.stop)) {            // the boundary step(s): one iteration unless > 4 symbols start in the last TL - 1 bits
     const uint64_t w = zn_window(in, c.pos - 1 - base_bit);
     uint2 e = lut[(uint32_t)(w >> 32) >> sh];
     if (!(c.pos > c.stop)) { e.x = 0; e.y = 0; }
-    zn_chain_apply<MODE, AMASK>(c, zn_trim_group(e, c.pos - c.stop), stage);
+    zn_chain_apply<MODE>(c, zn_trim_group(e, c.pos - c.stop), stage);
   }
 }
 
@@ -256,15 +256,12 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
 // shift: its source would be a register PAIR per step with a zero upper half, twice the registers.)
 // `hook(ZnIdx<t>)` runs after step t (the caller spreads its HBM requests for the flush over the pass there: their
 // destination registers come into use as the record registers fall out of it).
-// AMASK: ~3 for a linear staging buffer; (size - 4) for a CIRCULAR one of `size` bytes (a power of two) — wpos is then the running
-// symbol index of the stream, the mask wraps it, and the dword behind the buffer's last one is the mirror of dword 0 (the upper
-// dword of a group that straddles the end goes there; whoever reads row 0 ORs it in).
-template <int TF, int TB, bool DENSE = false, uint32_t AMASK = ~3u, typename HOOK>
+template <int TF, int TB, bool DENSE = false, typename HOOK>
 __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& rec, int nfull, int nbnd, HOOK&& hook) {
   uint32_t wm1 = wpos - 1u;                                // (wpos == 0: the pair starts one dword below the buffer and that dword gets a zero)
   auto put = [&](uint32_t cnt, uint32_t sv) {
     const uint32_t g = ~wm1;                               // low two bits = (-wpos) & 3
-    uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & AMASK));
+    uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & ~3u));
 #ifndef ZN_F_P2_MASK
 #define ZN_F_P2_MASK 2        // 1: lanes with nothing to add stay out of the atomics (exec mask) — 2: per dword.  (0, every lane every dword, is a
                               // developer measurement only, refused outside ZN_DEV_BUILD: with wpos == 0 the pair starts one dword BELOW the staging

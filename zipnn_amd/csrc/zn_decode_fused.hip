@@ -49,17 +49,7 @@
 #include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
 
-#define ZN_F_THREADS 256                 // the decode waves of a workgroup: 4 waves = the 4 streams of a huff0 block
-// Wave specialisation (round 4).  The plain (non-delta) kernel runs FIVE waves per workgroup: waves 0-3 decode (run-in, decode
-// pass, compaction into a circular staging ring in LDS) and never touch the raw planes or the output; wave 4 — the MOVER — does
-// nothing else: it requests the raw-plane rows of all four streams ZN_F_MOVER_Q rows ahead, takes the rows the decode waves
-// publish out of the rings, interleaves and stores them.  A decode wave therefore never waits for HBM (its stream tile is
-// prefetched a whole tile ahead), the mover always has loads and stores in flight, and the flush's registers leave the decode
-// waves: 96 instead of 128 VGPRs, i.e. 5 waves per SIMD where the LDS budget allowed 4 workgroups per CU before and after.
-#ifndef ZN_F_SPEC
-#define ZN_F_SPEC 1
-#endif
-#define ZN_F_THREADS_SPEC (2 * ZN_F_THREADS)
+#define ZN_F_THREADS 256
 #ifndef ZN_F_RING_BYTES
 #define ZN_F_RING_BYTES 4096u            // per wave; multiple of every row size (512 / 1024 symbols)
 #endif
@@ -155,9 +145,6 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
 #define ZN_KEEP32(x) ((void)(x))
 #define ZN_BFI(mask, a, b) ((((uint32_t)(a)) & (uint32_t)(mask)) | (((uint32_t)(b)) & ~(uint32_t)(mask)))
 #endif
-#ifndef ZN_F_ABL
-#define ZN_F_ABL 0                       // developer builds (scripts/ab_variants.py), timing only, WRONG output: drop a phase to price it on the device — 1 compaction, 2 raw-plane loads, 4 output stores, 8 fix-up iterations, 16 LUT fill (after a group's first chunk)
-#endif
 #ifndef ZN_F_EARLY_STAGE
 #define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
 #endif
@@ -225,43 +212,17 @@ typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 #define ZN_LD_STREAM32(p) (*(const uint32_t*)(p))
 #endif
 
-// producer / consumer hand-over between the decode waves and the mover of a specialised workgroup: two words per stream in LDS
-// (symbols published, symbols taken), polled by the whole wave (one broadcast ds_read) with a short sleep in between.  The emulator's
-// lanes are fibers that only switch at collectives, so its pause is a yield.
-#if defined(ZN_SIMT_EMULATOR)
-#define ZN_SPIN_PAUSE() zn_simt_spin_yield()
-#else
-#define ZN_SPIN_PAUSE() __builtin_amdgcn_s_sleep(1)
-#endif
-#define ZN_SPEC_POISON 0xFFFFFFFFu         // published by a decode wave that gave up on its stream: the mover stops waiting for it
-// (the words are LDS and the accesses must be DS operations: through a generic volatile pointer they become system-scope FLAT
-//  operations behind an s_waitcnt vmcnt(0) — a drain of the wave's memory queue at every look)
-#if defined(ZN_SIMT_EMULATOR) || !defined(__HIP_DEVICE_COMPILE__)
-#define ZN_LDS_VOLATILE(p) ((volatile uint32_t*)(p))
-#else
-#define ZN_LDS_VOLATILE(p) ((volatile __attribute__((address_space(3))) uint32_t*)(unsigned int)(unsigned long long)(p))
-#endif
-__device__ __forceinline__ uint32_t zn_peek(const uint32_t* p) { return zn_uniform(*ZN_LDS_VOLATILE(p)); }
-__device__ __forceinline__ void zn_poke(uint32_t* p, uint32_t v, uint32_t lane) {
-  __builtin_amdgcn_wave_barrier();         // (the LDS executes one wave's operations in the order they were issued: the word that announces the
-  if (lane == 0) *ZN_LDS_VOLATILE(p) = v;  //  writes is queued behind them and needs no wait; the emulator's lanes meet at the barrier)
-}
-
 struct ZnFusedPlane { uint64_t off; uint32_t kind; uint32_t csize; };   // off: body offset (RAW/HUF) or byte value (RLE)
 
 struct __attribute__((aligned(16))) ZnFusedLds {
   uint2 lut[1u << ZN_F_TLMAX];             // multi-symbol decode table: {symbols, meta} per TL-bit window (ZN_E_META)
-  uint32_t ring[4][ZN_F_RING_DW + 4];      // per-wave output ring; ring[0] holds the 16-bit LUT while tables are built.  Dword ZN_F_RING_DW is the
-                                           // MIRROR of dword 0 in the specialised form (the ring is circular there: a group that straddles its end
-                                           // puts its upper dword into the mirror, the mover ORs it into row 0); + 3 keeps the rings 16-byte aligned
+  uint32_t ring[4][ZN_F_RING_DW];          // per-wave output ring; ring[0] holds the 16-bit LUT while tables are built
   uint32_t in[4][ZN_F_IN_DW];              // per-wave staged stream tile
   uint8_t symlist[4][256];                 // per chunk of the group: symbols in canonical order
   uint32_t rank_start[4][14], sym_start[4][14];
   ZnFusedPlane plane[4][4];                // [chunk of the group][plane]
   ZnWaveStats st[4];
   uint32_t what[4];
-  uint32_t work;                           // persistent workgroups: the group index thread 0 drew for the next round
-  uint32_t prod[4], cons[4];               // specialised form, per stream: symbols published by the decode wave / rows' symbols taken (and zeroed) by the mover
 };
 
 #include "zn_decode_chain.hpp"
@@ -269,16 +230,14 @@ struct __attribute__((aligned(16))) ZnFusedLds {
 // Decode tables of one huff0 block, by the whole workgroup: the canonical single-symbol LUT (u16, aliased into
 // staging buffer 0, idle at this point), then the multi-symbol LUT.  j = which of the group's symbol orders.
 // Contains one __syncthreads(); the caller syncs again before the staging buffers are used.
-// (threads beyond ZN_F_THREADS — the mover wave of a specialised workgroup — only keep the barrier count)
 __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, uint32_t TL, uint32_t j, uint32_t lmin = 1) {
   uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
-  const bool worker = tid < ZN_F_THREADS;
-  if (worker) {
+  {
     const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
     for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[ZN_L16(u)] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
   }
   __syncthreads();
-  if (worker) {
+  {
     // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
     const uint32_t mask = (1u << TL) - 1u;
     uint32_t pos[8], cnt[8], syms[8], ef[8];
@@ -313,16 +272,11 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
 // which lets the tile loads / staging loops unroll exactly), 0 = run-time Du.
 // X: the output is XORed with the delta base `xq` (same offsets as outq; may still be null for a tensor without one).
 // xq == outq accumulates into rows already written (every row is loaded before it is stored, once).
-// SPEC: the wave is a DECODE wave of a specialised workgroup — it decodes and compacts into its ring, which is circular (symbol j of
-// the stream lives at byte j mod ZN_F_RING_BYTES), announces the symbols in *prod and waits on *cons for room; the raw planes, the
-// interleave and the stores are the mover's (zn_mover_role).  outq_ / xq_ / rawq_ are unused then.
-template <int P, int H, int DC, bool X = false, bool SPEC = false>
+template <int P, int H, int DC, bool X = false>
 __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* outq_, const uint8_t* xq_, const ZnFusedPlane (&pl_)[P], const uint8_t* const (&rawq_)[P],
                                               const uint2* lut, uint32_t* ring, uint32_t* in, uint32_t lane_, uint32_t seg_,
-                                              uint32_t TL_, uint32_t Du, const uint8_t* stream_, uint32_t slen_, bool ragged,
-                                              uint32_t* prod, uint32_t* cons ZN_PT_PARAM) {
-  static_assert(!SPEC || (H >= 0 && !X), "the specialised form: a Huffman plane, no delta base");
+                                              uint32_t TL_, uint32_t Du, const uint8_t* stream_, uint32_t slen_, bool ragged ZN_PT_PARAM) {
   // Everything the caller hands over is the same in all 64 lanes, but most of it came through LDS or was derived from
   // threadIdx, which makes it per-lane data to the compiler: vector registers, and exec-masked control flow around every
   // branch that depends on it (the tile loop, the choice of the decode form).  Say that it is uniform.
@@ -374,10 +328,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       //  offset instead of keeping — and spilling — a 64-bit pointer per lane and row)
       const uint8_t* au = rawq[p] + (first_row_sym + (uint32_t)r * UNIT);
       const uint8_t* a = au + (uint32_t)EPL * lane_v;
-#if ZN_F_ABL & 2
-      for (int k = 0; k < EW; k++) pre[r][p][k] = (uint32_t)(uint64_t)a;
-      continue;
-#endif
       for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
     }
   };
@@ -438,11 +388,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         x[0] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[r][1 % P][0], pre[r][0][0], 0x07030602u);
         x[2] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[r][1 % P][1 % EW], pre[r][0][1 % EW], 0x07030602u);
         if (X) for (int k = 0; k < 4; k++) x[k] ^= xr_[k % XW];
-#if ZN_F_ABL & 4
-        { uint32_t t_ = x[0] ^ x[1] ^ x[2] ^ x[3]; asm volatile("" : "+v"(t_)); (void)o; }
-#else
         ZN_ST128(o, x[0], x[1], x[2], x[3]);
-#endif
       } else {
         for (int half = 0; half < 2; half++) {
           const int k = half % EW;
@@ -470,11 +416,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     return true;
   }
 
-  for (uint32_t i = lane; i < ZN_F_RING_DW + (SPEC ? 4u : 0u); i += 64u) ring[i] = 0;     // (specialised form: and the mirror dword)
+  for (uint32_t i = lane; i < ZN_F_RING_DW; i += 64u) ring[i] = 0;
   __builtin_amdgcn_wave_barrier();
-  // specialised form: room for the symbols below index `upto` / the symbols below `j` are in the ring
-  auto wait_space = [&](uint32_t upto) { if (ZN_F_ABL & 32) return; while ((int32_t)(upto - ZN_F_RING_BYTES - zn_peek(cons)) > 0) ZN_SPIN_PAUSE(); };
-  auto publish = [&](uint32_t j) { zn_poke(prod, j, lane); };
 
   uint32_t J = 0;                             // symbols decoded into the ring so far
   const uint8_t last = stream[slen - 1];
@@ -528,7 +471,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     __builtin_amdgcn_wave_barrier();
   };
   fetch_tile(hi_dw - TD, hi_dw);
-  if (SPEC || ZN_F_EARLY_STAGE) stage_tile();
+#if ZN_F_EARLY_STAGE
+  stage_tile();
+#endif
 
   // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it; returns the
   // position the lane's own decode starts from (lane 0: the true position carried over from the previous tile)
@@ -575,7 +520,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   bool ok = true;
   while (32 * hi_dw > b0) {
     if (DC) ZN_ASM_MARK("ZN_HOT_TILE_BEGIN");
-    if (DC && SPEC) ZN_ASM_MARK("ZN_SPEC_FORM");
     // the stream position and the counters are wave-uniform; said once per tile, because across the two tile forms and
     // the fix-up loop the compiler takes them for per-lane values: vector registers (the 64-bit stream pointer among them,
     // spilled), and an exec-mask region around every branch that depends on them
@@ -586,7 +530,9 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     J = zn_uniform(J); JF = zn_uniform(JF);
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
-    if (!SPEC && !ZN_F_EARLY_STAGE) stage_tile();
+#if !ZN_F_EARLY_STAGE
+    stage_tile();
+#endif
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
     // (tried, r02: requesting the rows this tile will PROBABLY complete — predicted from the previous tile's count — at the top of
     //  the tile, a whole decode pass ahead: no gain; a second flush batch's rows requested behind the first batch's wait: slower)
@@ -626,7 +572,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         const int32_t e_prev = __shfl_up(e, 1u);
         const bool mism = active && lane > 0 && e_prev != s;
         if (it == 0) ZN_PT(6); else ZN_PT(7);   // first decode pass / fix-up passes
-        if (__builtin_expect(!__any(mism), 1) || (ZN_F_ABL & 8)) { chained = true; break; }
+        if (__builtin_expect(!__any(mism), 1)) { chained = true; break; }
         ZN_PT_COUNT(16, 1);                    // number of fix-up iterations
         ZN_PT_COUNT(17, __popcll(__ballot(mism)));
         ZN_DBG_COUNT(2);
@@ -641,28 +587,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         // (J, JF and everything derived from them are wave-uniform; the compiler loses that across the loop — as per-lane
         //  values every `r < rows` below becomes an exec-mask dance of six scalar instructions instead of one compare-and-branch)
         J = zn_uniform(J); JF = zn_uniform(JF);
-        if constexpr (SPEC) {
-          // ---- specialised form: compact into the circular ring and announce it; rows are the mover's business ----
-          const uint32_t base = J & (UNIT - 1u);                 // the incomplete row the mover cannot take yet
-          if (J + N <= seg && base + N <= ZN_F_RING_BYTES) {
-            const uint32_t nact = (uint32_t)__popcll(__ballot(active));
-            carry = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u)); hi_dw = lo_dw;
-            wait_space(J + N);
-            ZN_PT(8);   // scans / shuffles / wait for room
-            ZN_PRIO(ZN_F_PRIO_WRITE);
-            if (DC) ZN_ASM_MARK("ZN_MARK pass2");
-            const int nf = __builtin_amdgcn_readfirstlane(nfull), nb_ = __builtin_amdgcn_readfirstlane(nbnd);
-            zn_pass2<TF, TB, DENSE, ZN_F_RING_BYTES - 4u>(ring, J + o_k, rec, nf, nb_, [](auto) {});
-            ZN_PRIO(0);
-            ZN_PT(9);   // compaction
-            J += N;
-            publish(J);
-            if (32 * hi_dw > b0) stage_tile();                   // (the decode pass is over: the stream-tile buffer is free for the next tile, requested a whole tile ago)
-            ZN_PT_COUNT(20, 1);
-            if (DC) ZN_ASM_MARK("ZN_MARK fastend");
-            done = true;
-          }
-        } else {
         const uint32_t base = J - JF;                            // < UNIT
         if (J + N <= seg && base + N <= ZN_F_RING_BYTES - 4u) {
           const uint32_t nact = (uint32_t)__popcll(__ballot(active));
@@ -685,7 +609,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           // (lanes without a sub-block hold zero records.)  The raw rows RH.. are requested after step TF/2 - 1: the records of
           // the steps before it are dead by then, so the rows' registers do not add to the peak at the start of the compaction.
           bool late_rows = (RH < RB);
-          if (!(ZN_F_ABL & 1)) zn_pass2<TF, TB, DENSE>(ring, base + o_k, rec, nf, nb_, [&](auto I) {
+          zn_pass2<TF, TB, DENSE>(ring, base + o_k, rec, nf, nb_, [&](auto I) {
             if constexpr (RH < RB && decltype(I)::v == TF / 2 - 1) { for (int r = RH; r < RB; r++) if (r < first) fetch_row(JF, r); late_rows = false; }
           });
           if (late_rows) for (int r = RH; r < RB; r++) if (r < first) fetch_row(JF, r);     // (a tile of fewer steps than that)
@@ -707,7 +631,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           ZN_PT_COUNT(20, 1);                    // write groups (== tiles when nothing overflowed)
           if (DC) ZN_ASM_MARK("ZN_MARK fastend");
           done = true;
-        }
         }
       }
     }
@@ -744,29 +667,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       if (!chained || J + N > seg) { ok = false; break; }
       carry = e_last; hi_dw = lo_dw;
       uint32_t lane_lo = 0, wdone = 0;
-      if constexpr (SPEC) {
-        // specialised form: lane groups only where a tile is denser than the ring; each group waits for its room and is announced by itself
-        do {
-          const uint32_t base = J & (UNIT - 1u);
-          const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - base);      // monotone in the lane index
-          const uint32_t lane_hi = (uint32_t)__popcll(__ballot(fits));
-          if (lane_hi <= lane_lo) { ok = false; break; }         // cannot happen: one sub-block always fits
-          if (lane_hi < 64u) ZN_DBG_COUNT(3);
-          const uint32_t wend = (lane_hi >= 64u) ? N : (uint32_t)__shfl((int)o_k, (int)(lane_hi & 63u));
-          const uint32_t nsub = wend - wdone;
-          wait_space(J + nsub);
-          ZN_PRIO(ZN_F_PRIO_WRITE);
-          const bool mine = active && lane >= lane_lo && lane < lane_hi;
-          A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? J + o_k - wdone : 0u;
-          zn_fused_run<2, ZN_F_RING_BYTES - 4u>(lut, in, base_bit, TL, A, ring, (lane_lo == 0u && lane_hi >= 64u) ? U_blk : 0);
-          ZN_PRIO(0);
-          J += nsub; wdone = wend; lane_lo = lane_hi;
-          publish(J);
-          ZN_PT_COUNT(20, 1);
-        } while (lane_lo < 64u);
-        if (!ok) break;
-        if (32 * hi_dw > b0) stage_tile();
-      } else {
       do {
         const uint32_t base = J - JF;                            // < UNIT
         const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - 4u - base);   // monotone in the lane index
@@ -797,139 +697,17 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         if (total_rows > 0 && J > JF) keep_remainder(total_rows);
         ZN_PT_COUNT(20, 1);
       } while (lane_lo < 64u);
-      }
       if (!ok) break;
     }
     ZN_PT(3);   // flush rows
     if (DC) ZN_ASM_MARK("ZN_HOT_TILE_END");
   }
   ZN_PRIO(0);                                 // (an error exit leaves the loop from inside a pass)
-  if (SPEC) return ok && carry == b0 && J == seg;
   if (ragged && ok && carry == b0 && J == seg && JF < seg) {
     // a stream of a partial chunk: the last row is incomplete — store it whole (the destination is padded)
     emit_rows(JF, 1, 0, [] {}); JF += UNIT;
   }
   return ok && carry == b0 && J == seg && JF >= seg;
-}
-
-// ---- the MOVERS: waves 4-7 of a specialised workgroup, one per stream -----------------------------------------------------------
-// Everything of a stream's quarter that touches HBM except the stream tiles: the raw planes in, the interleaved rows out.  Mover w
-// keeps the raw bytes of the next Q rows of ITS quarter in registers — the request for row r + Q leaves when row r has been stored —
-// and takes the rows its decode wave announces (prod) out of the ring, zeroes them behind the read and hands them back (cons).
-// One stream per mover, so its program order is fixed: [row r: take, interleave, store, request r + Q] — the number of vector-memory
-// operations between a request and its use is a compile-time constant, and only with constant distances does the compiler wait with
-// s_waitcnt vmcnt(N > 0) — for exactly the row it needs, with the younger requests and the stores still in flight (loads and stores
-// share one in-order counter on this chip) — instead of draining the queue at every row.  The first and the last round of Q rows are
-// separate copies of the loop body for the same reason (their distances differ).
-// (Round 4 tried ONE mover for the four streams of a 5-wave workgroup first: five-wave workgroups do not pack — the hardware deals a
-//  workgroup's waves to the SIMDs in a fixed rotation, two of them stayed resident per CU, 9-11 waves instead of 20:
-//  profiles/r04_decode_experiments.txt.)
-#ifndef ZN_F_MOVER_Q2
-#define ZN_F_MOVER_Q2 8                    // rows requested ahead, two planes (2 registers a row)
-#endif
-#ifndef ZN_F_MOVER_Q4
-#define ZN_F_MOVER_Q4 4                    // … four planes (three raw planes, 6 registers a row)
-#endif
-template <int P, int H>
-__device__ __forceinline__ void zn_mover_role(const ZnGeom& g, const uint8_t* __restrict__ body_, uint8_t* outq_, const ZnFusedPlane (&pl_)[P],
-                                              uint32_t* ring_, uint32_t* prod, uint32_t* cons, uint32_t w_, uint32_t seg_) {
-  static_assert(H >= 0 && H < P, "the plane the decode waves produce");
-  constexpr int EPL = (P == 1) ? 16 : 8, EW = EPL / 4;
-  constexpr uint32_t UNIT = 64u * EPL, RROWS = ZN_F_RING_BYTES / UNIT;
-  constexpr int Q = (P == 4) ? ZN_F_MOVER_Q4 : ZN_F_MOVER_Q2;
-  const uint32_t seg = zn_uniform(seg_), rows = seg / UNIT, wq = zn_uniform(w_);
-  uint8_t* const outq = zn_uniform_ptr(outq_);               // this quarter of the chunk in the output
-  uint32_t* const ring = ring_;
-  const uint8_t* rawq[P]; uint32_t kind[P], rle[P];
-  bool allraw = true;
-  for (int p = 0; p < P; p++) {
-    kind[p] = zn_uniform(pl_[p].kind); rle[p] = (zn_uniform((uint32_t)pl_[p].off) & 0xFFu) * 0x01010101u;
-    rawq[p] = zn_uniform_ptr(body_ + zn_uniform64(pl_[p].off) + (uint64_t)wq * seg);
-    if (p != H && kind[p] != ZN_KIND_RAW) allraw = false;
-  }
-  uint32_t lane_v = zn_lane_id(); ZN_OPAQUE32(lane_v);
-  const uint32_t lane = lane_v;
-  const uint32_t rot = zn_uniform(g.rot);
-
-  // raw bytes of row `row` → a register set
-  // (a wave-uniform base + a 32-bit lane offset, the lane made opaque at every use: otherwise the compiler keeps one 64-bit per-lane
-  //  pointer per plane alive across the rounds)
-  auto request = [&](uint32_t (&pre)[P][EW], uint32_t row, bool checked) {
-    uint32_t lv = lane_v; ZN_OPAQUE32(lv);
-    for (int p = 0; p < P; p++) if (p != H) {
-      if (checked && kind[p] != ZN_KIND_RAW) continue;
-      const uint8_t* a = rawq[p] + row * UNIT + (uint32_t)EPL * lv;
-      for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(a + 8 * k); pre[p][2 * k] = (uint32_t)t; pre[p][2 * k + 1] = (uint32_t)(t >> 32); }
-    }
-  };
-  uint32_t avail = 0;                                          // rows known to be in the ring (at the last look)
-  auto wait_rows = [&](uint32_t need_rows) {
-    if (ZN_F_ABL & 64) return;
-    while (avail < need_rows) {
-      avail = zn_peek(prod) / UNIT;                            // (ZN_SPEC_POISON counts as everything: a stream that was given up does not hang its mover)
-      if (avail >= need_rows) break;
-      ZN_SPIN_PAUSE();
-    }
-  };
-  // row `row`: wait until it is announced, take it out of the ring, hand the ring row back, interleave with the raw bytes in `pre`, store
-  auto move_row = [&](uint32_t (&pre)[P][EW], uint32_t row, bool checked) {
-    wait_rows(row + 1u);
-    const uint32_t need = (row + 1u) * UNIT;
-    const uint32_t rr = row & (RROWS - 1u);
-    const uint32_t i = (rr * UNIT + (uint32_t)EPL * lane) >> 2;
-    for (int k = 0; k < EW; k++) { pre[H][k] = ring[i + k]; ring[i + k] = 0; }
-    if (rr == 0u) { ZN_NO_IFCVT; if (lane == 0u) { pre[H][0] |= ring[ZN_F_RING_DW]; ring[ZN_F_RING_DW] = 0; } }     // the mirror of dword 0
-    zn_poke(cons, need, lane);                                 // (the zeroing is in the LDS queue ahead of the word that releases the row: no wait)
-    if (checked) for (int p = 0; p < P; p++) if (p != H && kind[p] == ZN_KIND_RLE) { ZN_NO_IFCVT; for (int k = 0; k < EW; k++) pre[p][k] = rle[p]; }
-    if (P >= 2 && rot) {
-      for (int k = 0; k < EW; k++) {
-        const uint32_t hi = pre[P - 1][k], lo = pre[(P >= 2) ? P - 2 : 0][k];
-        pre[P - 1][k] = ZN_BFI(0x80808080u, lo, hi >> 1);
-        pre[(P >= 2) ? P - 2 : 0][k] = ZN_BFI(0x7F7F7F7Fu, lo, hi << 7);
-      }
-    }
-    uint32_t lv = lane_v; ZN_OPAQUE32(lv);
-    uint8_t* o = (outq + row * UNIT * (uint32_t)P) + (uint32_t)EPL * lv * (uint32_t)P;
-    if (P == 1) {
-      ZN_ST128(o, pre[0][0], pre[0][1 % EW], pre[0][2 % EW], pre[0][3 % EW]);
-    } else if (P == 2) {
-      uint32_t x[4];
-      x[0] = __builtin_amdgcn_perm(pre[1 % P][0], pre[0][0], 0x05010400u); x[1] = __builtin_amdgcn_perm(pre[1 % P][0], pre[0][0], 0x07030602u);
-      x[2] = __builtin_amdgcn_perm(pre[1 % P][1 % EW], pre[0][1 % EW], 0x05010400u); x[3] = __builtin_amdgcn_perm(pre[1 % P][1 % EW], pre[0][1 % EW], 0x07030602u);
-      ZN_ST128(o, x[0], x[1], x[2], x[3]);
-    } else {
-      for (int half = 0; half < 2; half++) {
-        const int k = half % EW;
-        const uint32_t ab_lo = __builtin_amdgcn_perm(pre[1 % P][k], pre[0][k], 0x05010400u), ab_hi = __builtin_amdgcn_perm(pre[1 % P][k], pre[0][k], 0x07030602u);
-        const uint32_t cd_lo = __builtin_amdgcn_perm(pre[3 % P][k], pre[2 % P][k], 0x05010400u), cd_hi = __builtin_amdgcn_perm(pre[3 % P][k], pre[2 % P][k], 0x07030602u);
-        uint32_t x[4];
-        x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
-        x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-        *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);   // (two half-line stores per lane: not non-temporal, the L2 merges them)
-      }
-    }
-  };
-
-  const uint32_t rounds = rows / (uint32_t)Q;
-  uint32_t done_rows = 0;
-  if (allraw && rounds >= 2u) {
-    uint32_t pre[Q][P][EW];
-    // round 0's requests, then: first round / steady rounds / last round (no requests) as three copies of one body
-    zn_static_for<0, Q>([&](auto S) { constexpr int s_ = decltype(S)::v; request(pre[s_], (uint32_t)s_, false); });
-    auto round = [&](uint32_t r0, auto AHEAD) {
-      zn_static_for<0, Q>([&](auto S) {
-        constexpr int s_ = decltype(S)::v;
-        move_row(pre[s_], r0 + (uint32_t)s_, false);
-        if constexpr (decltype(AHEAD)::v != 0) request(pre[s_], r0 + (uint32_t)(Q + s_), false);
-      });
-    };
-    round(0u, ZnIdx<1>{});
-    for (uint32_t r = 1; r + 1u < rounds; r++) round(r * (uint32_t)Q, ZnIdx<1>{});
-    round((rounds - 1u) * (uint32_t)Q, ZnIdx<0>{});
-    done_rows = rounds * (uint32_t)Q;
-  }
-  // what the pipelined rounds do not take — a last few rows, a chunk with a constant (RLE) plane, a tiny chunk — row by row
-  for (uint32_t row = done_rows; row < rows; row++) { uint32_t pre1[P][EW]; request(pre1, row, true); move_row(pre1, row, true); }
 }
 
 // (b = index of the tail workgroup inside the launch; runs as the FIRST workgroups of zn_k_decode_fused, so that
@@ -980,8 +758,8 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg*
   if (ZN_F_DCAP && Du > ZN_F_DCAP && st.dom < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
   Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
   const bool ok = (Du == ZN_F_DCONST)
-    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true, nullptr, nullptr ZN_PT_PASS)
-    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true, nullptr, nullptr ZN_PT_PASS);
+    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
+    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
   if (lane == 0) L.what[wave] = ok ? 1u : 0u;
   __syncthreads();
   if (tid == 0) {
@@ -1004,7 +782,7 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // (wave-uniform, and the compiler should know: everything derived from it lives in scalar registers)
-  uint32_t* ring = L.ring[wave & 3u]; uint32_t* in = L.in[wave & 3u];
+  uint32_t* ring = L.ring[wave]; uint32_t* in = L.in[wave];
   bool ok = true;
   ZN_PT_SHARED;
   for (int p2 = 1; p2 < P; p2++) {
@@ -1036,10 +814,9 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
     uint32_t Du2 = ((ZN_F_RING_BYTES - UNIT - 128u) * slen2) / (256u * seg);
     Du2 = Du2 > ZN_F_DMAX ? ZN_F_DMAX : (Du2 < 1u ? 1u : Du2);
     Du2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du2);
-#define ZN_ACC_ARGS g, body, body_end, outq, outq, pl2, rawq, L.lut, ring, in, lane, seg, TL2, Du2, stream2, slen2, false, nullptr, nullptr ZN_PT_PASS
-    bool ok2 = true;
-    if (wave >= 4u) { }                      // (the mover wave of a specialised workgroup sits these passes out; it only keeps the barrier count)
-    else if (p2 == 1) ok2 = zn_fused_wave<P, (P >= 2 ? 1 : 0), 0, true>(ZN_ACC_ARGS);
+#define ZN_ACC_ARGS g, body, body_end, outq, outq, pl2, rawq, L.lut, ring, in, lane, seg, TL2, Du2, stream2, slen2, false ZN_PT_PASS
+    bool ok2;
+    if (p2 == 1) ok2 = zn_fused_wave<P, (P >= 2 ? 1 : 0), 0, true>(ZN_ACC_ARGS);
     else if (p2 == 2) ok2 = zn_fused_wave<P, (P >= 4 ? 2 : 0), 0, true>(ZN_ACC_ARGS);
     else ok2 = zn_fused_wave<P, (P >= 4 ? 3 : 0), 0, true>(ZN_ACC_ARGS);
 #undef ZN_ACC_ARGS
@@ -1058,59 +835,18 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
 #ifndef ZN_F_XWAVES
 #define ZN_F_XWAVES ZN_F_WAVES_PER_SIMD
 #endif
-static_assert(sizeof(ZnFusedLds) * ZN_F_WAVES_PER_SIMD <= 160u * 1024u || ZN_F_RING_BYTES < 4096u, "ZnFusedLds: the LDS budget of ZN_F_WAVES_PER_SIMD workgroups per CU");
-// The plain instances run the specialised form (ZN_F_SPEC): five waves per workgroup — four decode waves and the mover — and five waves
-// per SIMD (ZN_F_WAVES_PER_SIMD workgroups per CU as before: the LDS budget has not changed, the register budget is 96).
-#define ZN_F_SPECK(X_) (ZN_F_SPEC && !(X_))
-#ifndef ZN_F_PERSIST
-#define ZN_F_PERSIST 0
-#endif
-#define ZN_F_PERSIST_K(X_) (ZN_F_PERSIST && ZN_F_SPECK(X_))
-#ifndef ZN_F_SPEC_WAVES
-#define ZN_F_SPEC_WAVES 6                  // waves per SIMD the register budget is cut for: 6 = 80 VGPRs, three 8-wave workgroups per CU
-#endif
-#ifdef ZN_F_SPEC_VGPRS
-#define ZN_F_VGPR_ATTR __attribute__((amdgpu_waves_per_eu(6, 6)))         // (honoured only while the static LDS size allows that many waves)
-#else
-#define ZN_F_VGPR_ATTR
-#endif
+static_assert(sizeof(ZnFusedLds) * ZN_F_WAVES_PER_SIMD <= 160u * 1024u, "ZnFusedLds: the LDS budget of ZN_F_WAVES_PER_SIMD workgroups per CU");
 template <int P, bool X>
-#ifdef ZN_F_SPEC_VGPRS
-__global__ ZN_F_VGPR_ATTR __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS) void zn_k_decode_fused(
-#else
-__global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
-                             ZN_F_SPECK(X) ? ZN_F_SPEC_WAVES : (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(
-#endif
-                                                                  ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+__global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                   uint32_t* __restrict__ status, uint32_t ntail,
-                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done,
-                                                                  uint32_t nwg, uint32_t* __restrict__ work) {
+                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
-  if (blockIdx.x < ntail) {
-    if (threadIdx.x >= ZN_F_THREADS) return;       // (a tail workgroup is four decode waves in the classic form: the mover leaves)
-    zn_decode_tail_wg(L, one, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return;
-  }
-  // PERSISTENT workgroups (the specialised form): the grid is no larger than what the chip holds at once (workgroup slots x CUs) and
-  // every workgroup draws chunk groups from a counter until none is left.  Five-wave workgroups only pack four to a CU while they are
-  // placed in one sweep at the start of the launch: the hardware deals a workgroup's waves to the SIMDs in a fixed rotation, the
-  // fifth wave doubles up on one SIMD, and a workgroup that starts later, in the slots another one left, mostly finds that SIMD
-  // full (measured with one workgroup per group: 11.5 waves resident per CU instead of 20).  The first group is the block's own.
-  uint32_t wg = blockIdx.x - ntail;            // index among the full-chunk groups
-  const uint32_t npersist = gridDim.x - ntail;
-  for (bool first_round = true;; first_round = false) {
-  if (ZN_F_PERSIST_K(X)) {
-    if (!first_round) {
-      __syncthreads();                         // every wave is done with the previous group's tables, rings and flags
-      if (threadIdx.x == 0) L.work = npersist + atomicAdd(work, 1u);
-      __syncthreads();
-      wg = zn_uniform(L.work);
-    }
-    if (wg >= nwg) break;
-  }
+  if (blockIdx.x < ntail) { zn_decode_tail_wg(L, one, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return; }
+  const uint32_t wg = blockIdx.x - ntail;      // workgroup index among the full-chunk groups
   // (the segment comes back through private memory — a kernel argument or a table entry, chosen at run time — which makes
   //  every field per-lane data to the compiler: 64-bit pointers in vector registers, spilled and reloaded once per chunk,
   //  0.17 GB of scratch reads per GiB decoded.  They are uniform: scalar registers.)
@@ -1182,7 +918,6 @@ __global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
   for (uint32_t j = 0; j < nc; j++) {
     const uint64_t c = c0 + j;
     if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
-    if (ZN_F_SPECK(X) && tid < 8u) L.prod[tid] = 0;           // (prod[4], cons[4] are adjacent; seen by everybody behind the barriers of the LUT fill)
     ZN_PT(21);  // wait for the slowest wave of the previous chunk
     const uint32_t what = zn_uniform(L.what[j]);          // (what comes out of LDS or HBM below is wave-uniform: scalar registers, scalar branches)
     if (what == 0u) { ZN_SET_DONE(c, 0); continue; }
@@ -1205,7 +940,6 @@ __global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
       const ZnWaveStats st = L.st[j];
       const int hs = (int)zn_uniform((uint32_t)st.hs); TL = zn_uniform(st.tl);
       if (ZN_F_PRIO_FILL) ZN_PRIO(ZN_F_PRIO_FILL);
-      if (!((ZN_F_ABL & 16) && j > 0))
       zn_fused_fill_luts(L, tid, TL, j, zn_uniform(st.lmin));
       if (ZN_F_PRIO_FILL) ZN_PRIO(0);
       // jump table → this wave's stream
@@ -1222,25 +956,6 @@ __global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
     if (bad) { ZN_SET_DONE(c, 0); continue; }   // malformed jump table: the generic path reports it
 
     // ---- per-wave: decode the stream tile by tile, flush rows ----
-    // ---- the specialised form: waves 0-3 decode into their rings, wave 4 moves the rows (zn_mover_role) ----
-    const bool spec = ZN_F_SPECK(X) && h >= 0 && more == 0u;
-    if (ZN_F_SPECK(X) && wave >= 4u) {
-      if (spec) {
-        const uint32_t ws = wave - 4u;                 // the stream this mover serves
-        uint8_t* outq = dst + c * g.chunk + (uint64_t)ws * (g.chunk / 4u);
-#define ZN_MOVER_ARGS g, body, outq, pl, L.ring[ws], &L.prod[ws], &L.cons[ws], ws, seg
-        if (P == 1 || h == 0) zn_mover_role<P, 0>(ZN_MOVER_ARGS);
-        else if (P == 2 || h == 1) zn_mover_role<P, (P >= 2 ? 1 : 0)>(ZN_MOVER_ARGS);
-        else if (h == 2) zn_mover_role<P, (P >= 4 ? 2 : 0)>(ZN_MOVER_ARGS);
-        else zn_mover_role<P, (P >= 4 ? 3 : 0)>(ZN_MOVER_ARGS);
-#undef ZN_MOVER_ARGS
-      }
-#ifndef ZN_F_ONLY_HOT
-      if (P >= 2 && __builtin_expect(more != 0u, 0)) (void)zn_fused_more_passes<P>(L, g, body, body_end, nullptr, j, more, seg ZN_PT_PASS);     // (barriers only)
-#endif
-      ZN_SET_DONE(c, 1);                        // (tid ≥ 256: writes nothing; keeps the control flow of the two roles in step)
-      continue;
-    }
     const uint8_t* rawq[P];
     for (int p = 0; p < P; p++) rawq[p] = body + pl[p].off + (uint64_t)wave * seg;
     uint8_t* outq = dst + c * g.chunk + (uint64_t)wave * (g.chunk / 4u);
@@ -1256,17 +971,13 @@ __global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
     else if (ZN_F_DCAP && Du > ZN_F_DCAP && zn_uniform(L.st[j].dom) < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
     Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
     bool ok;
-#define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false, &L.prod[wave], &L.cons[wave] ZN_PT_PASS
-    // (a chunk in the specialised form takes the SPEC instances — decode and compact only; the classic instances are left for the
-    //  chunks with further Huffman planes, whose first pass writes the rows itself)
-#define ZN_WAVE_CASE_(H_, S_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X, S_>(ZN_WAVE_ARGS) \
-                            : (dense) ? zn_fused_wave<P, H_, ((X || P > 2 || !ZN_F_DCONST2) ? 0 : ZN_F_DCONST2), X, S_>(ZN_WAVE_ARGS) \
-                            : zn_fused_wave<P, H_, 0, X, S_>(ZN_WAVE_ARGS)
-#define ZN_WAVE_CASE(H_) do { if (ZN_F_SPECK(X) && spec) { ZN_WAVE_CASE_(H_, (ZN_F_SPECK(X))); if (!ok) zn_poke(&L.prod[wave], ZN_SPEC_POISON, lane); } \
-                              else if (!ZN_F_SPECK(X) || P >= 2) { ZN_WAVE_CASE_(H_, false); } else ok = false; } while (0)
+#define ZN_WAVE_ARGS g, body, body_end, outq, xq, pl, rawq, L.lut, ring, in, lane, seg, TL, Du, stream, slen, false ZN_PT_PASS
+#define ZN_WAVE_CASE(H_) ok = (Du == ZN_F_DCONST) ? zn_fused_wave<P, H_, ZN_F_DCONST, X>(ZN_WAVE_ARGS) \
+                            : (dense) ? zn_fused_wave<P, H_, ((X || P > 2 || !ZN_F_DCONST2) ? 0 : ZN_F_DCONST2), X>(ZN_WAVE_ARGS) \
+                            : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
     // (one instance per Huffman plane index that exists for this P — nothing is instantiated twice)
 #ifdef ZN_F_ONLY_HOT      // (developer probe: the common instance alone, to read its register use off the compiler's remarks)
-    if (P == 2) ok = zn_fused_wave<P, (P >= 2 ? 1 : 0), ZN_F_DCONST, X, ZN_F_SPECK(X)>(ZN_WAVE_ARGS); else
+    if (P == 2) ok = zn_fused_wave<P, (P >= 2 ? 1 : 0), ZN_F_DCONST, X>(ZN_WAVE_ARGS); else
 #endif
     if (h < 0) ok = zn_fused_wave<P, -1, 0, X>(ZN_WAVE_ARGS);
     else if (P == 1 || h == 0) ZN_WAVE_CASE(0);
@@ -1274,7 +985,6 @@ __global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
     else if (h == 2) ZN_WAVE_CASE((P >= 4 ? 2 : 0));
     else ZN_WAVE_CASE((P >= 4 ? 3 : 0));
 #undef ZN_WAVE_CASE
-#undef ZN_WAVE_CASE_
 #undef ZN_WAVE_ARGS
     // ---- further Huffman planes (deltas, sparse tensors: every plane compresses): one more pass per plane
 #ifndef ZN_F_ONLY_HOT
@@ -1289,8 +999,6 @@ __global__ __launch_bounds__(ZN_F_SPECK(X) ? ZN_F_THREADS_SPEC : ZN_F_THREADS,
     ZN_PT_COUNT(19, 1);                        // chunks
   }
   ZN_PT_FLUSH();
-  if (!ZN_F_PERSIST_K(X)) break;
-  }
 }
 
 // The Huffman-coded planes of a PARTIAL last chunk: one workgroup per plane, wave w = stream w, with the same
@@ -1309,7 +1017,7 @@ extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
 // chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
 // outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
 static std::atomic<int> g_zn_decode_group{0};
-static uint32_t zn_decode_fused_slots() {
+uint32_t zn_decode_fused_group(uint64_t K) {
   static std::atomic<int> slots_of[64];          // per device (a node may mix parts); 0 = not asked yet
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
@@ -1320,10 +1028,6 @@ static uint32_t zn_decode_fused_slots() {
     slots = cus * ZN_F_WAVES_PER_SIMD;
     slots_of[dev].store(slots, std::memory_order_relaxed);     // (racing first calls store the same value)
   }
-  return (uint32_t)slots;
-}
-uint32_t zn_decode_fused_group(uint64_t K) {
-  const uint32_t slots = zn_decode_fused_slots();
   uint32_t ncg = (uint32_t)(K / (uint64_t)slots);
   ncg = ncg > 4u ? 4u : (ncg < 1u ? 1u : ncg);
   const int forced = g_zn_decode_group.load(std::memory_order_relaxed);      // zn_set_decode_group (include/zipnn_hip.h): 0 = automatic
@@ -1340,12 +1044,8 @@ void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
                             uint8_t* d_tail_done, bool delta, hipStream_t stream) {
   if (total_wg == 0) return;
-  const uint32_t nwg = total_wg;
-  // (the persistent form: as many workgroups as the chip holds at once; they draw the groups beyond their own from d_status[4 + q])
-  uint32_t* d_work = d_status + 4 + (P == 1 ? 0 : P == 2 ? 1 : 2);
-  if (ZN_F_PERSIST_K(delta)) { const uint32_t slots = zn_decode_fused_slots(); if (total_wg > slots) total_wg = slots; }
   total_wg += ntail;                             // the tail workgroups come first
-#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_>), dim3(total_wg), dim3(ZN_F_SPECK(X_) ? ZN_F_THREADS_SPEC : ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, nwg, d_work)
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done)
   if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
   else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO

@@ -47,9 +47,6 @@ __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { const zn_ev4u v = _
 __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { return *(const uint4*)p; }
 #endif
 #define ZN_LD_STATS(p) zn_ldnt128(p)
-#ifndef ZN_E_ABL
-#define ZN_E_ABL 0                         // developer builds only (ZN_DEV_BUILD, zn_common.hpp): timing experiments with WRONG statistics
-#endif
 #ifndef ZN_E_EMIT_REVERSE
 #define ZN_E_EMIT_REVERSE 0               // 1: emit walks the chunks from the last one down (what the stats pass read last is what the 256 MB Infinity Cache still holds); measured ±0 at 4 GiB
 #endif
@@ -140,9 +137,6 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
     }
   };
   uint4 nx[4];
-#if ZN_E_ABL
-  uint32_t abl_sink = 0;
-#endif
   if (ZN_E_STATS_AHEAD) fetch(nx, 0u, tid);
   for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
   __syncthreads();
@@ -163,9 +157,6 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
           for (int t = 0; t < 4; t++) {
             const uint32_t b = (d[k] >> (8 * t)) & 0xFFu;
             const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;           // plane of byte t of a dword
-#if ZN_E_ABL                               // (timing experiments only: wrong statistics)
-            if ((ZN_E_ABL & 2) || ((ZN_E_ABL & 1) && (p & 1))) { abl_sink += b; continue; }
-#endif
             atomicAdd(hbase + (uint32_t)(p >> 1) * (256u * COLS) + b * COLS, (p & 1) ? 65536u : 1u);
           }
       }
@@ -183,9 +174,6 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
     __syncthreads();
   }
   ZN_PT(0);   // zero + histograms
-#if ZN_E_ABL
-  if (abl_sink == 0x12345678u) L.hist[0][tid] = abl_sink;
-#endif
 
   // ---- per plane: largest count, highest symbol, and the cheap exits of HUF_compress ----
   // (the histogram is dead from here on — the last column sum ended with a barrier —: its first 8·P dwords hold the

@@ -5,6 +5,7 @@ scripts/zipnn_decompress_safetensors.py:34-136: every floating-point tensor that
 `znn_compressed_vectors`; everything else is stored untouched.  Suffix: `.znn.safetensors`.
 """
 import os
+import struct
 
 import torch
 
@@ -170,10 +171,12 @@ def decode_file_on_device(filename, device, compressed_only=False, timings=None)
         arena = torch.empty(max(total, 16), dtype=torch.uint8, device=dev) if use_arena else None
         outs = [None] * len(plan) if use_arena else [torch.empty(fp[5], dtype=torch.uint8, device=dev) for (_, _, _, fp, _) in plan]
         base_in, base_out = blob.data_ptr(), (arena.data_ptr() if use_arena else 0)
+        pack = struct.Struct(_capi.ZN_BATCH_ITEM_FMT).pack
+        packed = b"".join([pack(base_in + b0, hi - b0, (((base_out + off) if use_arena else outs[i].data_ptr()) if fp[5] else 0), fp[5],
+                                fp[1], fp[2], fp[3], fp[4], 0) for i, (_, b0, hi, fp, off) in enumerate(plan)])
+        stream = codec._stream_handle(blob)
         with torch.cuda.device(dev) if dev.type == "cuda" else codec._nullctx():
-            lib.decompress_batch_dev(((base_in + b0, hi - b0, fp[1], fp[2], fp[3], fp[4], fp[5],
-                                       ((base_out + off) if use_arena else outs[i].data_ptr()) if fp[5] else 0)
-                                      for i, (_, b0, hi, fp, off) in enumerate(plan)), codec._stream_handle(blob), True)
+            lib.decompress_batch_dev_packed(packed, len(plan), stream, check=False)      # asynchronous: the verdict is asked for below
         # (views while the kernels run: one typed view of the arena per dtype, one as_strided per tensor)
         typed = {}
         for i, (name, _, _, fp, off) in enumerate(plan):
@@ -190,6 +193,9 @@ def decode_file_on_device(filename, device, compressed_only=False, timings=None)
                 out[name] = torch.as_strided(ta, shp, _contiguous_strides(shp), off // es)
             else:
                 out[name] = outs[i].view(dt).reshape(shape) if shape is not None else outs[i].view(dt)
+    if plan:
+        with torch.cuda.device(dev) if dev.type == "cuda" else codec._nullctx():
+            lib.decode_status(stream)                  # waits for the decode; raises for a corrupt frame exactly as a checked call would
     if not compressed_only:
         for name, (dt, shape, lo, hi) in layout.items():
             if name not in infos:
