@@ -361,13 +361,13 @@ def test_delta_xor_fused_into_the_kernels(simt_lib, case):
     assert "zn_k_decode_fused^delta" in simt_lib.last_kernels()
     if chunk % 16384 == 0:
         assert simt_lib.last_fused_chunks() == nb // chunk     # (a sparse delta: every plane is Huffman-coded)
-    # device entry points; the base at an odd address takes the generic kernels
+    # device entry points; the base at an odd address: every chunk is coded by the ragged-plane workgroups
     ta = torch.frombuffer(bytearray(a), dtype=torch.uint8)
     pad = torch.zeros(nb + 1, dtype=torch.uint8); pad[1:] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
     tb = pad[1:]
     body = codec.compress_device(simt_lib, ta, P, rot, bm, chunk, 0.95, delta=tb)
     assert body.numpy().tobytes() == want[32:]
-    assert "zn_k_encode_emit" not in simt_lib.last_kernels()
+    assert "zn_k_encode_emit^delta+tail" in simt_lib.last_kernels()        # (every plane by the tail workgroups of the fused launches)
     out = codec.decompress_device(simt_lib, body, P, rot, bm, chunk, nb, delta=tb)
     assert out.numpy().tobytes() == a
     assert simt_lib.last_fused_chunks() == 0
@@ -731,3 +731,15 @@ def test_tree_descriptions_written_by_the_wave_match_the_oracle(simt_lib):
             kinds["fse" if payload[start] < 128 else "raw4"] += 1
     assert kinds["fse"] >= 100 and kinds["raw4"] >= 20 and m2 >= 3, (kinds, m2)
     assert bytes(simt_lib.decompress(bytes(got)[32:], 1, 0, 10, chunk, len(d))) == d
+
+
+def test_ragged_planes_are_coded_inside_the_fused_launches(simt_lib):
+    """a tensor with a partial last chunk (and a geometry the fused kernels do not take at all) is compressed by the
+    same three launches as its full chunks — stats, tables, emit, with tail workgroups — and the scan; no split / encode / gather
+    kernels any more.  Bytes identical to the oracle's."""
+    for kind, nb, P, rot, bm, chunk in (("bf16", 3 * C + 250_001, 2, 1, 10, C), ("fp32", C + 4 * 999, 4, 1, 220, C), ("fp8", 2 * C + 777, 1, 1, 10, C),
+                                         ("bf16", 10 * 1000 + 6, 2, 1, 10, 1000), ("bf16", 37, 2, 1, 10, C)):
+        d = gen_bytes(kind, nb, 5)
+        assert bytes(simt_lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == O.compress_frame(HDR, d, P, rot, bm, chunk)
+        k = simt_lib.last_kernels()
+        assert k.split(";") == ["zn_k_encode_stats+tail", "zn_k_encode_tables", "zn_k_scan_sizes", "zn_k_encode_emit+tail"], k

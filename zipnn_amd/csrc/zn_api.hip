@@ -188,11 +188,10 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   const size_t nseg_all = segs[0].size() + segs[1].size() + segs[2].size();
   const bool table = nseg_all > 1;
   if ((rc = ws_reserve(w, WS_PLANES, slot_all * slot))) return rc;
-  if ((rc = ws_reserve(w, WS_ENC, slot_all * slot))) return rc;
   if ((rc = ws_reserve(w, WS_META_A, pc_all * sizeof(uint32_t)))) return rc;   // stored sizes
   if ((rc = ws_reserve(w, WS_META_B, pc_all))) return rc;                      // types
   if ((rc = ws_reserve(w, WS_META_C, pc_all * sizeof(uint64_t)))) return rc;   // payload offsets
-  if ((rc = ws_reserve(w, WS_DESC, (any_fused ? pc_all : 0) * sizeof(ZnEncDesc)))) return rc;
+  if ((rc = ws_reserve(w, WS_DESC, pc_all * sizeof(ZnEncDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_reserve(w, WS_TOTALS, count * sizeof(uint64_t)))) return rc;
   if ((rc = ws_host_words(w))) return rc;
@@ -231,15 +230,13 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
       const uint32_t nseg = (uint32_t)segs[q].size();
       const ZnESeg& one = segs[q][0];
       if (stage == 0) {
-        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream);
-        zn_launch_encode_generic_stats(P, one, d_segs, nseg, (uint32_t)tails_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES],
-                                       (uint8_t*)w.buf[WS_ENC], slot, d_csize, d_type, stream);
+        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES], slot,
+                                     d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream);
       } else if (stage == 1) {
         zn_launch_scan_sizes(one, d_segs, nseg, (uint32_t)scan_of[q], d_csize, d_type, d_offs, d_totals, stream);
       } else {
-        zn_launch_encode_fused_emit(P, one, d_segs, nseg, (uint32_t)chunks_of[q], d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, delta_of[q], stream);
-        zn_launch_encode_generic_gather(one, d_segs, nseg, (uint32_t)ptails_of[q], (const uint8_t*)w.buf[WS_PLANES], (const uint8_t*)w.buf[WS_ENC],
-                                        slot, d_csize, d_type, d_offs, stream);
+        zn_launch_encode_fused_emit(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)ptails_of[q], (const uint8_t*)w.buf[WS_PLANES], slot,
+                                    d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, delta_of[q], stream);
       }
       seg_base += nseg;
     }

@@ -100,11 +100,100 @@ struct ZnStatsLds {
 // quarter the columns are summed (thread = bin), which yields the per-stream symbol counts that turn code
 // lengths into stream sizes later without a second pass over the data.
 // X: the encoder sees src ^ xr (delta base; the host picks this instance when some tensor of the launch has one).
+// ---- RAGGED planes (the partial last chunk of a tensor; every chunk of a geometry the fused kernels do not take) ----
+// Extra workgroups BEHIND the full chunks of the same three launches (stats, tables, emit) — the encoder's counterpart of the decoder's
+// tail workgroups — so that a tensor's 250 KB tail is coded while its bulk is, instead of by three further kernels behind it (split /
+// encode / gather: 0.34 ms for one chunk, as long as 600 MB of bulk).  Stats: FOUR workgroups per (plane, chunk), one per huff0 stream
+// (a stream is ceil(n / 4) symbols, the last one what is left): each de-interleaves its quarter of the plane into the scratch slot (the
+// rotate of the reference, its un-rotated trailing bytes included) and counts it; the plane's decisions (RLE / raw / table) are taken
+// by its table job, which sees the four quarters' counts.  (One workgroup per plane took 80-130 µs for a 250 KB chunk — the whole stats
+// pass of a 100 MiB tensor takes 36.)  Reference: compression_worker csrc/zipnn_core.c:294-390 codes every chunk the same way.
+template <bool X>
+__device__ __forceinline__ void zn_encode_tail_stats(uint32_t* hist /* LDS: [256][32] */, const ZnESeg& S, uint64_t pcl, uint32_t q,
+                                                     uint8_t* __restrict__ planes_all, uint64_t slot, uint32_t* __restrict__ csize_all,
+                                                     uint8_t* __restrict__ type_all, ZnEncDesc* __restrict__ descs_all) {
+  const ZnGeom g = S.g; const uint64_t c0 = S.nfull, KL = g.K - c0;
+  const uint32_t P = g.P, p = (uint32_t)(pcl / KL);
+  const uint64_t c = c0 + pcl % KL, pc = (uint64_t)p * g.K + c;
+  const uint32_t clen = zn_chunk_len(g, c), n = zn_plane_len(clen, P, p);
+  const uint8_t* in = ZN_GLOBAL_PTR(const uint8_t, S.src) + c * g.chunk;
+  const uint8_t* xin = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;
+  uint8_t* pl = planes_all + (S.slot0 + pcl) * slot;
+  ZnEncDesc* D = descs_all + S.pc0 + pc;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const bool countable = n != 0u && n <= ZN_HUF_BLOCK_MAX;
+  if (!countable && q == 0u && tid == 0) { type_all[S.pc0 + pc] = 0; csize_all[S.pc0 + pc] = n; }   // empty, or larger than a huff0 block (HUF_compress: srcSize_wrong -> fails the threshold test): raw
+  const uint32_t seg = (n + 3u) / 4u;
+  // this workgroup's plane indices [i_lo, i_hi)
+  const uint32_t i_lo = (q * seg < n) ? q * seg : n, i_hi = (q == 3u) ? n : (((q + 1u) * seg < n) ? (q + 1u) * seg : n);
+  constexpr uint32_t TC = 32u;
+  uint32_t* hcol = hist + (lane & (TC - 1u));
+  for (uint32_t i = tid; i < 256u * TC; i += ZN_E_THREADS) hist[i] = 0;
+  __syncthreads();
+  const uint32_t nwords = clen / 4u;
+  auto one_byte = [&](uint32_t i) {              // plane byte i by itself: its source word, rotated — or a trailing byte, which keeps its place
+    const uint32_t j = i * P + p, wi = j >> 2;
+    uint32_t b;
+    if (wi < nwords) {
+      uint32_t w = zn_ld32(in + 4ull * wi);
+      if (xin) w ^= zn_ld32(xin + 4ull * wi);
+      if (g.rot) w = (P == 2) ? zn_rot_fwd16(w) : (P == 4) ? zn_rot_fwd32(w) : w;
+      b = (w >> (8u * (j & 3u))) & 0xFFu;
+    } else b = (uint32_t)(in[j] ^ (xin ? xin[j] : 0));
+    pl[i] = (uint8_t)b;
+    if (countable) atomicAdd(hcol + b * TC, 1u);
+  };
+  // whole 16-byte source vectors (16 / P consecutive bytes of this plane: P divides 4, so byte t of every word belongs to plane t mod P):
+  // four loads in flight per thread, ONE store per vector; the edges of the range, and everything when the source is not 16-byte aligned,
+  // byte by byte
+  const uint32_t per = 16u / P;
+  const bool aligned = ((((uint64_t)in) | ((uint64_t)xin)) & 15u) == 0;
+  uint32_t v_lo = (i_lo + per - 1u) / per, v_hi = i_hi / per;
+  if (v_hi > nwords / 4u) v_hi = nwords / 4u;
+  if (!aligned || v_hi < v_lo) { v_lo = 0; v_hi = 0; }
+  const uint32_t e_lo = (v_hi > v_lo) ? per * v_lo : i_hi, e_hi = (v_hi > v_lo) ? per * v_hi : i_hi;      // [i_lo, e_lo) and [e_hi, i_hi): the edges
+  for (uint32_t v0 = v_lo + tid; v0 < v_hi; v0 += 4u * ZN_E_THREADS) {
+    uint4 xs[4];
+    for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < v_hi) ? ZN_LD_STATS(in + 16ull * v) : make_uint4(0, 0, 0, 0); }
+    if (xin) for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < v_hi) { const uint4 t = ZN_LD_STATS(xin + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
+    for (int u = 0; u < 4; u++) {
+      const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u;
+      if (v >= v_hi) continue;
+      uint32_t d[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
+      if (g.rot) for (int k = 0; k < 4; k++) d[k] = (P == 2) ? zn_rot_fwd16(d[k]) : (P == 4) ? zn_rot_fwd32(d[k]) : d[k];
+      uint32_t o[4] = {0, 0, 0, 0};
+      if (P == 1) { for (int k = 0; k < 4; k++) o[k] = d[k]; }
+      else if (P == 2) { for (int k = 0; k < 4; k++) { const uint32_t h = ((d[k] >> (8u * p)) & 0xFFu) | (((d[k] >> (8u * p + 16u)) & 0xFFu) << 8); o[k >> 1] |= h << (16 * (k & 1)); } }
+      else { for (int k = 0; k < 4; k++) o[0] |= ((d[k] >> (8u * p)) & 0xFFu) << (8 * k); }
+      const uint32_t i0 = per * v;
+      if (P == 1) *(uint4*)(pl + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+      else if (P == 2) *(uint2*)(pl + i0) = make_uint2(o[0], o[1]);
+      else *(uint32_t*)(pl + i0) = o[0];
+      if (countable) for (uint32_t e = 0; e < per; e++) atomicAdd(hcol + ((o[e >> 2] >> (8u * (e & 3u))) & 0xFFu) * TC, 1u);
+    }
+  }
+  for (uint32_t i = i_lo + tid; i < e_lo; i += ZN_E_THREADS) one_byte(i);
+  for (uint32_t i = e_hi + tid; i < i_hi; i += ZN_E_THREADS) one_byte(i);
+  __syncthreads();
+  if (!countable) return;
+  uint32_t cum = 0;
+  for (uint32_t r = 0; r < TC; r++) cum += hist[tid * TC + ((r + tid) & (TC - 1u))];
+  D->qcount[q][tid] = (uint16_t)cum;             // (a quarter of a huff0 block: ≤ 32 768 symbols)
+}
+
 template <int P, bool X>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                   uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
-                                                                  ZnEncDesc* __restrict__ descs_all) {
+                                                                  ZnEncDesc* __restrict__ descs_all, uint32_t nchunks,
+                                                                  uint8_t* __restrict__ planes_all, uint64_t slot) {
   __shared__ ZnStatsLds<P> L;
+  if (blockIdx.x >= nchunks) {                   // a ragged plane (behind the full chunks)
+    const uint32_t tb = (blockIdx.x - nchunks) / 4u, tq = (blockIdx.x - nchunks) % 4u;       // four workgroups per ragged plane: one per stream
+    const ZnESeg S = zn_efind_ptail(one, segs, nseg, tb);
+    static_assert(sizeof(L.hist) >= 256u * 32u * sizeof(uint32_t), "a ragged quarter's counters lie over the histogram columns");
+    zn_encode_tail_stats<X>(&L.hist[0][0], S, tb - S.ptail0, tq, planes_all, slot, csize_all, type_all, descs_all);
+    return;
+  }
   const uint32_t sbid = blockIdx.x;
   const ZnESeg S = zn_efind_chunk(one, segs, nseg, sbid);
   const ZnGeom g = S.g;
@@ -221,18 +310,21 @@ struct ZnTablesLds {
 
 __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                          uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
-                                                         ZnEncDesc* __restrict__ descs_all) {
+                                                         ZnEncDesc* __restrict__ descs_all, uint32_t njobs) {
   __shared__ ZnTablesLds L;
-  const ZnESeg S = zn_efind_job(one, segs, nseg, blockIdx.x);
+  const bool ragged = blockIdx.x >= njobs;       // the jobs of the ragged planes come behind those of the full chunks
+  const ZnESeg S = ragged ? zn_efind_ptail(one, segs, nseg, blockIdx.x - njobs) : zn_efind_job(one, segs, nseg, blockIdx.x);
   const ZnGeom g = S.g; const uint64_t nfull = S.nfull; const float threshold = S.threshold;
   uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
   ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
   const uint32_t lane = threadIdx.x;
-  const uint64_t job = blockIdx.x - S.job0;
-  const uint32_t p = (uint32_t)(job / nfull);
-  const uint64_t c = job % nfull, pc = (uint64_t)p * g.K + c;
-  if (type_out[pc] != 2) return;
-  const uint32_t n = (uint32_t)(g.chunk / g.P);
+  uint32_t p; uint64_t c;
+  if (ragged) { const uint64_t KL = g.K - nfull, pcl = (uint64_t)(blockIdx.x - njobs) - S.ptail0; p = (uint32_t)(pcl / KL); c = nfull + pcl % KL; }
+  else { const uint64_t job = blockIdx.x - S.job0; p = (uint32_t)(job / nfull); c = job % nfull; }
+  const uint64_t pc = (uint64_t)p * g.K + c;
+  if (!ragged && type_out[pc] != 2) return;
+  const uint32_t n = ragged ? zn_plane_len(zn_chunk_len(g, c), g.P, p) : (uint32_t)(g.chunk / g.P);
+  if (ragged && (n == 0u || n > ZN_HUF_BLOCK_MAX)) return;       // stored raw by its stats workgroups
   const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
   ZnEncDesc* D = descs + pc;
   ZN_PT_DECL;
@@ -244,6 +336,19 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     for (int q = 0; q < 4; q++) { qv[q][k] = D->qcount[q][lane + 64u * (uint32_t)k]; cnt[k] += qv[q][k]; }
     const uint64_t m = __ballot(cnt[k] != 0);
     if (m) max_sv = 64u * (uint32_t)k + 63u - (uint32_t)__builtin_clzll(m);
+  }
+  if (ragged) {
+    // a ragged plane's decisions — the cheap exits of HUF_compress — are taken here, where the four quarters' counts meet (a full chunk's
+    // stats workgroup has taken them already)
+    uint32_t mx = 0;
+    for (int k = 0; k < 4; k++) mx = cnt[k] > mx ? cnt[k] : mx;
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d); if (m2 > mx) mx = m2; }
+    if (mx == n) {                               // RLE (threshold rule of compression_worker, zipnn_core.c:371-385)
+      const bool keep = 1.0 < (double)n * (double)threshold;
+      if (lane == 0) { type_out[pc] = keep ? 1 : 0; csize_out[pc] = keep ? 1u : n; if (keep) D->hdr[0] = (uint8_t)max_sv; }
+      return;
+    }
+    if (mx <= (n >> 7) + 4u) { if (lane == 0) { type_out[pc] = 0; csize_out[pc] = n; } return; }
   }
   for (uint32_t i = lane; i < 513u; i += 64u) { ZnHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nb = 0; L.nodes[i] = z; }
   __builtin_amdgcn_wave_barrier();
@@ -324,7 +429,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     const int h = zn_wave_write_ctable(&L.S, max_sv, wc, lane);
     if (h < 0) cs = 0xFFFFFFFFu;               // huff0 error → fails the threshold test → raw
     else if ((uint32_t)h + 12u >= n) cs = 0;
-    else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u) cs = 0;
+    else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u || n < 12u) cs = 0;      // (HUF_compress4X: a source of fewer than 12 bytes is not coded)
     else go = true;
     hdr_len = (uint32_t)(h > 0 ? h : 0);
   }
@@ -490,15 +595,131 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
   return true;
 }
 
+// One huff0 stream of a RAGGED plane, by one wave: codes of src[n-1] .. src[0], end mark, zero pad, LSB-first into dst (nbytes = the
+// stream size, known from the counts).  Tiles of 2048 symbols from the END of the segment — a lane packs 32 consecutive symbols, the
+// segment's first tile is the partial one —, otherwise the scheme of zn_emit_pass: pairs, quads of ≤ 44 bits, a prefix sum of the bit
+// counts places the lanes (lane 63 lowest), ds_or merges them in `buf` (ZN_E_BUF_DW + 4 dwords of LDS), whole dwords go out.
+__device__ __forceinline__ bool zn_pack_stream_ragged(uint8_t* dst, uint32_t nbytes, const uint8_t* src, uint32_t n, const uint32_t* code, uint32_t* buf, uint32_t lane) {
+  for (uint32_t i = lane; i < ZN_E_BUF_DW + 4u; i += 64u) buf[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  uint32_t carry = 0, written = 0;
+  const uint32_t ntiles = (n + ZN_E_TILE - 1u) / ZN_E_TILE;
+  for (uint32_t t = 0; t < ntiles; t++) {
+    const int32_t first = (int32_t)n - (int32_t)ZN_E_TILE * (int32_t)(t + 1u) + (int32_t)(ZN_E_SPL * lane);      // this lane's symbols: first .. first + 31 (negative: before the segment)
+    uint32_t cw[32];
+    if (first >= 0) {
+      const zn_eu128u a = *(const zn_eu128u*)(src + first), b2 = *(const zn_eu128u*)(src + first + 16);
+      const uint32_t dd[8] = {a.x, a.y, a.z, a.w, b2.x, b2.y, b2.z, b2.w};
+      for (int e = 0; e < 32; e++) cw[e] = code[(dd[e >> 2] >> (8 * (e & 3))) & 0xFFu];
+    } else {
+      for (int e = 0; e < 32; e++) { const int32_t i = first + e; cw[e] = (i >= 0) ? code[src[i]] : 0u; }
+    }
+    uint64_t qv[8]; uint32_t qn[8];
+    for (int i = 0; i < 8; i++) {
+      uint32_t pv[2], pn[2];
+      for (int h = 0; h < 2; h++) {
+        const uint32_t c0 = cw[4 * i + 2 * h], c1 = cw[4 * i + 2 * h + 1];
+        pv[h] = ((c0 & 0xFFFFu) << (c1 >> 16)) | (c1 & 0xFFFFu);                 // the later symbol takes the lower bits
+        pn[h] = (c0 >> 16) + (c1 >> 16);
+      }
+      qv[i] = ((uint64_t)pv[0] << pn[1]) | pv[1];
+      qn[i] = pn[0] + pn[1];
+    }
+    uint32_t qo[8]; uint32_t T = 0;
+    for (int i = 7; i >= 0; i--) { qo[i] = T; T += qn[i]; }
+    uint32_t total = 0;
+    const uint32_t excl = zn_wave_excl_scan_u32(T, &total);
+    const uint32_t b = carry + (total - excl - T);
+    for (int i = 0; i < 8; i++) {
+      const uint32_t bp = b + qo[i], idx = bp >> 5, sh = bp & 31u;
+      const uint64_t lo = qv[i] << sh;
+      const uint32_t w2 = (uint32_t)(((qv[i] >> 32) << sh) >> 32);
+      if ((uint32_t)lo) atomicOr(&buf[idx], (uint32_t)lo);
+      if ((uint32_t)(lo >> 32)) atomicOr(&buf[idx + 1u], (uint32_t)(lo >> 32));
+      if (w2) atomicOr(&buf[idx + 2u], w2);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t bits = carry + total, nd = bits >> 5;
+    if (written + 4u * nd > nbytes) return false;
+    uint32_t tail = 0;
+    for (uint32_t i = lane; i <= nd; i += 64u) {
+      const uint32_t x = buf[i];
+      if (i < nd) *(zn_eu32u*)(dst + written + 4u * i) = x;
+      if (i == nd) tail = x;
+      buf[i] = 0;
+    }
+    tail = __shfl(tail, (int)(nd & 63u));
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) buf[0] = tail;
+    __builtin_amdgcn_wave_barrier();
+    written += 4u * nd; carry = bits & 31u;
+  }
+  if (lane == 0) {
+    const uint32_t x = buf[0] | (1u << carry);             // end mark; the stream ends in a non-zero byte
+    const uint32_t nb = (carry + 1u + 7u) >> 3;
+    if (written + nb != nbytes) buf[1] = 0xDEAD;
+    else for (uint32_t k = 0; k < nb; k++) dst[written + k] = (uint8_t)(x >> (8 * k));
+  }
+  __builtin_amdgcn_wave_barrier();
+  return buf[1] != 0xDEAD;
+}
+
+// A ragged plane's bytes to their place in the body: the scratch plane as it is (raw), its one byte (RLE), or the huff0 block —
+// tree description, jump table, and wave w packs stream w.
+__device__ __forceinline__ void zn_encode_tail_emit(uint32_t* code /* LDS [256] */, uint32_t (*buf)[ZN_E_BUF_DW + 4], const ZnESeg& S, uint64_t pcl,
+                                    const uint8_t* __restrict__ planes_all, uint64_t slot, const uint32_t* __restrict__ csize_all,
+                                    const uint8_t* __restrict__ type_all, const uint64_t* __restrict__ offs_all,
+                                    const ZnEncDesc* __restrict__ descs_all, uint32_t* __restrict__ status) {
+  const ZnGeom g = S.g; const uint64_t c0 = S.nfull, KL = g.K - c0;
+  const uint32_t p = (uint32_t)(pcl / KL);
+  const uint64_t c = c0 + pcl % KL, pc = (uint64_t)p * g.K + c;
+  const uint32_t n = zn_plane_len(zn_chunk_len(g, c), g.P, p);
+  const uint8_t* pl = planes_all + (S.slot0 + pcl) * slot;
+  uint8_t* d = ZN_GLOBAL_PTR(uint8_t, S.body) + offs_all[S.pc0 + pc];
+  const uint32_t ty = type_all[S.pc0 + pc], cs = csize_all[S.pc0 + pc];
+  const ZnEncDesc* D = descs_all + S.pc0 + pc;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (!ty) {                                     // raw: 16 bytes per thread where source and destination allow it (the slot is 16-byte aligned)
+    const uint32_t head = (uint32_t)((16u - ((uint64_t)d & 15u)) & 15u) < n ? (uint32_t)((16u - ((uint64_t)d & 15u)) & 15u) : n;
+    for (uint32_t i = tid; i < head; i += ZN_E_THREADS) d[i] = pl[i];
+    const uint32_t nv = (n - head) / 16u;
+    for (uint32_t v0 = tid; v0 < nv; v0 += 4u * ZN_E_THREADS) {           // four vectors in flight per thread
+      zn_eu128u x[4];
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nv) x[u] = *(const zn_eu128u*)(pl + head + 16u * v); }
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nv) *(uint4*)(d + head + 16u * v) = make_uint4(x[u].x, x[u].y, x[u].z, x[u].w); }
+    }
+    for (uint32_t i = head + 16u * nv + tid; i < n; i += ZN_E_THREADS) d[i] = pl[i];
+    return;
+  }
+  if (cs == 1u) { if (tid == 0) d[0] = D->hdr[0]; return; }
+  const uint32_t hl = D->hdr_len;
+  for (uint32_t i = tid; i < hl; i += ZN_E_THREADS) d[i] = D->hdr[i];
+  if (tid < 3u) { const uint32_t s = D->ssize[tid]; d[hl + 2u * tid] = (uint8_t)s; d[hl + 2u * tid + 1u] = (uint8_t)(s >> 8); }
+  code[tid] = D->code[tid];
+  __syncthreads();
+  const uint32_t seg = (n + 3u) / 4u;
+  uint32_t so = hl + 6u;
+  for (uint32_t k = 0; k < wave; k++) so += D->ssize[k];
+  const uint32_t len = (wave < 3u) ? seg : n - 3u * seg;
+  if (!zn_pack_stream_ragged(d + so, D->ssize[wave], pl + wave * seg, len, code, buf[wave], lane)) { if (lane == 0) atomicOr(status, ZN_DEV_CORRUPT); }
+}
+
 template <int P, bool X>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                  const uint32_t* __restrict__ csize_all, const uint8_t* __restrict__ type_all,
                                                                  const uint64_t* __restrict__ offs_all, const ZnEncDesc* __restrict__ descs_all,
-                                                                 uint32_t* __restrict__ status) {
+                                                                 uint32_t* __restrict__ status, uint32_t nchunks,
+                                                                 const uint8_t* __restrict__ planes_all, uint64_t slot) {
   __shared__ ZnEmitLds<P> L;
+  if (blockIdx.x >= nchunks) {                   // a ragged plane (behind the full chunks)
+    const uint32_t tb = blockIdx.x - nchunks;
+    const ZnESeg S = zn_efind_ptail(one, segs, nseg, tb);
+    zn_encode_tail_emit(L.code, L.buf, S, tb - S.ptail0, planes_all, slot, csize_all, type_all, offs_all, descs_all, status);
+    return;
+  }
   // ZN_E_EMIT_REVERSE: the emit pass walks the chunks from the last one down — what the stats pass read last is what the
   // Infinity Cache (256 MB, memory side) still holds
-  const uint32_t bid = ZN_E_EMIT_REVERSE ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const uint32_t bid = ZN_E_EMIT_REVERSE ? nchunks - 1u - blockIdx.x : blockIdx.x;
   const ZnESeg S = zn_efind_chunk(one, segs, nseg, bid);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
@@ -558,9 +779,11 @@ bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr) {
 }
 
 void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
+                                  uint32_t total_ptails, uint8_t* d_planes, uint64_t slot,
                                   uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream) {
-  if (total_chunks == 0) return;
-#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_stats<P_, X_>), dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs)
+  if (total_chunks + total_ptails == 0) return;
+  // (the ragged planes — total_ptails of them — are further workgroups of the same launches, behind the full chunks / their table jobs)
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_stats<P_, X_>), dim3(total_chunks + 4u * total_ptails), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, total_chunks, d_planes, slot)
   // (the table kernel is serial-latency bound — ≈65 µs per job, ≈5 600 jobs on the chip at once, 0.21 ms for the 16 384 chunks of
   //  4 GiB.  Building the tables of one slab of chunks on a second stream while the stats kernel reads the next was tried in round 2
   //  and removed in round 3: 2.431 ms per call without, 2.440 / 2.464 / 2.548 ms with 2 / 4 / 8 slabs — the cross-stream event
@@ -568,18 +791,19 @@ void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs
   if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
   else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO
-  zn_note_kernel(delta ? "zn_k_encode_stats^delta" : "zn_k_encode_stats");
-  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs);
+  zn_note_kernel(delta ? (total_ptails ? "zn_k_encode_stats^delta+tail" : "zn_k_encode_stats^delta") : (total_ptails ? "zn_k_encode_stats+tail" : "zn_k_encode_stats"));
+  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs + total_ptails), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, total_jobs);
   zn_note_kernel("zn_k_encode_tables");
 }
 
-void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
+void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_ptails,
+                                 const uint8_t* d_planes, uint64_t slot,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
                                  uint32_t* d_status, bool delta, hipStream_t stream) {
-  if (total_chunks == 0) return;
-#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_emit<P_, X_>), dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status)
+  if (total_chunks + total_ptails == 0) return;
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_emit<P_, X_>), dim3(total_chunks + total_ptails), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_descs, d_status, total_chunks, d_planes, slot)
   if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
   else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO
-  zn_note_kernel(delta ? "zn_k_encode_emit^delta" : "zn_k_encode_emit");
+  zn_note_kernel(delta ? (total_ptails ? "zn_k_encode_emit^delta+tail" : "zn_k_encode_emit^delta") : (total_ptails ? "zn_k_encode_emit+tail" : "zn_k_encode_emit"));
 }

@@ -80,20 +80,19 @@ struct ZnESeg {
 // Slot stride of the generic path's scratch planes = zn_plane_slot(chunk, P).  All launchers: `one` when
 // d_segs == nullptr, else the table; grid totals are sums over the launch's tensors.
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr);    // d_xr: delta base or null
+// total_ptails ragged planes (partial last chunks, geometries the fused kernels do not take) ride along as further workgroups of the same
+// launches; d_planes / slot: their scratch planes (slot0 of a segment = its first slot)
 void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
+                                  uint32_t total_ptails, uint8_t* d_planes, uint64_t slot,
                                   uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream);
-void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks,
+void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_ptails,
+                                 const uint8_t* d_planes, uint64_t slot,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
                                  uint32_t* d_status, bool delta, hipStream_t stream);
-void zn_launch_encode_generic_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_tails, uint32_t total_ptails,
-                                    uint8_t* d_planes, uint8_t* d_enc, uint64_t slot, uint32_t* d_csize, uint8_t* d_type, hipStream_t stream);
 // per-tensor scan over ALL its chunks: types, cumSizes (into the body), payload offsets, total body length → d_total[total_idx]
 void zn_launch_scan_sizes(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_blocks, const uint32_t* d_csize,
                           const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, hipStream_t stream);
 void zn_scan_geometry(uint64_t PK, uint64_t* T, uint32_t* blocks);     // entries per block / number of blocks for PK entries
-void zn_launch_encode_generic_gather(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_ptails, const uint8_t* d_planes,
-                                     const uint8_t* d_enc, uint64_t slot, const uint32_t* d_csize, const uint8_t* d_type,
-                                     const uint64_t* d_offs, hipStream_t stream);
 
 // kernel-name log for zn_last_kernels()
 void zn_note_kernel(const char* name);
