@@ -106,6 +106,8 @@ VARIANTS = {
     "nmis2": (None, ["-DZN_F_NMIS=2"]),
     # round 4: wave specialisation (four decode waves + mover waves per workgroup) — the code lives in commit b49b217 only (profiles/r04_decode_experiments.txt)
     "r03": ("3c0f9d7", []),                         # the kernels of the round-3 final state
+    "nopipe": (None, ["-DZN_F_PIPE=0"]),
+    "p12cond": (None, ["-DZN_F_P12_UNCOND=0"]),     # zn_pass12 with masked atomics (the compiler then waits lgkmcnt(0) at every look-up)            # the tiles' passes one after the other (no zn_pass12)
     "spec8": ("b49b217", []),                       # 8-wave workgroups (4 decode + 4 movers), 80 VGPRs
     "spec8w5": ("b49b217", ["-DZN_F_SPEC_WAVES=5"]),   # … 96 VGPRs: two workgroups per CU
     "spec8free": ("b49b217", ["-DZN_F_ABL=96"]),    # … timing only: neither side of the hand-over waits
@@ -147,7 +149,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "r03", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
+ALLD = ("r01", "r02", "r03", "nopipe", "p12cond", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
 
 
 def run(names):
