@@ -149,7 +149,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "r03", "nopipe", "p12cond", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
+ALLD = ("r01", "r02", "r03", "pipe", "pipecond", "pipeoff", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
 
 
 def run(names):

@@ -245,86 +245,6 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
   return true;
 }
 
-// ---- the two passes of CONSECUTIVE tiles, step by step in one instruction stream (round 4) ----------------------------------------
-// Measured with one workgroup per CU (profiles/r04_decode_experiments.txt): the decode pass of a tile takes the same 3.4 k cycles
-// whether the CU is otherwise empty or full, and so do the compaction (2.3 k) and the run-in (1.4 k) — a wave is bound by ITS OWN
-// chain: a dependent LUT look-up of ~170 cycles a step in the decode pass (ten instructions issued, the wave idle for the rest),
-// the issue cadence of one instruction every ~5 cycles in the compaction (seventeen instructions a step, nothing to wait for).
-// The two are complementary, and they touch the record one slot at a time in the same order: step i of the compaction of tile t READS
-// slot i, step i of the decode pass of tile t + 1 WRITES it.  So both run in one loop — slot i is drained, then refilled — the
-// compaction's instructions fill the look-up's latency, and the record needs no second set of registers.
-// Arguments: zn_pass1's for the new tile, zn_pass2's (stage, wpos, nfull_prev, nbnd_prev) for the one in the record.  Returns what
-// zn_pass1 returns; the previous tile's compaction is complete either way.
-template <int TF, int TB, int U>
-__device__ __forceinline__ bool zn_pass12(const uint2* lut, const uint32_t* in, int32_t base_bit, uint32_t TL, int32_t pos0, int32_t stop,
-                                          bool own, ZnRec& rec, uint32_t& acc_out, int& nfull, int& nbnd,
-                                          uint32_t* stage, uint32_t wpos, int nfull_prev, int nbnd_prev) {
-  static_assert(TF + TB <= ZN_REC_MAX, "more record slots than ZnRec has");
-  // STATIC structure — every slot of both tiles in every pass, no wave-uniform early exits: a slot the previous tile did not use is
-  // drained as zero bytes (its atomics masked out), a step the new tile does not need records an empty group.  Two or three steps more
-  // than the early exits of zn_pass1 would take, but the number of LDS operations between a look-up and its use is then a compile-time
-  // constant, and only with that does the compiler wait for the look-up ALONE (s_waitcnt lgkmcnt(2): the slot's two atomics, issued
-  // behind it, stay in flight) — behind a branch it waits for everything, and the compaction would sit in the look-up's dependent chain.
-  const uint32_t sh = 32u - TL;
-  const int32_t R = own ? pos0 - stop : -1000;
-  const int32_t lim_full = R - (int32_t)TL + 1;
-  const int32_t qb = pos0 - 1 - base_bit;
-  uint64_t w = 0;
-  uint32_t acc = 0;
-  uint32_t wm1 = wpos - 1u;
-  // (zn_pass2's, but BOTH atomics of a slot are issued whatever their value — OR-ing zero changes nothing, also not in the dword
-  //  below the buffer that a wpos of 0 addresses — because a masked-out atomic is a branch around it to the compiler's wait-count pass,
-  //  and behind a branch it no longer knows how many LDS operations follow the look-up: it would wait for all of them)
-  auto put = [&](uint32_t cnt, uint32_t sv) {
-    const uint32_t g = ~wm1;
-    uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & ~3u));
-    const uint32_t lo = zn_alignbyte(sv, 0u, g), hi = zn_alignbyte(0u, sv, g);
-#ifndef ZN_F_P12_UNCOND
-#define ZN_F_P12_UNCOND 1
-#endif
-    if (ZN_F_P12_UNCOND) { atomicOr(d, lo); atomicOr(d + 1, hi); }
-    else { if (lo) atomicOr(d, lo); if (hi) atomicOr(d + 1, hi); }
-    wm1 += cnt;
-  };
-  zn_static_for<0, TF>([&](auto I) {
-    constexpr int t = decltype(I)::v;
-    constexpr bool checked = t >= U;
-    const bool act = !checked || (int32_t)(acc & 0xFFu) < lim_full;
-    if (t % 3 == 0) w = zn_window(in, qb - (int32_t)(acc & 0xFFu));
-    uint2 e = lut[(uint32_t)(w >> 32) >> sh];              // the new tile's look-up leaves first …
-    {                                                      // … the previous tile's slot t is drained while it is under way …
-      const bool used = t < nfull_prev;                    // (uniform)
-      const uint32_t cnt = used ? zn_rec_cnt<t>(rec) : 0u, sv = used ? zn_rec_s<t>(rec) : 0u;
-      put(cnt, sv);
-    }
-    if (checked && !act) { e.x = 0; e.y = 0; }             // … and refilled
-    w <<= (e.y & 63u);
-    acc += e.y;
-    zn_rec_put<t, false>(rec, e.x, e.y);
-    ZN_STEP_FENCE();
-  });
-  const bool overflow = __any((int32_t)(acc & 0xFFu) < lim_full);       // the new tile needs more whole-group steps than there are slots
-  zn_static_for<0, TB>([&](auto I) {
-    constexpr int b = decltype(I)::v;
-    const int32_t rem = R - (int32_t)(acc & 0xFFu);
-    w = zn_window(in, qb - (int32_t)(acc & 0xFFu));
-    uint2 e = lut[(uint32_t)(w >> 32) >> sh];
-    {
-      const bool used = b < nbnd_prev;
-      const uint32_t cnt = used ? zn_rec_cnt<TF + b>(rec) : 0u, sv = used ? zn_rec_s<TF + b>(rec) : 0u;
-      put(cnt, sv);
-    }
-    if (!(rem > 0) || overflow) { e.x = 0; e.y = 0; }
-    e = zn_trim_group(e, rem);
-    acc += e.y;
-    zn_rec_put<TF + b, false>(rec, e.x, e.y);
-    ZN_STEP_FENCE();
-  });
-  nfull = TF; nbnd = TB;                                   // (every slot holds this tile's group, possibly an empty one)
-  acc_out = acc;
-  return !overflow;
-}
-
 // compaction: the recorded groups of this lane go to bytes [wpos, wpos + n) of the staging buffer (ds_or_b32: the first
 // and the last dword are shared with the neighbouring lanes).  No table reads, no dependent chain: the byte position is
 // a running sum of the counts.  Slots a lane did not use hold zeros.

@@ -518,201 +518,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   };
 
   bool ok = true;
-  // ---- the looping form of one tile: count pass (with fix-up iterations), then a second decode that ORs the symbols into the
-  // staging buffer, in several lane groups with a flush after each when the tile is denser than the buffer.  `in` holds the tile,
-  // the prefetch registers the next one (staged inside the last flush).  false: the stream is damaged.
-  auto looping_tile = [&](int32_t lo_dw, int32_t base_bit, int32_t hi_k, int32_t stop, bool active, bool regular) -> bool {
-
-      ZN_NO_IFCVT;
-      ZN_PT_COUNT(22, 1);                    // tiles that took the looping form
-      ZN_DBG_COUNT(1);
-      ZN_PRIO(ZN_F_PRIO_SYNC);
-      int32_t s = sync_run(base_bit, hi_k, active, regular);
-      ZN_PRIO(ZN_F_PRIO_COUNT);
-      ZnChain A; A.wpos = 0;
-      // (whole-group steps no lane of a regular tile can take too far: see zn_fused_run)
-      const int U_blk = regular ? (int)zn_uniform((uint32_t)((32 * Di - 31) / 11)) : 0;
-      int32_t e = s; uint32_t n = 0; bool need = active, chained = false;
-      for (int it = 0; it < 66; it++) {
-        A.pos = need ? s : stop; A.stop = stop; A.n = 0;
-        zn_fused_run<1>(lut, in, base_bit, TL, A, nullptr, U_blk);
-        if (need) { e = A.pos; n = A.n; }
-        const int32_t e_prev = __shfl_up(e, 1u);
-        const bool mism = active && lane > 0 && e_prev != s;
-        if (!__any(mism)) { chained = true; break; }
-        if (it == 0) note_mismatch();
-        need = mism;
-        if (mism) s = e_prev;
-      }
-      if (!active) n = 0;
-      uint32_t N = 0;
-      const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
-      const uint32_t nact = (uint32_t)__popcll(__ballot(active));
-      const int32_t e_last = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u));
-      if (!chained || J + N > seg) { ok = false; return false; }
-      carry = e_last; hi_dw = lo_dw;
-      uint32_t lane_lo = 0, wdone = 0;
-      do {
-        const uint32_t base = J - JF;                            // < UNIT
-        const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - 4u - base);   // monotone in the lane index
-        const uint32_t lane_hi = (uint32_t)__popcll(__ballot(fits));
-        if (lane_hi <= lane_lo) { ok = false; break; }           // cannot happen: one sub-block always fits
-        if (lane_hi < 64u) ZN_DBG_COUNT(3);
-        const uint32_t wend = (lane_hi >= 64u) ? N : (uint32_t)__shfl((int)o_k, (int)(lane_hi & 63u));
-        const uint32_t nsub = wend - wdone;
-        int rows = (int)((base + nsub) / UNIT);
-        const int first = rows < RB ? rows : RB;
-        fetch_rows(JF, first);
-        ZN_PRIO(ZN_F_PRIO_WRITE);
-        const bool mine = active && lane >= lane_lo && lane < lane_hi;
-        A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
-        zn_fused_run<2>(lut, in, base_bit, TL, A, ring, (lane_lo == 0u && lane_hi >= 64u) ? U_blk : 0);
-        __builtin_amdgcn_wave_barrier();
-        ZN_PRIO(0);
-        J += nsub; wdone = wend; lane_lo = lane_hi;
-        const uint32_t total_rows = (uint32_t)rows;
-        uint32_t srow = 0;
-        emit_rows(JF, first, srow, [&] {
-#if ZN_F_EARLY_STAGE
-          if (lane_hi >= 64u && 32 * hi_dw > b0) stage_tile();
-#endif
-        });
-        JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
-        while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
-        if (total_rows > 0 && J > JF) keep_remainder(total_rows);
-        ZN_PT_COUNT(20, 1);
-      } while (lane_lo < 64u);
-      if (!ok) return false;
-          return true;
-  };
-
-#ifndef ZN_F_PIPE
-#define ZN_F_PIPE 1                        // 1: the 4-dword instance compacts tile t inside the decode pass of tile t + 1 (zn_pass12)
-#endif
-  constexpr bool PIPE = ZN_F_PIPE && DC != 0 && !DENSE && TF > 0;
-  if constexpr (PIPE) {
-    // ---- the PIPELINED register-resident form (round 4): a tile that has been decoded and verified stays in the record ("pending")
-    // until the NEXT tile's decode pass, which drains it slot by slot into the staging buffer while it refills the record
-    // (zn_pass12); its rows are flushed behind that pass.  Per iteration: request the pending tile's raw rows, run-in of the next tile,
-    // both passes in one, chain check + prefix sum of the new tile, flush of the pending one (the tile after next is staged inside that
-    // flush, as before).  A tile the register-resident form does not take is decoded by the looping form once the pending one is out.
-    ZnRec rec;
-    bool pend = false;                        // (uniform) the record holds a verified tile that is not compacted yet …
-    uint32_t p_ok = 0, p_N = 0; int p_nf = 0, p_nb = 0;       // … its per-lane offset, symbol count, slot counts
-    while (32 * hi_dw > b0 || pend) {
-      if (DC) ZN_ASM_MARK("ZN_HOT_TILE_BEGIN");
-      lane = zn_lane_id();
-      lane_v = lane; ZN_OPAQUE32(lane_v);
-      hi_dw = __builtin_amdgcn_readfirstlane(hi_dw); carry = __builtin_amdgcn_readfirstlane(carry);
-      delta = __builtin_amdgcn_readfirstlane(delta); nmis = __builtin_amdgcn_readfirstlane(nmis);
-      J = zn_uniform(J); JF = zn_uniform(JF);
-      pend = (bool)__builtin_amdgcn_readfirstlane((int)pend);
-      p_N = zn_uniform(p_N); p_nf = __builtin_amdgcn_readfirstlane(p_nf); p_nb = __builtin_amdgcn_readfirstlane(p_nb);
-      const bool more = 32 * hi_dw > b0;
-      const int32_t lo_dw = hi_dw - TD;
-      // the pending tile: rows it completes; their raw bytes are requested now, consumed behind the passes
-      const uint32_t p_base = J - JF;                             // < UNIT
-      int p_rows = 0, p_first = 0;
-      if (pend) {
-        p_rows = (int)zn_uniform((p_base + p_N) / UNIT);
-        p_first = p_rows < RB ? p_rows : RB;
-        for (int r = 0; r < RB; r++) if (r < p_first) fetch_row(JF, r);
-      }
-      ZN_PT(8);
-      bool t_ok = false; uint32_t t_ok_off = 0, t_N = 0; int t_nf = 0, t_nb = 0; int32_t t_carry = 0;
-      bool compacted = false;
-      int32_t base_bit = 0, hi_k = 0, stop = 0; bool active = false, regular = false;
-      if (more) {
-        if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the tile after this one
-        base_bit = 32 * (lo_dw - 1);
-        hi_k = 32 * (hi_dw - (int32_t)lane * Di); const int32_t lo_k = hi_k - 32 * Di;
-        stop = lo_k > b0 ? lo_k : b0;
-        active = hi_k > b0;
-        regular = (32 * lo_dw >= b0);
-        ZN_PT_COUNT(18, 1);
-        ZN_DBG_COUNT(0);
-        ZN_PRIO(ZN_F_PRIO_SYNC);
-        if (DC) ZN_ASM_MARK("ZN_MARK sync");
-        int32_t s = sync_run(base_bit, hi_k, active, regular);
-        ZN_PRIO(ZN_F_PRIO_COUNT);
-        ZN_PT(5);
-        if (DC) ZN_ASM_MARK("ZN_MARK pass1");
-        int nfull = 0, nbnd = 0;
-        uint32_t acc = 0, n = 0; int32_t e = s;
-        bool took = true, chained = false;
-        for (int it = 0; it < 4; it++) {
-          if (it == 0 && pend) {
-            // (the pending tile's compaction rides in this pass)
-            if (regular) took = zn_pass12<TF, TB, UF>(lut, in, base_bit, TL, s, stop, true, rec, acc, nfull, nbnd, ring, p_base + p_ok, p_nf, p_nb);
-            else took = zn_pass12<TF, TB, 0>(lut, in, base_bit, TL, s, stop, active, rec, acc, nfull, nbnd, ring, p_base + p_ok, p_nf, p_nb);
-            compacted = true;
-          } else {
-            if (regular) took = zn_pass1<TF, TB, UF, false>(lut, in, base_bit, TL, s, stop, true, rec, acc, nfull, nbnd);
-            else took = zn_pass1<TF, TB, 0, false>(lut, in, base_bit, TL, s, stop, active, rec, acc, nfull, nbnd);
-          }
-          if (!took) break;
-          e = s - (int32_t)(acc & 0xFFu); n = (acc >> 8) & 0xFFu;
-          const int32_t e_prev = __shfl_up(e, 1u);
-          const bool mism = active && lane > 0 && e_prev != s;
-          if (it == 0) ZN_PT(6); else ZN_PT(7);
-          if (__builtin_expect(!__any(mism), 1)) { chained = true; break; }
-          ZN_PT_COUNT(16, 1);
-          ZN_PT_COUNT(17, __popcll(__ballot(mism)));
-          ZN_DBG_COUNT(2);
-          if (it == 0) note_mismatch();
-          if (mism) s = e_prev;
-        }
-        if (DC) ZN_ASM_MARK("ZN_MARK scan");
-        if (took && chained) {
-          if (!active) n = 0;
-          uint32_t N = 0;
-          const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
-          // where the staging buffer will stand once the pending tile is out
-          const uint32_t J2 = J + (pend ? p_N : 0u), JF2 = JF + (uint32_t)p_rows * UNIT;
-          if (J2 + N <= seg && (J2 - JF2) + N <= ZN_F_RING_BYTES - 4u) {
-            const uint32_t nact = (uint32_t)__popcll(__ballot(active));
-            t_carry = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u));
-            t_ok = true; t_ok_off = o_k; t_N = N; t_nf = nfull; t_nb = nbnd;
-          }
-        }
-        t_ok = (bool)__builtin_amdgcn_readfirstlane((int)t_ok);
-      }
-      // ---- the pending tile leaves: its compaction if no pass carried it, then its rows ----
-      bool staged = false;
-      if (pend) {
-        ZN_PRIO(ZN_F_PRIO_WRITE);
-        if (!compacted) { if (DC) ZN_ASM_MARK("ZN_MARK pass2"); zn_pass2<TF, TB, false>(ring, p_base + p_ok, rec, p_nf, p_nb, [](auto) {}); }
-        __builtin_amdgcn_wave_barrier();
-        ZN_PRIO(0);
-        ZN_PT(9);
-        if (DC) ZN_ASM_MARK("ZN_MARK flush");
-        J += p_N;
-        const uint32_t total_rows = (uint32_t)p_rows;
-        int rows = p_rows;
-        // (the register-resident tile that follows is staged behind this flush's wait: `in` is free once its own pass is over —
-        //  unless that tile goes to the looping form, which still needs `in` and stages its successor itself)
-        emit_rows(JF, p_first, 0, [&] { if (t_ok && 32 * lo_dw > b0) { stage_tile(); staged = true; } });
-        uint32_t srow = (uint32_t)p_first;
-        JF += (uint32_t)p_first * UNIT; rows -= p_first;
-        while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
-        if (total_rows > 0 && J > JF) keep_remainder(total_rows);
-        ZN_PT_COUNT(20, 1);
-        pend = false;
-      }
-      if (more) {
-        if (t_ok) {
-          if (!staged && 32 * lo_dw > b0) stage_tile();          // (no flush in this round: the first tile of a stream, or behind a looping-form tile)
-          pend = true; p_ok = t_ok_off; p_N = t_N; p_nf = t_nf; p_nb = t_nb;
-          carry = t_carry; hi_dw = lo_dw;
-        } else {
-          ZN_NO_IFCVT;
-          if (!looping_tile(lo_dw, base_bit, hi_k, stop, active, regular)) break;
-        }
-      }
-      ZN_PT(3);
-      if (DC) ZN_ASM_MARK("ZN_HOT_TILE_END");
-    }
-  } else
   while (32 * hi_dw > b0) {
     if (DC) ZN_ASM_MARK("ZN_HOT_TILE_BEGIN");
     // the stream position and the counters are wave-uniform; said once per tile, because across the two tile forms and
@@ -830,8 +635,70 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       }
     }
 
-    // ---- the looping form (looping_tile above) for what the register-resident form left
-    if (!done) { ZN_NO_IFCVT; if (!looping_tile(lo_dw, base_bit, hi_k, stop, active, regular)) break; }
+    // ---- the looping form: count pass (with fix-up iterations), then a second decode that ORs the symbols into the
+    // staging buffer, in several lane groups with a flush after each when the tile is denser than the buffer
+    if (!done) {
+      ZN_NO_IFCVT;
+      ZN_PT_COUNT(22, 1);                    // tiles that took the looping form
+      ZN_DBG_COUNT(1);
+      ZN_PRIO(ZN_F_PRIO_SYNC);
+      int32_t s = sync_run(base_bit, hi_k, active, regular);
+      ZN_PRIO(ZN_F_PRIO_COUNT);
+      ZnChain A; A.wpos = 0;
+      // (whole-group steps no lane of a regular tile can take too far: see zn_fused_run)
+      const int U_blk = regular ? (int)zn_uniform((uint32_t)((32 * Di - 31) / 11)) : 0;
+      int32_t e = s; uint32_t n = 0; bool need = active, chained = false;
+      for (int it = 0; it < 66; it++) {
+        A.pos = need ? s : stop; A.stop = stop; A.n = 0;
+        zn_fused_run<1>(lut, in, base_bit, TL, A, nullptr, U_blk);
+        if (need) { e = A.pos; n = A.n; }
+        const int32_t e_prev = __shfl_up(e, 1u);
+        const bool mism = active && lane > 0 && e_prev != s;
+        if (!__any(mism)) { chained = true; break; }
+        if (it == 0) note_mismatch();
+        need = mism;
+        if (mism) s = e_prev;
+      }
+      if (!active) n = 0;
+      uint32_t N = 0;
+      const uint32_t o_k = zn_wave_excl_scan(n, lane, &N);
+      const uint32_t nact = (uint32_t)__popcll(__ballot(active));
+      const int32_t e_last = __builtin_amdgcn_readlane(e, (int)(nact ? nact - 1u : 0u));
+      if (!chained || J + N > seg) { ok = false; break; }
+      carry = e_last; hi_dw = lo_dw;
+      uint32_t lane_lo = 0, wdone = 0;
+      do {
+        const uint32_t base = J - JF;                            // < UNIT
+        const bool fits = o_k + n <= wdone + (ZN_F_RING_BYTES - 4u - base);   // monotone in the lane index
+        const uint32_t lane_hi = (uint32_t)__popcll(__ballot(fits));
+        if (lane_hi <= lane_lo) { ok = false; break; }           // cannot happen: one sub-block always fits
+        if (lane_hi < 64u) ZN_DBG_COUNT(3);
+        const uint32_t wend = (lane_hi >= 64u) ? N : (uint32_t)__shfl((int)o_k, (int)(lane_hi & 63u));
+        const uint32_t nsub = wend - wdone;
+        int rows = (int)((base + nsub) / UNIT);
+        const int first = rows < RB ? rows : RB;
+        fetch_rows(JF, first);
+        ZN_PRIO(ZN_F_PRIO_WRITE);
+        const bool mine = active && lane >= lane_lo && lane < lane_hi;
+        A.pos = mine ? s : stop; A.stop = stop; A.wpos = mine ? base + o_k - wdone : 0u;
+        zn_fused_run<2>(lut, in, base_bit, TL, A, ring, (lane_lo == 0u && lane_hi >= 64u) ? U_blk : 0);
+        __builtin_amdgcn_wave_barrier();
+        ZN_PRIO(0);
+        J += nsub; wdone = wend; lane_lo = lane_hi;
+        const uint32_t total_rows = (uint32_t)rows;
+        uint32_t srow = 0;
+        emit_rows(JF, first, srow, [&] {
+#if ZN_F_EARLY_STAGE
+          if (lane_hi >= 64u && 32 * hi_dw > b0) stage_tile();
+#endif
+        });
+        JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
+        while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
+        if (total_rows > 0 && J > JF) keep_remainder(total_rows);
+        ZN_PT_COUNT(20, 1);
+      } while (lane_lo < 64u);
+      if (!ok) break;
+    }
     ZN_PT(3);   // flush rows
     if (DC) ZN_ASM_MARK("ZN_HOT_TILE_END");
   }
