@@ -192,6 +192,13 @@ int zn_set_decode_group(int chunks_per_workgroup);
  * directions.  Process-wide.  Returns 0 or ZN_E_ARG. */
 int zn_set_host_slices(int slices);
 
+/* Which huff0 the compressed bytes imitate where the two in circulation differ — the FSE-coded tree description of a plane, when one
+ * of its code-weight values is rare enough to round below one FSE cell: 0 (default) = zstd >= 1.4.7 (a full cell, "+1"; what the
+ * reference writes when built against a current libzstd, oracle/_ref), 1 = the FiniteStateEntropy library the reference's PyPI wheels
+ * bundle (/root/reference/setup.py:23-28; the "less than one" marker, "-1").  Every huff0 decoder — this library's included — reads both;
+ * with 1 the frames are byte-identical to a wheel's.  Process-wide.  Returns 0 or ZN_E_ARG. */
+int zn_set_legacy_tree_descriptions(int on);
+
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);
 

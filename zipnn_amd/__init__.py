@@ -22,3 +22,12 @@ def install_as_zipnn():
     sys.modules["zipnn"] = this
     sys.modules["zipnn.zipnn"] = _impl
     return this
+
+
+def set_legacy_tree_descriptions(on=True):
+    """Make compress() write the tree descriptions of its Huffman planes the way the reference's PyPI wheels do (the huff0 of the
+    bundled FiniteStateEntropy library: rare code-weight values as "-1" markers) instead of zstd >= 1.4.7's way (the default; what the
+    reference writes when built against a current libzstd).  Every decoder reads both; only with this on are the frames byte-identical
+    to a wheel's.  Process-wide (zn_set_legacy_tree_descriptions)."""
+    from . import _capi
+    _capi.lib().set_legacy_tree_descriptions(bool(on))

@@ -104,6 +104,8 @@ class ZnLib:
         L.zn_copy_to_device.restype = ci; L.zn_copy_to_device.argtypes = [vp, vp, sz]
         L.zn_copy_to_host.restype = ci; L.zn_copy_to_host.argtypes = [vp, vp, sz]
         L.zn_release_workspace.restype = ci
+        L.zn_set_legacy_tree_descriptions.restype = ci
+        L.zn_set_legacy_tree_descriptions.argtypes = [ci]
         L.zn_decode_status.restype = ci
         L.zn_decode_status.argtypes = [vp]
         L.zn_last_fused_chunks.restype = ctypes.c_longlong
@@ -261,6 +263,10 @@ class ZnLib:
     def set_host_slices(self, slices):
         """Tuning knob (zn_set_host_slices): slices of the pipelined host path; 0 = automatic, 1 = one shot."""
         self._check(self._L.zn_set_host_slices(int(slices)))
+
+    def set_legacy_tree_descriptions(self, on):
+        """zn_set_legacy_tree_descriptions: True = write tree descriptions the way the reference's PyPI wheels do (-1 markers)."""
+        self._check(self._L.zn_set_legacy_tree_descriptions(1 if on else 0))
 
     def set_decode_group(self, chunks_per_workgroup):
         """Tuning knob (zn_set_decode_group): chunks per workgroup of the fused decoder, 1..4; 0 = automatic."""

@@ -139,6 +139,16 @@ size_t zn_compress_bound(size_t n, int num_buf, size_t chunk, size_t hdr_len) {
   return hdr_len + 9u * (size_t)num_buf * zn_num_chunks(n, chunk) + n;
 }
 
+// Which of the two huff0 forms of a tree description the encoder writes (both decode with every huff0): 0 = zstd >= 1.4.7's (the
+// default; what the oracle's pin and the reference built against a current libzstd write), 1 = the FiniteStateEntropy library's, which
+// the reference's PyPI wheels bundle: weight counts that round below one FSE cell as -1 markers.  Process-wide.
+static std::atomic<int> g_legacy_weights{0};
+int zn_set_legacy_tree_descriptions(int on) {
+  if (on != 0 && on != 1) return ZN_E_ARG;
+  g_legacy_weights.store(on, std::memory_order_relaxed);
+  return ZN_OK;
+}
+
 // Compress `count` tensors: one launch per stage and plane count over all of them (a single tensor travels to the
 // kernels as an argument, a batch as a segment table), one read-back of all body lengths.
 static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t stream) {
@@ -159,6 +169,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
     const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
     const uint64_t PK = (uint64_t)sg.g.P * sg.g.K;
     sg.src = (const uint8_t*)it.d_src; sg.body = (uint8_t*)it.d_body; sg.threshold = it.threshold;
+    sg.legacy_weights = g_legacy_weights.load(std::memory_order_relaxed) ? 1u : 0u;
     sg.xr = it.n ? (const uint8_t*)it.d_delta : nullptr;
     if (sg.xr) delta_of[q] = true;
     // full chunks go through the fused encoder, the partial tail (or everything, for geometries the fused

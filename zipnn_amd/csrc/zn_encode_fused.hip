@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
   // the tree description: the whole wave, its serial chain on wave-uniform values (zn_wave_write_ctable)
   uint32_t cs = 0, hdr_len = 0; bool go = false;
   {
-    const int h = zn_wave_write_ctable(&L.S, max_sv, wc, lane);
+    const int h = zn_wave_write_ctable(&L.S, max_sv, wc, lane, S.legacy_weights ? -1 : 1);
     if (h < 0) cs = 0xFFFFFFFFu;               // huff0 error → fails the threshold test → raw
     else if ((uint32_t)h + 12u >= n) cs = 0;
     else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u || n < 12u) cs = 0;      // (HUF_compress4X: a source of fewer than 12 bytes is not coded)

@@ -168,9 +168,12 @@ __device__ inline void zn_sbw_add(ZnSmallBitW* w, uint32_t v, uint32_t nb) {
   while (w->nacc >= 8) { if (w->nbytes < w->cap) w->out[w->nbytes] = (uint8_t)w->acc; w->nbytes++; w->acc >>= 8; w->nacc -= 8; }
 }
 
-// FSE_normalizeCount (+ FSE_normalizeM2) for the weight histogram; low-probability
-// symbols get +1 (huff0 of zstd ≥ 1.4.7).  Returns 0 ok, 1 = rle, -1 = error.
-__device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_t* count, uint32_t total_in, uint32_t max_sv) {
+// FSE_normalizeCount (+ FSE_normalizeM2) for the weight histogram.  low_prob: what a count that rounds below one table cell
+// becomes — +1 (huff0 of zstd ≥ 1.4.7: HUF_compressWeights passes useLowProbCount = 0; the default here and what the oracle's pin
+// writes) or -1 (the huff0 of the FiniteStateEntropy library the reference's PyPI wheels bundle, /root/reference/setup.py:23-28:
+// the "less than one" marker — the symbol gets the table's top cell; zn_set_legacy_tree_descriptions).  Both decode everywhere.
+// Returns 0 ok, 1 = rle, -1 = error.
+__device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_t* count, uint32_t total_in, uint32_t max_sv, int low_prob = 1) {
 #define ZN_RTB(p_) ((p_) == 0 ? 0u : (p_) == 1 ? 473195u : (p_) == 2 ? 504333u : (p_) == 3 ? 520860u : (p_) == 4 ? 550000u : (p_) == 5 ? 700000u : (p_) == 6 ? 750000u : 830000u)
   uint64_t total = total_in;
   const uint64_t scale = 62 - tl, step = (1ULL << 62) / (uint32_t)total, vstep = 1ULL << (scale - 20);
@@ -179,7 +182,7 @@ __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_
   for (uint32_t s = 0; s <= max_sv; s++) {
     if (count[s] == total) return 1;
     if (count[s] == 0) { norm[s] = 0; continue; }
-    if (count[s] <= low_thr) { norm[s] = 1; still--; continue; }
+    if (count[s] <= low_thr) { norm[s] = (int16_t)low_prob; still--; continue; }
     int16_t p = (int16_t)(((uint64_t)count[s] * step) >> scale);
     if (p < 8) { const uint64_t beat = vstep * ZN_RTB(p); p += ((uint64_t)count[s] * step) - ((uint64_t)p << scale) > beat; }
     if (p > largest_p) { largest_p = p; largest = s; }
@@ -191,7 +194,7 @@ __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_
   uint32_t distributed = 0, to_dist, low_one = (uint32_t)((total * 3) >> (tl + 1));
   for (uint32_t s = 0; s <= max_sv; s++) {
     if (count[s] == 0) { norm[s] = 0; continue; }
-    if (count[s] <= low_thr) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+    if (count[s] <= low_thr) { norm[s] = (int16_t)low_prob; distributed++; total -= count[s]; continue; }
     if (count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; continue; }
     norm[s] = UNSET;
   }
@@ -232,7 +235,7 @@ __device__ inline int zn_fse_normalize(int16_t* norm, uint32_t tl, const uint32_
 // HUF_compressWeights: weights w[0..nw) -> dst.  0 = not compressible, 1 = single value,
 // >1 = size (1000 = "too long to be kept"), -1 = error.
 // pre: S->wcount already holds the histogram of w[0..nw) (filled in parallel by the caller).
-__device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint8_t* w, uint32_t nw, bool pre = false) {
+__device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint8_t* w, uint32_t nw, bool pre = false, int low_prob = 1) {
   uint32_t* count = S->wcount;
   uint32_t max_sv = ZN_HUF_LOG_MAX, max_c = 0;
   if (nw <= 1) return 0;
@@ -245,7 +248,7 @@ __device__ inline int zn_huf_compress_weights(ZnTabScratch* S, uint8_t* dst, uin
   if (max_c == nw) return 1;
   if (max_c == 1) return 0;
   const uint32_t tl = zn_optimal_table_log(ZN_WEIGHT_FSE_LOG, nw, max_sv, 2);
-  { int r = zn_fse_normalize(S->norm, tl, count, nw, max_sv); if (r != 0) return r == 1 ? 0 : -1; }
+  { int r = zn_fse_normalize(S->norm, tl, count, nw, max_sv, low_prob); if (r != 0) return r == 1 ? 0 : -1; }
   uint32_t off = 0;
   // FSE_writeNCount
   {
@@ -427,7 +430,7 @@ __device__ inline uint32_t zn_wave_tree_from_sorted(ZnTabScratch* S, ZnHNode* ta
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t zn_trl(uint32_t v, uint32_t idx) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)idx); }
 
-__device__ inline int zn_wave_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint32_t (&wc)[13], uint32_t nw, uint32_t lane) {
+__device__ inline int zn_wave_compress_weights(ZnTabScratch* S, uint8_t* dst, uint32_t cap, const uint32_t (&wc)[13], uint32_t nw, uint32_t lane, int low_prob = 1) {
   if (nw <= 1) return 0;
   uint32_t max_sv = 0, max_c = 0;
   for (uint32_t v = 0; v < 13u; v++) { if (wc[v]) max_sv = v; if (wc[v] > max_c) max_c = wc[v]; }
@@ -435,6 +438,18 @@ __device__ inline int zn_wave_compress_weights(ZnTabScratch* S, uint8_t* dst, ui
   if (max_c == 1) return 0;
   const uint32_t tl = zn_optimal_table_log(ZN_WEIGHT_FSE_LOG, nw, max_sv, 2);
   const uint32_t size = 1u << tl;
+  if (low_prob < 0) {
+    // legacy tree descriptions (-1 markers): only a description in which some weight value is rare enough to get one differs from the
+    // default form — that one is written by the serial builder on one lane (its table build knows the marker's top cells); every other
+    // description takes the wave's path below, whose bytes are the same in both forms
+    bool rare = false;
+    for (uint32_t v = 0; v <= max_sv; v++) if (wc[v] != 0u && wc[v] <= (nw >> tl)) rare = true;
+    if (rare) {
+      if (lane == 0) { const int h = zn_huf_compress_weights(S, dst, cap, S->weights, nw, true, -1); S->cumul[14] = (uint32_t)h; }
+      __builtin_amdgcn_wave_barrier();
+      return (int)S->cumul[14];
+    }
+  }
 
   // ---- FSE_normalizeCount, lane s = weight value s; the correction of the largest count in symbol order on uniform values ----
   uint32_t normv = 0;
@@ -462,7 +477,7 @@ __device__ inline int zn_wave_compress_weights(ZnTabScratch* S, uint8_t* dst, ui
     if (-still < (nl >> 1)) normv = (lane == largest) ? (uint32_t)(nl + still) : p;
     else {
       // secondary normalisation (rare): the serial builder on one lane
-      if (lane == 0) { const int r = zn_fse_normalize(S->norm, tl, S->wcount, nw, max_sv); S->cumul[0] = (uint32_t)r; }
+      if (lane == 0) { const int r = zn_fse_normalize(S->norm, tl, S->wcount, nw, max_sv, 1); S->cumul[0] = (uint32_t)r; }      // (no rare count on this path in either form: see above)
       __builtin_amdgcn_wave_barrier();
       const int r = (int)S->cumul[0];
       if (r != 0) return r == 1 ? 0 : -1;
@@ -566,8 +581,8 @@ __device__ inline int zn_wave_compress_weights(ZnTabScratch* S, uint8_t* dst, ui
 
 // HUF_writeCTable by one wave: S->weights / S->wcount (+ the same histogram, wave-uniform, in wc) -> S->hdr.
 // Returns the header size, or -1 (the caller stores the plane raw).  S->hdr is complete after the caller's next barrier.
-__device__ inline int zn_wave_write_ctable(ZnTabScratch* S, uint32_t max_sv, const uint32_t (&wc)[13], uint32_t lane) {
-  const int h = zn_wave_compress_weights(S, S->hdr + 1, 140, wc, max_sv, lane);
+__device__ inline int zn_wave_write_ctable(ZnTabScratch* S, uint32_t max_sv, const uint32_t (&wc)[13], uint32_t lane, int low_prob = 1) {
+  const int h = zn_wave_compress_weights(S, S->hdr + 1, 140, wc, max_sv, lane, low_prob);
   if (h < 0) return -1;
   if (h > 1 && (uint32_t)h < max_sv / 2u) { if (lane == 0) S->hdr[0] = (uint8_t)h; return h + 1; }
   if (max_sv > 128u) return -1;

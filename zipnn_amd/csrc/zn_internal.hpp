@@ -62,7 +62,7 @@ struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs f
 struct ZnESeg {
   ZnGeom g;
   const uint8_t* src; uint8_t* body;
-  float threshold; uint32_t pad_;
+  float threshold; uint32_t legacy_weights;   // 1: tree descriptions with -1 markers (zn_set_legacy_tree_descriptions)
   uint64_t nfull;      // chunks [0, nfull) go through the fused kernels, [nfull, K) through the generic ones
   uint64_t pc0;        // base of its (plane, chunk) entries
   uint64_t slot0;      // base of its generic-path scratch slots (P·(K-nfull) of them)
