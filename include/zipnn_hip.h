@@ -186,6 +186,11 @@ int zn_copy_to_host(void* dst, const void* d_src, size_t n);
  * to fill every workgroup slot of the device with groups, fewer for small tensors).  Process-wide.  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_group(int chunks_per_workgroup);
 
+/* Tuning knob: the small-input form of the decoder (one 16-wave workgroup per chunk, four waves per huff0 stream) — 0 = never,
+ * 1 (default) = automatic: calls whose chunks number at most the compute units of the device and have no delta base, 2 = every
+ * call without a delta base.  The bytes produced are the same in every mode.  Process-wide.  Returns 0 or ZN_E_ARG. */
+int zn_set_decode_wide(int mode);
+
 /* Tuning knob of the host-buffer entry points (zn_compress / zn_decompress): slices of the three-stage pipeline
  * upload | code | download that large pageable buffers can go through (both PCIe directions busy at once).  0 (default) = automatic
  * (compress: 4-8 slices from 192 MiB up; decompress: one shot — measured: no gain there), 1 = never, 2..64 = that many, both

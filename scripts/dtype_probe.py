@@ -11,6 +11,8 @@ from scripts.bench_dtypes import make
 def main():
     kind = sys.argv[1]; gib = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0; calls = int(sys.argv[3]) if len(sys.argv) > 3 else 3
     lib = _capi.lib(); dev = torch.device("cuda:0")
+    if os.environ.get("ZN_WIDE_MODE"):
+        lib.set_decode_wide(int(os.environ["ZN_WIDE_MODE"]))
     n = int(gib * (1 << 30))
     x, P, rot, bm, chunk = make(kind, n, dev)
     flat = codec.flat_bytes(x)

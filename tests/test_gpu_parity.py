@@ -106,10 +106,12 @@ def test_two_streams_share_the_device_workspace_safely(lib):
 
 
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
-def test_fused_decode_chunk_groups(lib, group, decode_group):
+def test_fused_decode_chunk_groups(lib, group, decode_group, request):
     """Workgroups decode `group` consecutive chunks; mixed Huffman / raw / RLE / two-Huffman-plane chunks, short last group."""
     from test_kernels_simt import _gen2
     decode_group(lib, group)
+    lib.set_decode_wide(0)                 # (a call this small would go to the wide kernel, one chunk per workgroup)
+    request.addfinalizer(lambda: lib.set_decode_wide(1))
     ch = 65536
     r = np.random.default_rng(5)
     parts = []
@@ -121,6 +123,33 @@ def test_fused_decode_chunk_groups(lib, group, decode_group):
     assert bytes(lib.compress(HDR, d, 2, 0, 10, ch, 0.95)) == want
     assert bytes(lib.decompress(want[32:], 2, 0, 10, ch, len(d))) == d
     assert lib.last_fused_chunks() == 23               # incl. the three "pair" chunks (two Huffman planes: two passes)
+
+
+@pytest.mark.parametrize("kind,P,rot,bm", [("bf16", 2, 1, 10), ("fp32", 4, 1, 220), ("fp16", 2, 0, 10), ("fp8", 1, 0, 10), ("slowsync", 2, 0, 10), ("mixed", 2, 0, 10)])
+def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, request):
+    """zn_k_decode_wide (16 waves per chunk, four per huff0 stream, tile tops guessed and checked across waves): every mode of
+    zn_set_decode_wide gives the input back — 1, 7 + tail, 200 and 257 chunks, repeated (the waves of a workgroup race differently
+    every time), with the frame equal to the oracle's.  Automatic mode uses it up to one chunk per CU."""
+    from test_kernels_simt import _gen2, _slow_sync_bf16
+    request.addfinalizer(lambda: lib.set_decode_wide(1))
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for nb in (C, 7 * C + C // 2 + 10, 200 * C, (cus + 1) * C):
+        if kind == "slowsync":
+            d = _slow_sync_bf16(nb, 3)
+        elif kind == "mixed":          # chunk by chunk: weights-like, incompressible, constant, two Huffman planes, dense
+            d = b"".join(_gen2(["bf16", "rand", "const", "u11", "bf16", "burst16"][k % 6], min(C, nb - k * C), 50 + k) for k in range((nb + C - 1) // C))
+        else:
+            d = _gen2(kind, nb, 31)
+        frame = O.compress_frame(HDR, d, P, rot, bm, C, threads=8)
+        assert bytes(lib.compress(HDR, d, P, rot, bm, C, 0.95)) == frame
+        K = (nb + C - 1) // C
+        for mode in (1, 2, 0):
+            lib.set_decode_wide(mode)
+            for _ in range(6 if nb <= 8 * C else 2):
+                assert bytes(lib.decompress(frame[32:], P, rot, bm, C, nb)) == d, (kind, nb, mode)
+            used = lib.last_kernels().split(";")[0]
+            assert used.startswith("zn_k_decode_wide") == (mode == 2 or (mode == 1 and K <= cus)), (used, mode, K)
+            assert lib.last_fused_chunks() >= (nb // C if kind in ("bf16", "fp32", "fp16", "fp8", "slowsync") else 0)
 
 
 @pytest.mark.parametrize("name", G.names())

@@ -229,7 +229,7 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
     out = torch.empty(nb, dtype=torch.uint8)
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
     assert out.numpy().tobytes() == d
-    assert "zn_k_decode_fused+tail" in simt_lib.last_kernels()
+    assert simt_lib.last_kernels().split(";")[0] in ("zn_k_decode_fused+tail", "zn_k_decode_wide+tail")     # (wide: calls of at most one full chunk per CU)
     assert simt_lib.last_tail_planes() == want_tail_planes
 
 
@@ -743,3 +743,94 @@ def test_ragged_planes_are_coded_inside_the_fused_launches(simt_lib):
         assert bytes(simt_lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == O.compress_frame(HDR, d, P, rot, bm, chunk)
         k = simt_lib.last_kernels()
         assert k.split(";") == ["zn_k_encode_stats+tail", "zn_k_encode_tables", "zn_k_scan_sizes", "zn_k_encode_emit+tail"], k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the small-input decoder (zn_decode_wide.hpp): one 16-wave workgroup per chunk, four waves per huff0 stream
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.fixture()
+def wide_mode(simt_lib):
+    """zn_set_decode_wide for one test (0 never / 1 automatic / 2 always); back to automatic afterwards."""
+    yield simt_lib.set_decode_wide
+    simt_lib.set_decode_wide(1)
+
+
+def _slow_sync_bf16(nbytes, seed):
+    """A bf16-like tensor whose top-byte code re-synchronises badly (three equally likely 2-bit codes hold 95 % of the mass) at the
+    density of a weights tensor: some tiles' top sub-block guesses its start wrong, the wave decodes the tile again."""
+    r = np.random.default_rng(seed)
+    p = np.array([500, 500, 480] + [40] * 6 + [2] * 20 + [0.05] * 16); p = p / p.sum()
+    n = nbytes // 2
+    hi = (r.choice(len(p), size=n, p=p) * 3 + 40).astype(np.uint8)
+    lo = r.integers(0, 256, size=n, dtype=np.uint8)
+    return np.stack([lo, hi], axis=1).reshape(-1).tobytes()
+
+
+@pytest.mark.parametrize("kind,nb,P,rot,bm,wide_chunks,pending", [
+    ("bf16", 3 * C, 2, 1, 10, 3, 0), ("fp32", 2 * C, 4, 1, 220, 2, 0), ("bf16", 2 * C + C // 2 + 10, 2, 1, 10, 2, 1), ("fp32", C + C // 4 + 4, 4, 1, 220, 1, 1),
+    ("fp8", 2 * C, 1, 0, 10, 0, 2), ("fp16", 2 * C, 2, 0, 10, 0, 2), ("rand", 2 * C, 2, 1, 10, 0, 2), ("const", 2 * C, 2, 1, 10, 0, 2), ("slowsync", 3 * C, 2, 0, 10, 3, 0)],
+    ids=["bf16", "fp32", "bf16-tail", "fp32-tail", "fp8-dense-code", "fp16-dense-code", "raw-planes", "rle-planes", "slow-sync"])
+def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt_lib, wide_mode, kind, nb, P, rot, bm, wide_chunks, pending):
+    """Forced on (mode 2): the full chunks of weights-like tensors are decoded by zn_k_decode_wide (counter 4 of the emulated build); dense codes,
+    chunks without exactly one Huffman plane and partial last chunks are left pending (counter 5) and taken by the fused kernel behind it — same
+    bytes in every case.  The slow-sync tensor makes some tile tops guess wrong: those tiles are decoded again (counter 6)."""
+    d = _slow_sync_bf16(nb, 4) if kind == "slowsync" else _gen2(kind, nb, 23)
+    frame = O.compress_frame(HDR, d, P, rot, bm, C)
+    wide_mode(2)
+    _tile_counters()
+    assert bytes(simt_lib.decompress(frame[32:], P, rot, bm, C, len(d))) == d
+    cnt = _tile_counters()
+    assert cnt[4] == wide_chunks and cnt[5] == pending
+    ks = simt_lib.last_kernels().split(";")
+    assert ks[0] == ("zn_k_decode_wide+tail" if nb % C and kind in ("bf16", "fp32") else "zn_k_decode_wide") and ks[1] == "zn_k_decode_fused^pending"
+    if kind == "slowsync":
+        assert cnt[6] > 0
+    if pending == 0:
+        assert cnt[0] == 0                       # no tile went through the fused kernel
+    wide_mode(0)
+    assert bytes(simt_lib.decompress(frame[32:], P, rot, bm, C, len(d))) == d
+    assert simt_lib.last_kernels().split(";")[0].startswith("zn_k_decode_fused") and "wide" not in simt_lib.last_kernels()
+
+
+def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_one_chunk_per_cu(simt_lib, wide_mode):
+    """Mode 1 (the default): calls whose chunks number at most the CUs of the device (the emulated device has one) and carry no delta base."""
+    d1 = _gen2("bf16", C, 5); d3 = _gen2("bf16", 3 * C, 6)
+    f1 = O.compress_frame(HDR, d1, 2, 1, 10, C); f3 = O.compress_frame(HDR, d3, 2, 1, 10, C)
+    wide_mode(1)
+    assert bytes(simt_lib.decompress(f1[32:], 2, 1, 10, C, len(d1))) == d1
+    assert simt_lib.last_kernels().startswith("zn_k_decode_wide;")
+    assert bytes(simt_lib.decompress(f3[32:], 2, 1, 10, C, len(d3))) == d3
+    assert simt_lib.last_kernels().startswith("zn_k_decode_fused;")
+    with pytest.raises(ValueError):
+        simt_lib.set_decode_wide(3)
+
+
+def test_wide_decoder_batches_and_corrupt_streams(simt_lib, wide_mode):
+    """A batch (segment table) through the wide kernel; a corrupted stream is handed to the fused kernel, which reports it."""
+    from zipnn_amd import codec
+    wide_mode(2)
+    specs = [("bf16", 2 * C + 10, 2, 1, 10, C), ("fp32", 2 * C, 4, 1, 220, C), ("fp8", C + 1, 1, 1, 10, C), ("bf16", 7, 2, 1, 10, C), ("bf16", 0, 2, 1, 10, C)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = gen_bytes(kind, nb, 40 + i)
+        body = O.compress_frame(HDR, d, P, rot, bm, chunk)[32:]
+        datas.append(d)
+        items.append((torch.frombuffer(bytearray(body), dtype=torch.uint8) if body else torch.empty(0, dtype=torch.uint8), P, rot, bm, chunk, nb))
+    _tile_counters()
+    outs = codec.decompress_device_batch(simt_lib, items)
+    for d, o in zip(datas, outs):
+        assert o.numpy().tobytes() == d
+    assert _tile_counters()[4] == 2 + 2 and "zn_k_decode_wide" in simt_lib.last_kernels()
+    # a stream whose last byte is zero (no end mark): the wide kernel leaves the chunk pending, the fused kernel reports it
+    d = _gen2("bf16", 2 * C, 9)
+    body = bytearray(O.compress_frame(HDR, d, 2, 1, 10, C)[32:])
+    K = 2
+    PK = 2 * K                                                            # body = types[P][K], cumulative sizes u64[P][K] (per plane), payload plane by plane
+    cum = lambda p, c: int.from_bytes(body[PK + 8 * (p * K + c): PK + 8 * (p * K + c) + 8], "little")
+    assert body[1 * K + 0] == 1 and cum(1, 0) < C // 2                    # plane 1 (sign-rotated exponent byte) of chunk 0 is a huff0 block
+    body[9 * PK + cum(0, K - 1) + cum(1, 0) - 1] = 0                      # its last byte = the last byte of its stream 4
+    _tile_counters()
+    with pytest.raises(RuntimeError):
+        simt_lib.decompress(bytes(body), 2, 1, 10, C, len(d))
+    cnt = _tile_counters()
+    assert cnt[5] >= 1

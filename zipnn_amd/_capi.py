@@ -85,6 +85,8 @@ class ZnLib:
         L.zn_set_host_slices.argtypes = [ci]
         L.zn_set_decode_group.restype = ci
         L.zn_set_decode_group.argtypes = [ci]
+        L.zn_set_decode_wide.restype = ci
+        L.zn_set_decode_wide.argtypes = [ci]
         L.zn_compress_dev.restype = ci
         L.zn_compress_dev.argtypes = [vp, sz, ci, ci, ci, sz, cf, vp, sz, ctypes.POINTER(sz), vp]
         L.zn_decompress_dev.restype = ci
@@ -267,6 +269,10 @@ class ZnLib:
     def set_legacy_tree_descriptions(self, on):
         """zn_set_legacy_tree_descriptions: True = write tree descriptions the way the reference's PyPI wheels do (-1 markers)."""
         self._check(self._L.zn_set_legacy_tree_descriptions(1 if on else 0))
+
+    def set_decode_wide(self, mode):
+        """Tuning knob (zn_set_decode_wide): the small-input decoder — 0 never, 1 automatic (default), 2 every call without a delta base."""
+        self._check(self._L.zn_set_decode_wide(int(mode)))
 
     def set_decode_group(self, chunks_per_workgroup):
         """Tuning knob (zn_set_decode_group): chunks per workgroup of the fused decoder, 1..4; 0 = automatic."""

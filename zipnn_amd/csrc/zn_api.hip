@@ -291,8 +291,14 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   uint64_t pk_of[3] = {0, 0, 0}, k_of[3] = {0, 0, 0}; uint64_t wg_of[3] = {0, 0, 0}, tail_of[3] = {0, 0, 0};
   bool delta_of[3] = {false, false, false};
   uint64_t total_chunks = 0;
-  for (size_t i = 0; i < count; i++) total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk);
-  const uint32_t ncg = zn_decode_fused_group(total_chunks);
+  bool any_delta = false;
+  uint64_t full_chunks = 0;
+  for (size_t i = 0; i < count; i++) {
+    total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk); if (items[i].d_delta) any_delta = true;
+    if (items[i].chunk) full_chunks += items[i].orig_size / items[i].chunk;
+  }
+  const bool wide = zn_decode_use_wide(full_chunks, any_delta);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
+  const uint32_t ncg = wide ? 1u : zn_decode_fused_group(total_chunks);
   for (size_t i = 0; i < count; i++) {
     const zn_batch_item& it = items[i];
     ZnSeg sg;
@@ -342,7 +348,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if ((rc = ws_acquire(w, stream))) return rc;
   uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
   w.last_K = all_k; w.last_tails = all_tail;
-  ZN_HIP(hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream));     // status + the three "left to the generic kernels" counters
+  // status + the three "left to the generic kernels" counters (a wide call: its first kernel zeroes them)
+  bool status_zeroed = false;
+  if (!wide || all_tail) { ZN_HIP(hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream)); status_zeroed = true; }
   if (all_tail) ZN_HIP(hipMemsetAsync(w.buf[WS_META_A], 0, all_tail, stream));
   if (table) {
     // the previous batched call may still be reading the pinned staging: wait for it on the host
@@ -363,7 +371,8 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
-                           d_tail_done, delta_of[q], stream);
+                           d_tail_done, delta_of[q], wide ? (status_zeroed ? 1 : 2) : 0, stream);
+    status_zeroed = true;
     zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
   }

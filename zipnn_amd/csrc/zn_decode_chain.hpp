@@ -256,12 +256,15 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
 // shift: its source would be a register PAIR per step with a zero upper half, twice the registers.)
 // `hook(ZnIdx<t>)` runs after step t (the caller spreads its HBM requests for the flush over the pass there: their
 // destination registers come into use as the record registers fall out of it).
-template <int TF, int TB, bool DENSE = false, typename HOOK>
+// AMASK: byte-offset mask of the pair's first dword — ~3 for a linear staging buffer; (size - 4) for a CIRCULAR one of a power-of-two
+// size (zn_decode_wide.hpp), which has one more dword behind its end: the pair that starts in the last dword puts its second half
+// there, and the flush ORs that dword into dword 0.
+template <int TF, int TB, bool DENSE = false, uint32_t AMASK = ~3u, typename HOOK>
 __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& rec, int nfull, int nbnd, HOOK&& hook) {
   uint32_t wm1 = wpos - 1u;                                // (wpos == 0: the pair starts one dword below the buffer and that dword gets a zero)
   auto put = [&](uint32_t cnt, uint32_t sv) {
     const uint32_t g = ~wm1;                               // low two bits = (-wpos) & 3
-    uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & ~3u));
+    uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & AMASK));
 #ifndef ZN_F_P2_MASK
 #define ZN_F_P2_MASK 2        // 1: lanes with nothing to add stay out of the atomics (exec mask) — 2: per dword.  (0, every lane every dword, is a
                               // developer measurement only, refused outside ZN_DEV_BUILD: with wpos == 0 the pair starts one dword BELOW the staging

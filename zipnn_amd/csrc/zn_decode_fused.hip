@@ -230,24 +230,27 @@ struct __attribute__((aligned(16))) ZnFusedLds {
 // Decode tables of one huff0 block, by the whole workgroup: the canonical single-symbol LUT (u16, aliased into
 // staging buffer 0, idle at this point), then the multi-symbol LUT.  j = which of the group's symbol orders.
 // Contains one __syncthreads(); the caller syncs again before the staging buffers are used.
-__device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, uint32_t TL, uint32_t j, uint32_t lmin = 1) {
+// NT = threads of the workgroup (256: the fused kernel; 1024: the wide kernel of zn_decode_wide.hpp); LDS = its shared-memory struct.
+template <int NT = ZN_F_THREADS, typename LDS>
+__device__ __forceinline__ void zn_fused_fill_luts(LDS& L, uint32_t tid, uint32_t TL, uint32_t j, uint32_t lmin = 1) {
+  constexpr int KE = (int)((1u << ZN_F_TLMAX) / (uint32_t)NT);   // table entries per thread
   uint16_t* lut16 = (uint16_t*)&L.ring[0][0];
   {
     const ZnRankTab rt = zn_load_ranks(L.rank_start[j], L.sym_start[j]);
-    for (uint32_t u = tid; u < (1u << TL); u += ZN_F_THREADS) lut16[ZN_L16(u)] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
+    for (uint32_t u = tid; u < (1u << TL); u += (uint32_t)NT) lut16[ZN_L16(u)] = (uint16_t)zn_lut_entry(u, TL, L.symlist[j], rt, L.rank_start[j], L.sym_start[j]);
   }
   __syncthreads();
   {
-    // 2^TL / 256 ≤ 8 entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
+    // 2^TL / NT ≤ KE entries per thread, advanced in lock-step so the dependent LUT16 reads overlap
     const uint32_t mask = (1u << TL) - 1u;
-    uint32_t pos[8], cnt[8], syms[8], ef[8];
-    for (int k = 0; k < 8; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; }
+    uint32_t pos[KE], cnt[KE], syms[KE], ef[KE];
+    for (int k = 0; k < KE; k++) { pos[k] = 0; cnt[k] = 0; syms[k] = 0; ef[k] = 0; }
     // (a window of TL bits holds at most TL / lmin symbols: a dense code's table needs two rounds of look-ups, not four)
     const int rounds = (int)zn_uniform(lmin ? (TL / lmin > 4u ? 4u : TL / lmin) : 4u);
     for (int step = 0; step < 4; step++) {
       if (step >= rounds) break;
-      for (int k = 0; k < 8; k++) {
-        const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+      for (int k = 0; k < KE; k++) {
+        const uint32_t u = tid + (uint32_t)k * (uint32_t)NT;
         if (u <= mask && cnt[k] == (uint32_t)step) {
           const uint32_t e = lut16[ZN_L16((u << pos[k]) & mask)]; const uint32_t len = e >> 8;
           if (pos[k] + len <= TL) {             // the window holds this code completely
@@ -258,8 +261,8 @@ __device__ __forceinline__ void zn_fused_fill_luts(ZnFusedLds& L, uint32_t tid, 
         }
       }
     }
-    for (int k = 0; k < 8; k++) {
-      const uint32_t u = tid + (uint32_t)k * ZN_F_THREADS;
+    for (int k = 0; k < KE; k++) {
+      const uint32_t u = tid + (uint32_t)k * (uint32_t)NT;
       for (uint32_t i = 1; i <= 3u; i++) if (i >= cnt[k]) ef[k] |= pos[k] << (16u + 4u * (i - 1u));   // E_i = total for a symbol that does not exist
       if (u <= mask) L.lut[u] = make_uint2(syms[k], ZN_E_META(cnt[k], pos[k], ef[k]));
     }
@@ -840,7 +843,7 @@ template <int P, bool X>
 __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                   uint32_t* __restrict__ status, uint32_t ntail,
-                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done) {
+                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done, uint32_t only_pending) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
@@ -864,6 +867,8 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 //  return at once when it is zero)
 #define ZN_SET_DONE(c_, v_) do { if (tid == 0) { done[c_] = (v_); if (!(v_)) atomicAdd(status + 1 + (P == 1 ? 0 : P == 2 ? 1 : 2), 1u); } if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;
+  // behind the wide kernel (zn_decode_wide.hpp; one chunk per workgroup there and here): only the chunks it left pending
+  if (only_pending && zn_uniform(done[(uint64_t)(wg - S.wg0) * ncg]) != 2u) return;
 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // (wave-uniform, and the compiler should know: everything derived from it lives in scalar registers)
   const uint64_t c0 = (uint64_t)(wg - S.wg0) * ncg;
@@ -1001,6 +1006,8 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
   ZN_PT_FLUSH();
 }
 
+#include "zn_decode_wide.hpp"
+
 // The Huffman-coded planes of a PARTIAL last chunk: one workgroup per plane, wave w = stream w, with the same
 // parallel stream decoder (its single-plane instance), into a padded scratch slot: stream w's symbols start at
 // slot + w * ZN_TAIL_SEGPAD.  The generic merge kernel interleaves from there.  Anything unusual (raw / RLE /
@@ -1034,6 +1041,23 @@ uint32_t zn_decode_fused_group(uint64_t K) {
   if (forced >= 1 && forced <= 4) ncg = (uint32_t)forced;
   return ncg;
 }
+// The wide kernel (zn_decode_wide.hpp) takes a call whose full chunks number at most the CUs of the device — below that the fused
+// kernel's workgroups leave most of the chip idle.  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 = always.
+static std::atomic<int> g_zn_decode_wide{1};
+bool zn_decode_use_wide(uint64_t K, bool delta) {
+  const int mode = g_zn_decode_wide.load(std::memory_order_relaxed);
+  if (mode == 0 || delta || K == 0) return false;
+  if (mode == 2) return true;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
+  return K <= (uint64_t)cus;
+}
+extern "C" int zn_set_decode_wide(int mode) {
+  if (mode < 0 || mode > 2) return -1;     // ZN_E_ARG
+  g_zn_decode_wide.store(mode, std::memory_order_relaxed);
+  return 0;
+}
 extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
   if (chunks_per_workgroup < 0 || chunks_per_workgroup > 4) return -1;     // ZN_E_ARG
   g_zn_decode_group.store(chunks_per_workgroup, std::memory_order_relaxed);
@@ -1042,12 +1066,22 @@ extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
 
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, hipStream_t stream) {
+                            uint8_t* d_tail_done, bool delta, int wide, hipStream_t stream) {
   if (total_wg == 0) return;
+  const uint32_t only_pending = wide ? 1u : 0u;
+  if (wide) {
+    // small inputs: one 16-wave workgroup per chunk first; the fused kernel behind it takes what that one left pending (and the tails)
+    const uint32_t zs = (wide == 2 && ntail == 0) ? 1u : 0u;
+#define ZN_GOW(P_) hipLaunchKernelGGL((zn_k_decode_wide<P_>), dim3(total_wg + ntail), dim3(ZN_W_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail, d_tail_scratch, d_tail_done)
+    if (P == 1) ZN_GOW(1); else if (P == 2) ZN_GOW(2); else ZN_GOW(4);
+#undef ZN_GOW
+    zn_note_kernel(ntail ? "zn_k_decode_wide+tail" : "zn_k_decode_wide");
+    ntail = 0;                                   // (done: the launch below has none)
+  }
   total_wg += ntail;                             // the tail workgroups come first
-#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done)
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, only_pending)
   if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
   else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO
-  zn_note_kernel(delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
+  zn_note_kernel(wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
 }
