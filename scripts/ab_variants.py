@@ -112,6 +112,9 @@ VARIANTS = {
     "spec8w5": ("b49b217", ["-DZN_F_SPEC_WAVES=5"]),   # … 96 VGPRs: two workgroups per CU
     "spec8free": ("b49b217", ["-DZN_F_ABL=96"]),    # … timing only: neither side of the hand-over waits
     "spec8pers": ("b49b217", ["-DZN_F_PERSIST=1"]), # … persistent workgroups
+    # (an unrolled run-in for up to 88 / 110 / 132 bits — the dense instance's 88 bits go through the looping form — was built and measured
+    #  in round 4: no effect on any dtype, profiles/r04_decode_experiments.txt; not in the sources)
+    "r04a": ("5b359c5", []),
 }
 
 
@@ -149,7 +152,7 @@ def load(path):
     return L
 
 
-ALLD = ("r01", "r02", "r03", "pipe", "pipecond", "pipeoff", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
+ALLD = ("r04a", "r01", "r02", "r03", "pipe", "pipecond", "pipeoff", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
 
 
 def run(names):
