@@ -72,7 +72,7 @@ def make_tensor(n_bytes, device, seed, dtype=torch.bfloat16):
 
 def stats(ms):
     s = sorted(ms)
-    return {"avg": sum(ms) / len(ms), "min": s[0], "median": s[len(s) // 2]}
+    return {"avg": sum(ms) / len(ms), "min": s[0], "median": s[len(s) // 2], "max": s[-1]}
 
 
 def time_events(fn, steps):
@@ -84,6 +84,34 @@ def time_events(fn, steps):
         ev[i + 1].record()
     torch.cuda.synchronize()
     return [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
+
+
+def device_state_under_load(burst):
+    """Shader clock / power of the busy GPU while `burst()` (asynchronous launches worth ~0.2 s) is in flight — outside every timed region.
+    The boxes of a pool differ (the same library: 1.46-1.69 ms per step); this says whether a slow line is a slow box.  Read from the amdgpu
+    hwmon files of every card of the node (the busy one is the one with the highest shader clock); None where they cannot be read."""
+    import glob
+    try:
+        burst()
+        time.sleep(0.06)
+        best = None
+        for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+            def rd(name):
+                try:
+                    with open(os.path.join(hw, name)) as f:
+                        return int(f.read().strip())
+                except (OSError, ValueError):
+                    return None
+            sclk = rd("freq1_input")
+            if sclk is not None and (best is None or sclk > best["sclk_MHz"] * 1e6):
+                p, cap, mclk, t = rd("power1_input"), rd("power1_cap"), rd("freq2_input"), rd("temp2_input")
+                best = {"sclk_MHz": round(sclk / 1e6), "mclk_MHz": None if mclk is None else round(mclk / 1e6), "power_W": None if p is None else round(p / 1e6),
+                        "power_cap_W": None if cap is None else round(cap / 1e6), "temp_C": None if t is None else round(t / 1e3)}
+        torch.cuda.synchronize()
+        return best
+    except Exception:       # noqa: BLE001 — a diagnostic, never a reason to fail the bench
+        torch.cuda.synchronize()
+        return None
 
 
 def rank_spread(td, device, my_ms, world):
@@ -110,8 +138,9 @@ def size_sweep(lib, codec, device, steps):
         d = stats(time_events(lambda: codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n, out=dst, check=False), steps))
         c = stats(time_events(lambda: codec.compress_device(lib, flat, P, ROT, BMODE, CHUNK, THR), max(2, steps // 2)))
         torch.cuda.synchronize()
-        out[f"{mib}MiB"] = {"decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "compress_GBps": round(n / c["avg"] / 1e6, 1),
-                            "compress_ms": round(c["avg"], 4), "exact": bool(torch.equal(dst, flat))}
+        out[f"{mib}MiB"] = {"decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "decompress_ms_median": round(d["median"], 4),
+                            "compress_GBps": round(n / c["avg"] / 1e6, 1), "compress_ms": round(c["avg"], 4), "compress_ms_median": round(c["median"], 4),
+                            "compress_ms_max": round(c["max"], 4), "exact": bool(torch.equal(dst, flat))}
         del x, flat, body, dst
     torch.cuda.empty_cache()
     return out
@@ -681,6 +710,7 @@ def main():
                                   "note": "events bracket the whole zn_compress_dev call: four kernels + one 8-byte length read-back"},
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},
         }
+        line["device_under_load"] = device_state_under_load(lambda: [codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n_bytes, out=out, check=False) for _ in range(120)])
         line["rccl_ranks"] = rccl_ranks
         line["rank_ms_per_step"] = rank_ms          # every rank's own wall time per step (a straggler shows as max >> min); null without torch.distributed
     # ---- BASELINE.json configs[4] on the same line, at every N (every rank takes part; strong scaling) ----

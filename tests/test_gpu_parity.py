@@ -148,7 +148,7 @@ def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, reques
             for _ in range(6 if nb <= 8 * C else 2):
                 assert bytes(lib.decompress(frame[32:], P, rot, bm, C, nb)) == d, (kind, nb, mode)
             used = lib.last_kernels().split(";")[0]
-            assert used.startswith("zn_k_decode_wide") == (mode == 2 or (mode == 1 and K <= cus)), (used, mode, K)
+            assert used.startswith("zn_k_decode_wide") == (mode == 2 or (mode == 1 and nb // C <= cus and rot == 1)), (used, mode, K)     # (automatic: sign-rotated layouts only)
             assert lib.last_fused_chunks() >= (nb // C if kind in ("bf16", "fp32", "fp16", "fp8", "slowsync") else 0)
 
 

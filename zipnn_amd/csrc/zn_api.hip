@@ -292,12 +292,14 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   bool delta_of[3] = {false, false, false};
   uint64_t total_chunks = 0;
   bool any_delta = false;
-  uint64_t full_chunks = 0;
+  uint64_t full_chunks = 0; bool all_rotated = true;
   for (size_t i = 0; i < count; i++) {
     total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk); if (items[i].d_delta) any_delta = true;
     if (items[i].chunk) full_chunks += items[i].orig_size / items[i].chunk;
+    // (tensors without the sign rotate — fp16, fp8, integers: their Huffman planes are dense codes, which the wide kernel parses and declines)
+    if (!(items[i].bits_mode == 1 && items[i].num_buf > 1)) all_rotated = false;
   }
-  const bool wide = zn_decode_use_wide(full_chunks, any_delta);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
+  const bool wide = zn_decode_use_wide(full_chunks, any_delta, all_rotated);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
   const uint32_t ncg = wide ? 1u : zn_decode_fused_group(total_chunks);
   for (size_t i = 0; i < count; i++) {
     const zn_batch_item& it = items[i];

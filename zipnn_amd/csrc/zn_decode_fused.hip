@@ -1042,12 +1042,14 @@ uint32_t zn_decode_fused_group(uint64_t K) {
   return ncg;
 }
 // The wide kernel (zn_decode_wide.hpp) takes a call whose full chunks number at most the CUs of the device — below that the fused
-// kernel's workgroups leave most of the chip idle.  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 = always.
+// kernel's workgroups leave most of the chip idle — if its tensors are split with the sign rotate (bf16 / fp32: the layouts whose Huffman plane
+// is an exponent byte; measured: fp16 / fp8 calls only pay the extra parse, 2-12 us).  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 = always.
 static std::atomic<int> g_zn_decode_wide{1};
-bool zn_decode_use_wide(uint64_t K, bool delta) {
+bool zn_decode_use_wide(uint64_t K, bool delta, bool weights_like) {
   const int mode = g_zn_decode_wide.load(std::memory_order_relaxed);
   if (mode == 0 || delta || K == 0) return false;
   if (mode == 2) return true;
+  if (!weights_like) return false;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
