@@ -186,9 +186,10 @@ int zn_copy_to_host(void* dst, const void* d_src, size_t n);
  * to fill every workgroup slot of the device with groups, fewer for small tensors).  Process-wide.  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_group(int chunks_per_workgroup);
 
-/* Tuning knob: the small-input form of the decoder (one 16-wave workgroup per chunk, four waves per huff0 stream) — 0 = never,
- * 1 (default) = automatic: calls whose full chunks number at most the compute units of the device, whose tensors are all split with the
- * sign rotate (bits_mode 1 with 2 or 4 byte planes: bf16, fp32) and have no delta base, 2 = every call without a delta base.  The bytes produced are the same in every mode.  Process-wide.  Returns 0 or ZN_E_ARG. */
+/* Tuning knob: the small-input form of the decoder (one workgroup per chunk, four or two waves per huff0 stream) — 0 = never,
+ * 1 (default) = automatic: calls whose tensors are all split with the sign rotate (bits_mode 1 with 2 or 4 byte planes: bf16, fp32), are whole
+ * multiples of their chunk size, have no delta base and at most one (16-wave form) or two (8-wave form) chunks per compute unit of the device; 2 / 3 = every call without a
+ * delta base, 16- / 8-wave form.  The bytes produced are the same in every mode.  Process-wide.  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_wide(int mode);
 
 /* Tuning knob of the host-buffer entry points (zn_compress / zn_decompress): slices of the three-stage pipeline

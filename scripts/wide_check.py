@@ -26,7 +26,7 @@ def main():
             flat = x.view(torch.uint8).reshape(-1); n = flat.numel()
             body = codec.compress_device(lib, flat, P, rot, bm, B.CHUNK, B.THR).clone()
             row = {"kind": kind, "MiB": round(n / 2**20, 2)}
-            for mode in (0, 1, 2):
+            for mode in (0, 1, 2, 3):
                 lib.set_decode_wide(mode)
                 dst = torch.zeros(n, dtype=torch.uint8, device=dev)
                 codec.decompress_device(lib, body, P, rot, bm, B.CHUNK, n, out=dst, check=True)

@@ -46,9 +46,9 @@ def main():
         n = flat.numel()
         body = codec.compress_device(lib, flat, P, rot, bm, C, 0.95).clone()
         outs = {}
-        for mode in (2, 0):
+        for mode in (2, 3, 0):
             lib.set_decode_wide(mode)
-            for rep in range(3 if mode == 2 else 1):
+            for rep in range(3 if mode else 1):
                 dst = torch.zeros(n, dtype=torch.uint8, device=dev)
                 codec.decompress_device(lib, body, P, rot, bm, C, n, out=dst, check=True)
                 if not torch.equal(dst, flat):

@@ -133,7 +133,7 @@ def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, reques
     from test_kernels_simt import _gen2, _slow_sync_bf16
     request.addfinalizer(lambda: lib.set_decode_wide(1))
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    for nb in (C, 7 * C + C // 2 + 10, 200 * C, (cus + 1) * C):
+    for nb in (C, 7 * C + C // 2 + 10, 200 * C, (cus + 1) * C, (2 * cus + 1) * C):
         if kind == "slowsync":
             d = _slow_sync_bf16(nb, 3)
         elif kind == "mixed":          # chunk by chunk: weights-like, incompressible, constant, two Huffman planes, dense
@@ -143,12 +143,15 @@ def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, reques
         frame = O.compress_frame(HDR, d, P, rot, bm, C, threads=8)
         assert bytes(lib.compress(HDR, d, P, rot, bm, C, 0.95)) == frame
         K = (nb + C - 1) // C
-        for mode in (1, 2, 0):
+        for mode in (1, 2, 3, 0):
             lib.set_decode_wide(mode)
             for _ in range(6 if nb <= 8 * C else 2):
                 assert bytes(lib.decompress(frame[32:], P, rot, bm, C, nb)) == d, (kind, nb, mode)
             used = lib.last_kernels().split(";")[0]
-            assert used.startswith("zn_k_decode_wide") == (mode == 2 or (mode == 1 and nb // C <= cus and rot == 1)), (used, mode, K)     # (automatic: sign-rotated layouts only)
+            full = nb // C
+            want = {0: "zn_k_decode_fused", 2: "zn_k_decode_wide", 3: "zn_k_decode_wide^2",
+                    1: "zn_k_decode_fused" if rot != 1 or nb % C or full > 2 * cus else "zn_k_decode_wide" if full <= cus else "zn_k_decode_wide^2"}[mode]     # (automatic: sign-rotated layouts, whole chunks)
+            assert used.split("+")[0] == want, (used, mode, K)
             assert lib.last_fused_chunks() >= (nb // C if kind in ("bf16", "fp32", "fp16", "fp8", "slowsync") else 0)
 
 

@@ -750,7 +750,7 @@ def test_ragged_planes_are_coded_inside_the_fused_launches(simt_lib):
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.fixture()
 def wide_mode(simt_lib):
-    """zn_set_decode_wide for one test (0 never / 1 automatic / 2 always); back to automatic afterwards."""
+    """zn_set_decode_wide for one test (0 never / 1 automatic / 2 always, 16-wave form / 3 always, 8-wave form); back to automatic afterwards."""
     yield simt_lib.set_decode_wide
     simt_lib.set_decode_wide(1)
 
@@ -770,19 +770,21 @@ def _slow_sync_bf16(nbytes, seed):
     ("bf16", 3 * C, 2, 1, 10, 3, 0), ("fp32", 2 * C, 4, 1, 220, 2, 0), ("bf16", 2 * C + C // 2 + 10, 2, 1, 10, 2, 1), ("fp32", C + C // 4 + 4, 4, 1, 220, 1, 1),
     ("fp8", 2 * C, 1, 0, 10, 0, 2), ("fp16", 2 * C, 2, 0, 10, 0, 2), ("rand", 2 * C, 2, 1, 10, 0, 2), ("const", 2 * C, 2, 1, 10, 0, 2), ("slowsync", 3 * C, 2, 0, 10, 3, 0)],
     ids=["bf16", "fp32", "bf16-tail", "fp32-tail", "fp8-dense-code", "fp16-dense-code", "raw-planes", "rle-planes", "slow-sync"])
-def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt_lib, wide_mode, kind, nb, P, rot, bm, wide_chunks, pending):
+@pytest.mark.parametrize("mode", [2, 3], ids=["16-waves", "8-waves"])
+def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt_lib, wide_mode, mode, kind, nb, P, rot, bm, wide_chunks, pending):
     """Forced on (mode 2): the full chunks of weights-like tensors are decoded by zn_k_decode_wide (counter 4 of the emulated build); dense codes,
     chunks without exactly one Huffman plane and partial last chunks are left pending (counter 5) and taken by the fused kernel behind it — same
     bytes in every case.  The slow-sync tensor makes some tile tops guess wrong: those tiles are decoded again (counter 6)."""
     d = _slow_sync_bf16(nb, 4) if kind == "slowsync" else _gen2(kind, nb, 23)
     frame = O.compress_frame(HDR, d, P, rot, bm, C)
-    wide_mode(2)
+    wide_mode(mode)                        # 2: four waves per stream (16-wave workgroups), 3: two (8-wave workgroups, two per CU)
     _tile_counters()
     assert bytes(simt_lib.decompress(frame[32:], P, rot, bm, C, len(d))) == d
     cnt = _tile_counters()
     assert cnt[4] == wide_chunks and cnt[5] == pending
     ks = simt_lib.last_kernels().split(";")
-    assert ks[0] == ("zn_k_decode_wide+tail" if nb % C and kind in ("bf16", "fp32") else "zn_k_decode_wide") and ks[1] == "zn_k_decode_fused^pending"
+    name = "zn_k_decode_wide" if mode == 2 else "zn_k_decode_wide^2"
+    assert ks[0] == (name + "+tail" if nb % C and kind in ("bf16", "fp32") else name) and ks[1] == "zn_k_decode_fused^pending"
     if kind == "slowsync":
         assert cnt[6] > 0
     if pending == 0:
@@ -792,17 +794,27 @@ def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt
     assert simt_lib.last_kernels().split(";")[0].startswith("zn_k_decode_fused") and "wide" not in simt_lib.last_kernels()
 
 
-def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_one_chunk_per_cu(simt_lib, wide_mode):
-    """Mode 1 (the default): calls whose chunks number at most the CUs of the device (the emulated device has one) and carry no delta base."""
-    d1 = _gen2("bf16", C, 5); d3 = _gen2("bf16", 3 * C, 6)
-    f1 = O.compress_frame(HDR, d1, 2, 1, 10, C); f3 = O.compress_frame(HDR, d3, 2, 1, 10, C)
+def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(simt_lib, wide_mode):
+    """Mode 1 (the default): sign-rotated layouts without a delta base, at most one full chunk per CU of the device (the emulated device has one CU)
+    in the 16-wave form, at most two in the 8-wave form."""
+    d1 = _gen2("bf16", C, 5); d2 = _gen2("bf16", 2 * C, 7); d3 = _gen2("bf16", 3 * C, 6)
+    f1 = O.compress_frame(HDR, d1, 2, 1, 10, C); f2 = O.compress_frame(HDR, d2, 2, 1, 10, C); f3 = O.compress_frame(HDR, d3, 2, 1, 10, C)
     wide_mode(1)
     assert bytes(simt_lib.decompress(f1[32:], 2, 1, 10, C, len(d1))) == d1
-    assert simt_lib.last_kernels().startswith("zn_k_decode_wide;")
+    assert simt_lib.last_kernels().startswith("zn_k_decode_wide;")                  # one chunk per CU: four waves per stream
+    assert bytes(simt_lib.decompress(f2[32:], 2, 1, 10, C, len(d2))) == d2
+    assert simt_lib.last_kernels().startswith("zn_k_decode_wide^2")                 # two: the 8-wave form
     assert bytes(simt_lib.decompress(f3[32:], 2, 1, 10, C, len(d3))) == d3
     assert simt_lib.last_kernels().startswith("zn_k_decode_fused;")
+    dt = d1 + d1[:1000]                                                             # a partial last chunk: its tail workgroup + merge set the pace either way
+    ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
+    assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
+    assert simt_lib.last_kernels().startswith("zn_k_decode_fused+tail;")
+    f16 = O.compress_frame(HDR, d1, 2, 0, 10, C)                                    # no sign rotate (an fp16 layout): not in automatic mode
+    assert bytes(simt_lib.decompress(f16[32:], 2, 0, 10, C, len(d1))) == d1
+    assert simt_lib.last_kernels().startswith("zn_k_decode_fused;")
     with pytest.raises(ValueError):
-        simt_lib.set_decode_wide(3)
+        simt_lib.set_decode_wide(4)
 
 
 def test_wide_decoder_batches_and_corrupt_streams(simt_lib, wide_mode):

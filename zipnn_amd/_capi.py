@@ -271,7 +271,7 @@ class ZnLib:
         self._check(self._L.zn_set_legacy_tree_descriptions(1 if on else 0))
 
     def set_decode_wide(self, mode):
-        """Tuning knob (zn_set_decode_wide): the small-input decoder — 0 never, 1 automatic (default), 2 every call without a delta base."""
+        """Tuning knob (zn_set_decode_wide): the small-input decoder — 0 never, 1 automatic (default), 2 / 3 every call without a delta base in its 16- / 8-wave form."""
         self._check(self._L.zn_set_decode_wide(int(mode)))
 
     def set_decode_group(self, chunks_per_workgroup):

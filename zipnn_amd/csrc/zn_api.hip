@@ -298,8 +298,11 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (items[i].chunk) full_chunks += items[i].orig_size / items[i].chunk;
     // (tensors without the sign rotate — fp16, fp8, integers: their Huffman planes are dense codes, which the wide kernel parses and declines)
     if (!(items[i].bits_mode == 1 && items[i].num_buf > 1)) all_rotated = false;
+    // (… and a partial last chunk is decoded by a four-wave tail workgroup + the merge kernel whichever kernel takes the full chunks: ≈ 130 µs a
+    //  call, the wide kernel's extra launch only adds to it — measured 146 vs 137 µs at 65 MiB + 250 KB)
+    if (items[i].chunk && items[i].orig_size % items[i].chunk) all_rotated = false;
   }
-  const bool wide = zn_decode_use_wide(full_chunks, any_delta, all_rotated);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
+  const int wide = zn_decode_use_wide(full_chunks, any_delta, all_rotated);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
   const uint32_t ncg = wide ? 1u : zn_decode_fused_group(total_chunks);
   for (size_t i = 0; i < count; i++) {
     const zn_batch_item& it = items[i];
@@ -373,7 +376,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
-                           d_tail_done, delta_of[q], wide ? (status_zeroed ? 1 : 2) : 0, stream);
+                           d_tail_done, delta_of[q], wide, status_zeroed, stream);
     status_zeroed = true;
     zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];

@@ -1043,20 +1043,22 @@ uint32_t zn_decode_fused_group(uint64_t K) {
 }
 // The wide kernel (zn_decode_wide.hpp) takes a call whose full chunks number at most the CUs of the device — below that the fused
 // kernel's workgroups leave most of the chip idle — if its tensors are split with the sign rotate (bf16 / fp32: the layouts whose Huffman plane
-// is an exponent byte; measured: fp16 / fp8 calls only pay the extra parse, 2-12 us).  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 = always.
+// is an exponent byte; measured: fp16 / fp8 calls only pay the extra parse, 2-12 us); up to two chunks per CU its 8-wave form, two workgroups per CU.
+// Returns the waves per stream (4 / 2) or 0.  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 / 3 = always the 16- / 8-wave form.
 static std::atomic<int> g_zn_decode_wide{1};
-bool zn_decode_use_wide(uint64_t K, bool delta, bool weights_like) {
+int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like) {     // weights_like: sign-rotated layouts, no partial last chunk
   const int mode = g_zn_decode_wide.load(std::memory_order_relaxed);
-  if (mode == 0 || delta || K == 0) return false;
-  if (mode == 2) return true;
-  if (!weights_like) return false;
+  if (mode == 0 || delta || K == 0) return 0;
+  if (mode == 2) return 4;
+  if (mode == 3) return 2;
+  if (!weights_like) return 0;
   int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return false; }
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return false; }
-  return K <= (uint64_t)cus;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return 0; }
+  return K <= (uint64_t)cus ? 4 : K <= 2ull * (uint64_t)cus ? 2 : 0;
 }
 extern "C" int zn_set_decode_wide(int mode) {
-  if (mode < 0 || mode > 2) return -1;     // ZN_E_ARG
+  if (mode < 0 || mode > 3) return -1;     // ZN_E_ARG
   g_zn_decode_wide.store(mode, std::memory_order_relaxed);
   return 0;
 }
@@ -1068,16 +1070,17 @@ extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
 
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, int wide, hipStream_t stream) {
+                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, hipStream_t stream) {
   if (total_wg == 0) return;
   const uint32_t only_pending = wide ? 1u : 0u;
   if (wide) {
     // small inputs: one 16-wave workgroup per chunk first; the fused kernel behind it takes what that one left pending (and the tails)
-    const uint32_t zs = (wide == 2 && ntail == 0) ? 1u : 0u;
-#define ZN_GOW(P_) hipLaunchKernelGGL((zn_k_decode_wide<P_>), dim3(total_wg + ntail), dim3(ZN_W_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail, d_tail_scratch, d_tail_done)
-    if (P == 1) ZN_GOW(1); else if (P == 2) ZN_GOW(2); else ZN_GOW(4);
+    const uint32_t zs = (!status_zeroed && ntail == 0) ? 1u : 0u;
+#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail, d_tail_scratch, d_tail_done)
+    if (wide == 4) { if (P == 1) ZN_GOW(1, 4); else if (P == 2) ZN_GOW(2, 4); else ZN_GOW(4, 4); }
+    else { if (P == 1) ZN_GOW(1, 2); else if (P == 2) ZN_GOW(2, 2); else ZN_GOW(4, 2); }
 #undef ZN_GOW
-    zn_note_kernel(ntail ? "zn_k_decode_wide+tail" : "zn_k_decode_wide");
+    zn_note_kernel(wide == 4 ? (ntail ? "zn_k_decode_wide+tail" : "zn_k_decode_wide") : (ntail ? "zn_k_decode_wide^2+tail" : "zn_k_decode_wide^2"));
     ntail = 0;                                   // (done: the launch below has none)
   }
   total_wg += ntail;                             // the tail workgroups come first

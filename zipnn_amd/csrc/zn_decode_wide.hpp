@@ -1,4 +1,4 @@
-// zn_decode_wide.hpp — decompress of SMALL inputs: one workgroup of 16 waves per chunk.  (Included by zn_decode_fused.hip.)
+// zn_decode_wide.hpp — decompress of SMALL inputs: one workgroup of 16 (or 8) waves per chunk.  (Included by zn_decode_fused.hip.)
 //
 // The fused kernel gives a chunk four waves, one per huff0 stream, and a stream's ~11 tiles are decoded one after the other:
 // ≈ 80 µs per chunk whatever the input size, which a tensor of a few hundred chunks (≤ 64 MiB of bf16: fewer chunks than the
@@ -15,36 +15,43 @@
 // dwords), no delta base.  Everything else is marked pending (done flag 2) and decoded by the fused kernel, which the host
 // launches behind this one in its `only pending` mode.  Results are the same bytes either way; this is a latency form.
 //
-// LDS: 16 KB LUT + 4 × 16 KB staging + 16 × 1 KB stream tiles ≈ 99 KB: one workgroup per CU.
+// Two sizes (template WPS = waves per stream).  Four: 16 waves, LDS 16 KB LUT + 4 × 16 KB staging + 16 × 1 KB stream tiles ≈ 99 KB, one workgroup
+// per CU — for calls of at most one chunk per CU.  Two: 8 waves, 16 + 4 × 8 + 8 ≈ 58 KB, two workgroups per CU (one parses its tree description
+// while the other decodes) — for calls of at most two chunks per CU, where four-wave workgroups of the fused kernel would still leave half the chip's
+// wave slots empty for the ≈ 80 µs a chunk takes them.
 #pragma once
 
-#define ZN_W_THREADS 1024
-#define ZN_W_RING 16384u                 // staging bytes per stream (power of two): a round's four tiles (≤ ~3.5 KB each) + the carried remainder
 #define ZN_W_D 4                         // sub-block dwords
 #define ZN_W_TD (64 * ZN_W_D)
 #define ZN_W_IN_DW (ZN_W_TD + 8)         // dwords lo_dw - 1 .. hi_dw + 1 of the tile (look-ahead below, run-in of the top sub-block above)
 #define ZN_W_DELTA 44                    // run-in (bits)
 #define ZN_W_MAXFIX 6                    // cross-wave fix-up iterations per round before the chunk is handed to the fused kernel
 
+// WPS = waves per huff0 stream: 4 (a 16-wave workgroup, one per CU: calls of at most one chunk per CU) or 2 (8 waves, 58 KB of LDS: two
+// workgroups per CU, one's tree description under the other's tiles: calls of at most two chunks per CU).
+template <int WPS>
 struct __attribute__((aligned(16))) ZnWideLds {
+  static constexpr uint32_t RING = 4096u * WPS;      // staging bytes per stream (power of two): a round's WPS tiles (≤ ~3.5 KB each) + the carried remainder
+  static constexpr uint32_t THREADS = 256u * WPS;
   uint2 lut[1u << ZN_F_TLMAX];
-  uint32_t ring[4][ZN_W_RING / 4 + 4];   // per stream, circular; dword ZN_W_RING / 4 = the second half of a pair that starts in the last dword
-  uint32_t in[16][ZN_W_IN_DW];           // per wave
+  uint32_t ring[4][RING / 4 + 4];        // per stream, circular; dword RING / 4 = the second half of a pair that starts in the last dword
+  uint32_t in[4 * WPS][ZN_W_IN_DW];      // per wave
   uint8_t symlist[1][256];
   uint32_t rank_start[1][14], sym_start[1][14];
   ZnFusedPlane plane[4];
   ZnWaveStats st;
   uint32_t what;
-  int32_t x_start[16], x_exit[16];       // per wave and round: where its tile's decode started / ended (bit positions)
-  uint32_t x_n[16], x_flag[16];          // symbols of the tile; 0 = no tile this round, 1 = decoded, 2 = failed
+  int32_t x_start[4 * WPS], x_exit[4 * WPS];   // per wave and round: where its tile's decode started / ended (bit positions)
+  uint32_t x_n[4 * WPS], x_flag[4 * WPS];      // symbols of the tile; 0 = no tile this round, 1 = decoded, 2 = failed
   uint32_t again[ZN_W_MAXFIX + 2];       // [i]: some wave decoded again in fix-up iteration i
   uint32_t rounds, fail;
 };
-static_assert(sizeof(ZnWideLds) <= 160u * 1024u, "ZnWideLds: one workgroup per CU");
+static_assert(sizeof(ZnWideLds<4>) <= 160u * 1024u, "ZnWideLds<4>: one workgroup per CU");
+static_assert(sizeof(ZnWideLds<2>) <= 80u * 1024u, "ZnWideLds<2>: two workgroups per CU");
 
 // One chunk, all 16 waves.  Returns (workgroup-uniform) whether the chunk was decoded; false = nothing usable was produced.
-template <int P, int H>
-__device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
+template <int P, int H, int WPS>
+__device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* outc, const ZnFusedPlane (&pl)[P], uint32_t seg, uint32_t TL,
                                               const uint8_t* js, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4) {
   constexpr int EPL = (P == 1) ? 16 : 8, EW = EPL / 4;
@@ -52,7 +59,8 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
   constexpr int RB = (P == 2) ? 8 : 4;      // rows of one flush batch: a wave's share of a round (the staging buffer holds ≤ 31 rows of 512 symbols, ≤ 15 of 1024) in one batch (two for 4 planes)
   constexpr int TF = ZN_F_TF(ZN_W_D), TB = 3, UF = (32 * ZN_W_D - 31) / 11;
   constexpr int32_t TD = ZN_W_TD;
-  const uint32_t tid = threadIdx.x, wave = zn_uniform(tid >> 6), s_id = wave >> 2, q = wave & 3u;
+  constexpr uint32_t ZN_W_RING = ZnWideLds<WPS>::RING, ZN_W_THREADS = ZnWideLds<WPS>::THREADS;
+  const uint32_t tid = threadIdx.x, wave = zn_uniform(tid >> 6), s_id = wave / (uint32_t)WPS, q = wave % (uint32_t)WPS;
   uint32_t lane = zn_lane_id();
   uint32_t lane_v = lane; ZN_OPAQUE32(lane_v);
   const uint32_t so = 6u + (s_id > 0 ? l1 : 0u) + (s_id > 1 ? l2 : 0u) + (s_id > 2 ? l3 : 0u);
@@ -80,7 +88,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
   const bool top_guard = ((const uint8_t*)(gdw + hi_dw0) > body_end);
   {
     const uint32_t ntiles = (uint32_t)((32 * hi_dw0 - b0 + 32 * TD - 1) / (32 * TD));
-    if (lane == 0 && q == 0) atomicMax(&L.rounds, (ntiles + 3u) / 4u);
+    if (lane == 0 && q == 0) atomicMax(&L.rounds, (ntiles + (uint32_t)WPS - 1u) / (uint32_t)WPS);
   }
   // tile k of the stream = dwords [hi_dw0 - (k + 1) TD, hi_dw0 - k TD); its dwords -1 .. TD + 2 (relative to lo_dw) go to `in`
   uint32_t nx[5];
@@ -101,7 +109,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
     for (int i = 0; i < 5; i++) { const uint32_t li = lane + 64u * (uint32_t)i; if (li < (uint32_t)TD + 3u) in[li] = nx[i]; }
     __builtin_amdgcn_wave_barrier();
   };
-  auto tile_hi = [&](uint32_t r) -> int32_t { return hi_dw0 - (int32_t)(4u * r + q) * TD; };
+  auto tile_hi = [&](uint32_t r) -> int32_t { return hi_dw0 - (int32_t)((uint32_t)WPS * r + q) * TD; };
   if (sok && 32 * tile_hi(0) > b0) { fetch_tile(tile_hi(0)); stage_tile(); }
   __syncthreads();
   const uint32_t rounds = zn_uniform(L.rounds);
@@ -181,12 +189,12 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
     int32_t expect = carry; bool chained = false;
     for (int it = 0; it <= ZN_W_MAXFIX; it++) {
       expect = carry; int bad = -1; bool broken = false;
-      for (uint32_t t = 0; t < 4u; t++) {
-        const uint32_t f = zn_uniform(L.x_flag[4u * s_id + t]);
+      for (uint32_t t = 0; t < (uint32_t)WPS; t++) {
+        const uint32_t f = zn_uniform(L.x_flag[(uint32_t)WPS * s_id + t]);
         if (f == 0u) break;
         if (f == 2u) { broken = true; break; }
-        if ((int32_t)zn_uniform((uint32_t)L.x_start[4u * s_id + t]) != expect) { bad = (int)t; break; }
-        expect = (int32_t)zn_uniform((uint32_t)L.x_exit[4u * s_id + t]);
+        if ((int32_t)zn_uniform((uint32_t)L.x_start[(uint32_t)WPS * s_id + t]) != expect) { bad = (int)t; break; }
+        expect = (int32_t)zn_uniform((uint32_t)L.x_exit[(uint32_t)WPS * s_id + t]);
       }
       if (broken) sok = false;
       const bool redo = sok && bad == (int)q && it < ZN_W_MAXFIX;
@@ -208,7 +216,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
     if (sok && !chained) sok = false;
     // (expect = the exit of the round's last tile)
     uint32_t off = 0, Nr = 0;
-    for (uint32_t t = 0; t < 4u; t++) { const uint32_t f = zn_uniform(L.x_flag[4u * s_id + t]); const uint32_t nt = (f == 1u) ? zn_uniform(L.x_n[4u * s_id + t]) : 0u; if (t < q) off += nt; Nr += nt; }
+    for (uint32_t t = 0; t < (uint32_t)WPS; t++) { const uint32_t f = zn_uniform(L.x_flag[(uint32_t)WPS * s_id + t]); const uint32_t nt = (f == 1u) ? zn_uniform(L.x_n[(uint32_t)WPS * s_id + t]) : 0u; if (t < q) off += nt; Nr += nt; }
     if (sok && (J + Nr > seg || (J - JF) + Nr > ZN_W_RING - 8u)) sok = false;
     if (!sok) { if (lane == 0) L.fail = 1u; Nr = 0; }
 
@@ -218,7 +226,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
     uint32_t pre[RB][P][EW];
     auto request_rows = [&](uint32_t m0) {
       for (int rr = 0; rr < RB; rr++) {
-        const uint32_t i = m0 + 4u * (uint32_t)rr;
+        const uint32_t i = m0 + (uint32_t)WPS * (uint32_t)rr;
         if (i < rows_total) {
           const uint32_t a = JF + i * UNIT;
           for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
@@ -241,12 +249,12 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
     __syncthreads();
 
     // ---- flush; the next tile is staged behind the first wait, ahead of the stores ----
-    for (uint32_t m0 = q; ; m0 += 4u * RB) {
+    for (uint32_t m0 = q; ; m0 += (uint32_t)WPS * RB) {
       if (m0 != q) request_rows(m0);
       __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0)
       if (m0 == q && have_next) stage_tile();
       for (int rr = 0; rr < RB; rr++) {
-        const uint32_t i = m0 + 4u * (uint32_t)rr;
+        const uint32_t i = m0 + (uint32_t)WPS * (uint32_t)rr;
         if (i < rows_total) {
           const uint32_t a = JF + i * UNIT, ra = a & (ZN_W_RING - 1u);
           for (int p = 0; p < P; p++) {
@@ -281,7 +289,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
           }
         }
       }
-      if (m0 + 4u * RB >= rows_total) break;
+      if (m0 + (uint32_t)WPS * RB >= rows_total) break;
     }
     if (sok) { J += Nr; JF += rows_total * UNIT; carry = expect; }
   }
@@ -293,15 +301,16 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds& L, const ZnGeom& g, con
 // zero_status: this is the first launch of the call (and it has no tail workgroups, which report through the status word).
 // grid: one workgroup per full chunk of the launch (segment table with ncg == 1).  done flag: 1 = decoded here, 2 = pending
 // (the fused kernel, launched behind this one with only_pending set, takes it).
-template <int P>
-__global__ __launch_bounds__(ZN_W_THREADS, 1) void zn_k_decode_wide(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+template <int P, int WPS>
+__global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                     uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                     uint32_t* __restrict__ status, uint32_t zero_status, uint32_t ntail,
                                                                     uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
-  __shared__ ZnWideLds L;
-  static_assert(sizeof(ZnFusedLds) <= sizeof(ZnWideLds), "the tail workgroups use the fused kernel's layout in the same allocation");
+  __shared__ ZnWideLds<WPS> L;
+  constexpr uint32_t ZN_W_RING = ZnWideLds<WPS>::RING, ZN_W_THREADS = ZnWideLds<WPS>::THREADS;
+  static_assert(sizeof(ZnFusedLds) <= sizeof(ZnWideLds<WPS>), "the tail workgroups use the fused kernel's layout in the same allocation");
   // the Huffman planes of partial last chunks: the fused kernel's tail workgroups (four waves), at the front of this grid too, so that
   // they run beside the full chunks and not behind them
   if (blockIdx.x < ntail) {
@@ -415,13 +424,13 @@ __global__ __launch_bounds__(ZN_W_THREADS, 1) void zn_k_decode_wide(ZnSeg one, c
     }
     const bool dense = Dmin > 4u && zn_uniform(st.lmin) >= ZN_F_DENSE_LMIN;
     if (!bad && Dmin >= 4u && !dense && (Dmin == 4u || zn_uniform(st.dom) < ZN_F_DOM_MAX)) {
-      zn_fused_fill_luts<ZN_W_THREADS>(L, tid, TL, 0, zn_uniform(st.lmin));
+      zn_fused_fill_luts<(int)ZN_W_THREADS>(L, tid, TL, 0, zn_uniform(st.lmin));
       __syncthreads();
       uint8_t* outc = dst + c * g.chunk;
-      if (P == 1 || h == 0) ok = zn_wide_chunk<P, 0>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
-      else if (P == 2 || h == 1) ok = zn_wide_chunk<P, (P >= 2 ? 1 : 0)>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
-      else if (h == 2) ok = zn_wide_chunk<P, (P >= 4 ? 2 : 0)>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
-      else ok = zn_wide_chunk<P, (P >= 4 ? 3 : 0)>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
+      if (P == 1 || h == 0) ok = zn_wide_chunk<P, 0, WPS>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
+      else if (P == 2 || h == 1) ok = zn_wide_chunk<P, (P >= 2 ? 1 : 0), WPS>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
+      else if (h == 2) ok = zn_wide_chunk<P, (P >= 4 ? 2 : 0), WPS>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
+      else ok = zn_wide_chunk<P, (P >= 4 ? 3 : 0), WPS>(L, g, body, body_end, outc, pl, seg, TL, js, l1, l2, l3, l4);
     }
   }
   if (tid == 0) done[c] = ok ? 1 : 2;

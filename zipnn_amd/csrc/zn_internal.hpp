@@ -44,10 +44,10 @@ uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a te
 // tail_done[i] = 1 where that worked — the generic kernels take it from there.
 void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, int wide, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
-// wide != 0: the launch's segments have ncg == 1 and zn_k_decode_wide (zn_decode_wide.hpp, small inputs) goes first; 2: … and zeroes
-// the status words (the call's first launch: the caller then leaves out its memset)
-bool zn_decode_use_wide(uint64_t total_full_chunks, bool delta, bool weights_like);     // weights_like: every tensor of the call is split with the sign rotate (bf16 / fp32)
+                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
+// wide = 4 / 2 (waves per stream): the launch's segments have ncg == 1 and zn_k_decode_wide (zn_decode_wide.hpp, small inputs) goes first;
+// !status_zeroed: … and zeroes the status words (the call's first launch: the caller then leaves out its memset)
+int zn_decode_use_wide(uint64_t total_full_chunks, bool delta, bool weights_like);     // weights_like: every tensor of the call is split with the sign rotate (bf16 / fp32)
 
 // ---- encode ----
 struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs for a plane kept as huff0 / RLE
