@@ -590,12 +590,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = world > 1 or ("LOCAL_RANK" in os.environ and "MASTER_ADDR" in os.environ)   # (under torch.distributed.run even a single rank takes the RCCL path)
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ZN_BENCH_SHARE_GPU=1 (+ ZN_BENCH_BACKEND=gloo): a DRY RUN of the N > 1 logic — barriers, max over ranks, per-rank times, the llama8b partition,
+    # rank 0's line — on a box with fewer GPUs than ranks (scripts/multi_gpu_selftest.sh on the one-GPU builder box).  The ranks share devices, so
+    # the numbers of such a line mean nothing; it says "dry_run_shared_gpu": true.
+    share = os.environ.get("ZN_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     td = None
     if dist:
         import torch.distributed as td
-        td.init_process_group(backend="nccl", device_id=device)
+        backend = os.environ.get("ZN_BENCH_BACKEND", "nccl") if share else "nccl"
+        td.init_process_group(backend=backend, **({"device_id": device} if backend == "nccl" else {}))
 
     from zipnn_amd import _capi, codec
     lib = _capi.lib()
@@ -710,6 +716,8 @@ def main():
                                   "note": "events bracket the whole zn_compress_dev call: four kernels + one 8-byte length read-back"},
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},
         }
+        if share:
+            line["dry_run_shared_gpu"] = True
         line["device_under_load"] = device_state_under_load(lambda: [codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n_bytes, out=out, check=False) for _ in range(120)])
         line["rccl_ranks"] = rccl_ranks
         line["rank_ms_per_step"] = rank_ms          # every rank's own wall time per step (a straggler shows as max >> min); null without torch.distributed

@@ -12,6 +12,10 @@ print("visible GPUs:", torch.cuda.device_count())
 PY
 echo "== the multi-device tests (skip themselves below 2 GPUs) =="
 timeout 300 python -m pytest tests/test_gpu_parity.py -q -m gpu -k "multi_device_entries_with_the_tensor_resident_in_hbm or replicated_decode_over_rccl_between_two_gpus" 2>&1 | tail -3
+if [ "$(python -c 'import torch; print(torch.cuda.device_count())')" -lt "$N" ]; then
+  echo "== fewer GPUs than ranks: DRY RUN of bench.py, $N ranks sharing the visible GPU(s) over gloo (logic only, numbers mean nothing) =="
+  export ZN_BENCH_SHARE_GPU=1 ZN_BENCH_BACKEND=gloo
+fi
 echo "== bench.py, $N ranks, 0.25 GiB per rank =="
 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus "$N" --gib 0.25 --steps 10 --warmup 5 \
   --no-cpu-baseline --no-other-dtypes --no-plugin --layers 2 2>/dev/null | grep "^{" | python -c "
