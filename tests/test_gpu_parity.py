@@ -885,13 +885,17 @@ def test_bench_two_ranks_dry_run_sharing_this_gpu(lib):
     """bench.py's N > 1 logic — process group, barriers, max over ranks, per-rank times, the llama8b partition over ranks, rank 0's one line —
     executed with TWO ranks that share this box's GPU over gloo (ZN_BENCH_SHARE_GPU=1: RCCL refuses two ranks on one device).  The numbers of
     such a line mean nothing; that it comes out, exact, with both ranks' times on it, is the point."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, ZN_BENCH_SHARE_GPU="1", ZN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+    with socket.socket() as sk:                       # a port that is free right now
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--gib", "0.125", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-other-dtypes", "--no-plugin", "--layers", "1"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    if r.returncode != 0 and ("address already in use" in r.stderr.lower() or "eaddrinuse" in r.stderr.lower()):
+        pytest.skip("the rendezvous port was taken between the probe and the launch")
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["dry_run_shared_gpu"] is True and j["bit_exact_roundtrip"] is True
