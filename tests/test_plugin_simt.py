@@ -309,3 +309,26 @@ def test_corrupt_frame_header_in_a_file_reports_the_real_error(use_simt, tmp_pat
     open(out, "wb").write(blob)
     with pytest.raises(ValueError, match="Header should start with ZN"):
         load_file(out, device="cpu")
+
+
+def test_load_file_unmaps_the_file_on_a_helper_thread_and_reports_its_phases(use_simt, tmp_path):
+    """decode_file_on_device closes its mapping on a helper thread (munmap behind the multi-threaded upload costs 1.2 ms on a 256-CPU host); the thread is
+    joined by the next call at the latest, the file can be replaced right away, and `timings` splits decode_s into launch / views / wait / plain copies."""
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io
+    sd = {"w": (torch.randn(70000) * 0.02).to(torch.bfloat16), "ids": torch.arange(16, dtype=torch.int64)}
+    src = str(tmp_path / "m.safetensors"); save_file(sd, src, {"format": "pt"})
+    znn = safetensors_io.compress_safetensors_file(src)
+    tm = {}
+    out = safetensors_io.load_file(znn, device="cpu", timings=tm)
+    assert all(torch.equal(out[k], sd[k]) for k in sd)
+    for k in ("decode_launch_s", "decode_views_s", "decode_wait_s", "decode_plain_s", "read_s", "h2d_s", "decode_s"):
+        assert tm[k] >= 0.0
+    assert abs(tm["decode_launch_s"] + tm["decode_views_s"] + tm["decode_wait_s"] + tm["decode_plain_s"] - tm["decode_s"]) < 1e-6
+    pend = list(safetensors_io._PENDING_CLOSERS)
+    assert len(pend) == 1
+    os.replace(znn, znn + ".moved")                      # (nothing holds the path)
+    pend[0].join(10.0)
+    assert not pend[0].is_alive()
+    out2 = safetensors_io.load_file(znn + ".moved", device="cpu")       # joins and drops the previous call's helper
+    assert pend[0] not in safetensors_io._PENDING_CLOSERS and torch.equal(out2["w"], sd["w"])
