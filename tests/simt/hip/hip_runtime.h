@@ -239,6 +239,7 @@ static inline uint32_t zn_simt_perm(uint32_t a, uint32_t b, uint32_t sel) {
 // rendezvous of the wave.
 static inline void zn_simt_wave_barrier() { zn_simt::collective(0, nullptr); }
 #define __builtin_amdgcn_wave_barrier() zn_simt_wave_barrier()
+#define __builtin_amdgcn_fence(order, scope) ((void)0)      /* fibers switch at collectives only: every earlier store is visible */
 #define __builtin_nontemporal_load(p) (*(p))
 #define __builtin_nontemporal_store(v, p) (*(p) = (v))
 

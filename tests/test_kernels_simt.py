@@ -784,7 +784,12 @@ def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt
     assert cnt[4] == wide_chunks and cnt[5] == pending
     ks = simt_lib.last_kernels().split(";")
     name = "zn_k_decode_wide" if mode == 2 else "zn_k_decode_wide^2"
-    assert ks[0] == (name + "+tail" if nb % C and kind in ("bf16", "fp32") else name) and ks[1] == "zn_k_decode_fused^pending"
+    # without a partial chunk the fused kernel's `rest` instance is the only other launch (it decodes what neither takes with the generic path's own code);
+    # with one, the tail workgroups ride in the wide launch and the two generic kernels follow
+    if nb % C:
+        assert ks == [name + "+tail", "zn_k_decode_fused^pending", "zn_k_decode_planes", "zn_k_merge_planes"]
+    else:
+        assert ks == [name, "zn_k_decode_fused^rest"]
     if kind == "slowsync":
         assert cnt[6] > 0
     if pending == 0:
@@ -846,3 +851,35 @@ def test_wide_decoder_batches_and_corrupt_streams(simt_lib, wide_mode):
         simt_lib.decompress(bytes(body), 2, 1, 10, C, len(d))
     cnt = _tile_counters()
     assert cnt[5] >= 1
+
+
+def test_rest_instance_decodes_what_neither_kernel_takes_with_the_generic_code(simt_lib, wide_mode):
+    """Behind the wide kernel, in a call without partial chunks, zn_k_decode_fused^rest is the only other launch: a geometry neither kernel takes
+    (a chunk size that is not a multiple of 4 P rows) is decoded chunk by chunk by the generic path's device functions inside it — same bytes —, and a
+    malformed jump table is reported by that code exactly as the generic kernels would."""
+    ch = 3072
+    d = _gen2("bf16", 5 * ch, 12)
+    frame = O.compress_frame(HDR, d, 2, 1, 10, ch)
+    for mode in (2, 3):
+        wide_mode(mode)
+        _tile_counters()
+        assert bytes(simt_lib.decompress(frame[32:], 2, 1, 10, ch, len(d))) == d
+        cnt = _tile_counters()
+        assert cnt[4] == 0 and cnt[5] == 5                       # the wide kernel declined all five
+        assert simt_lib.last_kernels().split(";")[1:] == ["zn_k_decode_fused^rest"] and simt_lib.last_fused_chunks() == 0
+    wide_mode(0)
+    assert bytes(simt_lib.decompress(frame[32:], 2, 1, 10, ch, len(d))) == d
+    assert simt_lib.last_kernels() == "zn_k_decode_fused;zn_k_decode_planes;zn_k_merge_planes"
+    # a weights-like chunk whose jump table claims more than the block holds
+    d = _gen2("bf16", 2 * C, 9)
+    body = bytearray(O.compress_frame(HDR, d, 2, 1, 10, C)[32:])
+    K = 2; PK = 2 * K
+    cum = lambda p, c: int.from_bytes(body[PK + 8 * (p * K + c): PK + 8 * (p * K + c) + 8], "little")
+    blk = 9 * PK + cum(0, K - 1)                                  # plane 1 of chunk 0
+    hs = 1 + body[blk]
+    assert body[blk] < 128
+    body[blk + hs: blk + hs + 2] = (0xFFFF).to_bytes(2, "little")
+    for mode in (2, 0):
+        wide_mode(mode)
+        with pytest.raises(RuntimeError):
+            simt_lib.decompress(bytes(body), 2, 1, 10, C, len(d))

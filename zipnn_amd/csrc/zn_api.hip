@@ -375,10 +375,11 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_tails = (uint8_t*)w.buf[WS_PLANES] + tail_base * ZN_TAIL_SLOT;
     uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
-    zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
-                           d_tail_done, delta_of[q], wide, status_zeroed, stream);
+    // (behind the wide kernel, in launches without partial chunks, the fused kernel's rest instance also does the generic kernels' job)
+    const bool rest = zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
+                                             d_tail_done, delta_of[q], wide, status_zeroed, d_descs, stream);
     status_zeroed = true;
-    zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
+    if (!rest) zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
   }
   ZN_HIP(hipGetLastError());

@@ -48,6 +48,7 @@
 #include <atomic>
 #include "zn_huf_wave.hpp"
 #include "zn_decode_common.hpp"
+#include "zn_decode_rest.hpp"
 
 #define ZN_F_THREADS 256
 #ifndef ZN_F_RING_BYTES
@@ -839,11 +840,15 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
 #define ZN_F_XWAVES ZN_F_WAVES_PER_SIMD
 #endif
 static_assert(sizeof(ZnFusedLds) * ZN_F_WAVES_PER_SIMD <= 160u * 1024u, "ZnFusedLds: the LDS budget of ZN_F_WAVES_PER_SIMD workgroups per CU");
-template <int P, bool X>
+// REST (only behind the wide kernel, in calls without partial chunks): a chunk this kernel does not take is decoded right here by the generic
+// path's own device functions (zn_decode_rest.hpp: one wave per plane, then the merge) instead of being left to two more launches that would
+// return at once in nearly every call; `descs_rest` = the launch's plane descriptors (the generic kernels' workspace).
+template <int P, bool X, bool REST = false>
 __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                   uint32_t* __restrict__ status, uint32_t ntail,
-                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done, uint32_t only_pending) {
+                                                                  uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done, uint32_t only_pending,
+                                                                  ZnPlaneDesc* __restrict__ descs_rest) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
@@ -865,6 +870,15 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
   uint8_t* __restrict__ pdone = pdone_all + S.desc0;   // the same flag per (plane, chunk)
 // (status[1 + q], q = 0/1/2 for 1/2/4 planes: how many chunks of this launch are left to the generic kernels — they
 //  return at once when it is zero)
+// (REST: the chunk is decoded here and now by the generic path's code — its planes by waves 0 .. P-1, each on an LDS instance of its own laid over
+//  this kernel's tables, then the merge by the whole workgroup; the done flag stays 0: "not by the fused kernel")
+#define ZN_REST_CHUNK(c_) do { if constexpr (REST) { \
+    static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS"); \
+    __syncthreads(); \
+    if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one, segs, nseg, S.desc0 + (uint64_t)wave * g.K + (c_), descs_rest, status, nullptr, lane); \
+    __threadfence(); __syncthreads(); \
+    for (uint32_t sub_ = 0; sub_ < ZN_MERGE_SUB; sub_++) zn_merge_chunk_item<P>(one, segs, nseg, S.chunk0 + (c_), sub_, descs_rest, nullptr); \
+    __syncthreads(); } } while (0)
 #define ZN_SET_DONE(c_, v_) do { if (tid == 0) { done[c_] = (v_); if (!(v_)) atomicAdd(status + 1 + (P == 1 ? 0 : P == 2 ? 1 : 2), 1u); } if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;
   // behind the wide kernel (zn_decode_wide.hpp; one chunk per workgroup there and here): only the chunks it left pending
@@ -925,7 +939,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
     ZN_PT(21);  // wait for the slowest wave of the previous chunk
     const uint32_t what = zn_uniform(L.what[j]);          // (what comes out of LDS or HBM below is wave-uniform: scalar registers, scalar branches)
-    if (what == 0u) { ZN_SET_DONE(c, 0); continue; }
+    if (what == 0u) { ZN_REST_CHUNK(c); ZN_SET_DONE(c, 0); continue; }
     const int h = (int)what - 2;
     ZnFusedPlane pl[P];
     uint32_t more = 0;                          // further Huffman planes (bit p): decoded by extra passes, zero bytes in this one
@@ -958,7 +972,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       __syncthreads();                         // lut16 (aliasing ring[0]) is dead from here on
       ZN_PT(2);   // LUT fill
     }
-    if (bad) { ZN_SET_DONE(c, 0); continue; }   // malformed jump table: the generic path reports it
+    if (bad) { ZN_REST_CHUNK(c); ZN_SET_DONE(c, 0); continue; }   // malformed jump table: the generic path reports it
 
     // ---- per-wave: decode the stream tile by tile, flush rows ----
     const uint8_t* rawq[P];
@@ -995,7 +1009,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 #ifndef ZN_F_ONLY_HOT
     if (P >= 2 && __builtin_expect(more != 0u, 0)) {
       const int r2 = zn_fused_more_passes<P>(L, g, body, body_end, outq, j, more, seg ZN_PT_PASS);
-      if (r2 < 0) { ZN_SET_DONE(c, 0); continue; }   // a later plane this kernel does not take: the generic path redoes the chunk
+      if (r2 < 0) { ZN_REST_CHUNK(c); ZN_SET_DONE(c, 0); continue; }   // a later plane this kernel does not take: the generic path redoes the chunk
       ok = ok && r2 > 0;
     }
 #endif
@@ -1068,10 +1082,11 @@ extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
   return 0;
 }
 
-void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
+bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, hipStream_t stream) {
-  if (total_wg == 0) return;
+                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, hipStream_t stream) {
+  if (!(wide && ntail == 0 && !delta)) d_descs_rest = nullptr;      // the rest instance runs behind the wide kernel only, in launches without tail workgroups
+  if (total_wg == 0) return false;
   const uint32_t only_pending = wide ? 1u : 0u;
   if (wide) {
     // small inputs: one 16-wave workgroup per chunk first; the fused kernel behind it takes what that one left pending (and the tails)
@@ -1084,9 +1099,11 @@ void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
     ntail = 0;                                   // (done: the launch below has none)
   }
   total_wg += ntail;                             // the tail workgroups come first
-#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, only_pending)
-  if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
-  else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
+#define ZN_GO(P_, X_, R_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_, R_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, only_pending, d_descs_rest)
+  if (d_descs_rest) { if (P == 1) ZN_GO(1, false, true); else if (P == 2) ZN_GO(2, false, true); else ZN_GO(4, false, true); }
+  else if (!delta) { if (P == 1) ZN_GO(1, false, false); else if (P == 2) ZN_GO(2, false, false); else ZN_GO(4, false, false); }
+  else { if (P == 1) ZN_GO(1, true, false); else if (P == 2) ZN_GO(2, true, false); else ZN_GO(4, true, false); }
 #undef ZN_GO
-  zn_note_kernel(wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
+  zn_note_kernel(d_descs_rest ? "zn_k_decode_fused^rest" : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
+  return d_descs_rest != nullptr;
 }

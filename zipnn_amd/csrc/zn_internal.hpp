@@ -42,11 +42,13 @@ uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a te
 // ntail: Huffman planes of partial last chunks are decoded by `ntail` extra workgroups at the front of the grid (the
 // parallel stream decoder on ragged streams) into padded scratch slots (ZN_TAIL_SLOT bytes per plane);
 // tail_done[i] = 1 where that worked — the generic kernels take it from there.
-void zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
+bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
+                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
 // wide = 4 / 2 (waves per stream): the launch's segments have ncg == 1 and zn_k_decode_wide (zn_decode_wide.hpp, small inputs) goes first;
-// !status_zeroed: … and zeroes the status words (the call's first launch: the caller then leaves out its memset)
+// !status_zeroed: … and zeroes the status words (the call's first launch: the caller then leaves out its memset);
+// d_descs_rest (used when wide, no tails, no delta): the fused kernel's `rest` instance decodes what it does not take with the generic
+// path's own code (zn_decode_rest.hpp) — returns true then, and the caller leaves out zn_launch_decode_generic
 int zn_decode_use_wide(uint64_t total_full_chunks, bool delta, bool weights_like);     // weights_like: every tensor of the call is split with the sign rotate (bf16 / fp32)
 
 // ---- encode ----
