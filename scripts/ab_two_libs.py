@@ -5,7 +5,7 @@ from ab_variants import load
 names=sys.argv[1:]
 libs=[(n, load(os.path.join(ROOT,"zipnn_amd",f"libzipnn_hip_ab_{n}.so"))) for n in names]
 st = torch.cuda.current_stream().cuda_stream
-for mib in (16, 64, 128, 1024, 4096):
+for mib in [int(x) for x in os.environ.get("ZN_AB_SIZES", "16,64,128,1024,4096").split(",")]:
     n = mib<<20
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     x = torch.empty(n//2, dtype=torch.bfloat16, device="cuda")

@@ -151,7 +151,7 @@ def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, reques
             full = nb // C
             want = {0: "zn_k_decode_fused", 2: "zn_k_decode_wide", 3: "zn_k_decode_wide^2",
                     1: "zn_k_decode_fused" if rot != 1 or nb % C or full > 2 * cus else "zn_k_decode_wide" if full <= cus else "zn_k_decode_wide^2"}[mode]     # (automatic: sign-rotated layouts, whole chunks)
-            assert used.split("+")[0] == want, (used, mode, K)
+            assert used.split("+")[0].replace("^rest", "") == want, (used, mode, K)       # (a call of whole chunks: the fused kernel's rest instance, no generic launches)
             assert lib.last_fused_chunks() >= (nb // C if kind in ("bf16", "fp32", "fp16", "fp8", "slowsync") else 0)
 
 

@@ -840,7 +840,7 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
 #define ZN_F_XWAVES ZN_F_WAVES_PER_SIMD
 #endif
 static_assert(sizeof(ZnFusedLds) * ZN_F_WAVES_PER_SIMD <= 160u * 1024u, "ZnFusedLds: the LDS budget of ZN_F_WAVES_PER_SIMD workgroups per CU");
-// REST (only behind the wide kernel, in calls without partial chunks): a chunk this kernel does not take is decoded right here by the generic
+// REST (launches without partial chunks and delta bases): a chunk this kernel does not take is decoded right here by the generic
 // path's own device functions (zn_decode_rest.hpp: one wave per plane, then the merge) instead of being left to two more launches that would
 // return at once in nearly every call; `descs_rest` = the launch's plane descriptors (the generic kernels' workspace).
 template <int P, bool X, bool REST = false>
@@ -1085,7 +1085,9 @@ extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
 bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
                             uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, hipStream_t stream) {
-  if (!(wide && ntail == 0 && !delta)) d_descs_rest = nullptr;      // the rest instance runs behind the wide kernel only, in launches without tail workgroups
+  // the rest instance: every launch without tail workgroups and delta bases (its tile loops run as fast as the plain instance's — measured, 160 MiB .. 4 GiB —
+  // and the two generic launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9)
+  if (!(ntail == 0 && !delta)) d_descs_rest = nullptr;
   if (total_wg == 0) return false;
   const uint32_t only_pending = wide ? 1u : 0u;
   if (wide) {

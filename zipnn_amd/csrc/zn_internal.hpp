@@ -47,7 +47,7 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
                             uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
 // wide = 4 / 2 (waves per stream): the launch's segments have ncg == 1 and zn_k_decode_wide (zn_decode_wide.hpp, small inputs) goes first;
 // !status_zeroed: … and zeroes the status words (the call's first launch: the caller then leaves out its memset);
-// d_descs_rest (used when wide, no tails, no delta): the fused kernel's `rest` instance decodes what it does not take with the generic
+// d_descs_rest (used when the launch has no tail workgroups and no delta base): the fused kernel's `rest` instance decodes what it does not take with the generic
 // path's own code (zn_decode_rest.hpp) — returns true then, and the caller leaves out zn_launch_decode_generic
 int zn_decode_use_wide(uint64_t total_full_chunks, bool delta, bool weights_like);     // weights_like: every tensor of the call is split with the sign rotate (bf16 / fp32)
 
