@@ -204,12 +204,13 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   if ((rc = ws_reserve(w, WS_META_C, pc_all * sizeof(uint64_t)))) return rc;   // payload offsets
   if ((rc = ws_reserve(w, WS_DESC, pc_all * sizeof(ZnEncDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
-  if ((rc = ws_reserve(w, WS_TOTALS, count * sizeof(uint64_t)))) return rc;
+  // (one slot more than there are tensors: the call's status word rides behind the body lengths, so that both come back in ONE copy)
+  if ((rc = ws_reserve(w, WS_TOTALS, (count + 1) * sizeof(uint64_t)))) return rc;
   if ((rc = ws_host_words(w))) return rc;
-  if (w.h_totals_cap < count) {
+  if (w.h_totals_cap < count + 1) {
     if (w.h_totals) { ZN_HIP(hipHostFree(w.h_totals)); w.h_totals = nullptr; w.h_totals_cap = 0; }
-    ZN_HIP(hipHostMalloc((void**)&w.h_totals, count * sizeof(uint64_t), hipHostMallocDefault));
-    w.h_totals_cap = count;
+    ZN_HIP(hipHostMalloc((void**)&w.h_totals, (count + 1) * sizeof(uint64_t), hipHostMallocDefault));
+    w.h_totals_cap = count + 1;
   }
   if (table) {
     if ((rc = ws_reserve(w, WS_SEGS, nseg_all * sizeof(ZnESeg)))) return rc;
@@ -222,9 +223,9 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   }
   if ((rc = ws_acquire(w, stream))) return rc;
   uint64_t* d_totals = (uint64_t*)w.buf[WS_TOTALS];
-  uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
+  uint32_t* d_status = (uint32_t*)(d_totals + count);
   uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
-  ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream));
+  bool status_zeroed = false;                    // (by the first table kernel of the call; a memset only when none is launched)
   if (table) {
     ZN_HIP(hipEventSynchronize(w.busy));         // the previous batched call may still be reading the pinned staging
     ZnESeg* hs = (ZnESeg*)w.h_segs; size_t o = 0;
@@ -234,6 +235,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   size_t seg_base = 0;
   for (int stage = 0; stage < 3; stage++) {      // stats (fused + generic) for every plane count, then the scans, then emit / gather
     seg_base = 0;
+    if (stage == 1 && !status_zeroed) { ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream)); status_zeroed = true; }
     for (int q = 0; q < 3; q++) {
       if (segs[q].empty()) continue;
       const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
@@ -241,8 +243,8 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
       const uint32_t nseg = (uint32_t)segs[q].size();
       const ZnESeg& one = segs[q][0];
       if (stage == 0) {
-        zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES], slot,
-                                     d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], stream);
+        if (zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES], slot,
+                                         d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], status_zeroed ? nullptr : d_status, stream)) status_zeroed = true;
       } else if (stage == 1) {
         zn_launch_scan_sizes(one, d_segs, nseg, (uint32_t)scan_of[q], d_csize, d_type, d_offs, d_totals, stream);
       } else {
@@ -253,12 +255,11 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
     }
   }
   ZN_HIP(hipGetLastError());
-  ZN_HIP(hipMemcpyAsync(w.h_totals, d_totals, count * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-  ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  ZN_HIP(hipMemcpyAsync(w.h_totals, d_totals, (count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));     // body lengths + the status word
   if ((rc = ws_release(w, stream))) return rc;
   ZN_HIP(hipStreamSynchronize(stream));
   for (size_t i = 0; i < count; i++) items[i].body_len = (size_t)w.h_totals[i];
-  if (*w.h_status) return ZN_E_CORRUPT;   // internal consistency check of the encoder failed
+  if ((uint32_t)w.h_totals[count]) return ZN_E_CORRUPT;   // internal consistency check of the encoder failed
   return ZN_OK;
 }
 

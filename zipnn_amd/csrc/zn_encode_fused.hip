@@ -310,8 +310,10 @@ struct ZnTablesLds {
 
 __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                          uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
-                                                         ZnEncDesc* __restrict__ descs_all, uint32_t njobs) {
+                                                         ZnEncDesc* __restrict__ descs_all, uint32_t njobs, uint32_t* __restrict__ status_zero) {
   __shared__ ZnTablesLds L;
+  // (the call's status word — set by the emit kernels, behind this launch — starts at zero: one memset node less in front of every compress call)
+  if (status_zero && blockIdx.x == 0 && threadIdx.x == 0) *status_zero = 0;
   const bool ragged = blockIdx.x >= njobs;       // the jobs of the ragged planes come behind those of the full chunks
   const ZnESeg S = ragged ? zn_efind_ptail(one, segs, nseg, blockIdx.x - njobs) : zn_efind_job(one, segs, nseg, blockIdx.x);
   const ZnGeom g = S.g; const uint64_t nfull = S.nfull; const float threshold = S.threshold;
@@ -778,10 +780,10 @@ bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr) {
   return (g.chunk % 16384ull) == 0 && (g.chunk % (8192ull * g.P)) == 0 && n <= ZN_HUF_BLOCK_MAX && ((((uint64_t)d_src) & 15u) == 0);
 }
 
-void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
+bool zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
                                   uint32_t total_ptails, uint8_t* d_planes, uint64_t slot,
-                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream) {
-  if (total_chunks + total_ptails == 0) return;
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, uint32_t* d_status_zero, hipStream_t stream) {
+  if (total_chunks + total_ptails == 0) return false;
   // (the ragged planes — total_ptails of them — are further workgroups of the same launches, behind the full chunks / their table jobs)
 #define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_stats<P_, X_>), dim3(total_chunks + 4u * total_ptails), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, total_chunks, d_planes, slot)
   // (the table kernel is serial-latency bound — ≈65 µs per job, ≈5 600 jobs on the chip at once, 0.21 ms for the 16 384 chunks of
@@ -792,8 +794,9 @@ void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs
   else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO
   zn_note_kernel(delta ? (total_ptails ? "zn_k_encode_stats^delta+tail" : "zn_k_encode_stats^delta") : (total_ptails ? "zn_k_encode_stats+tail" : "zn_k_encode_stats"));
-  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs + total_ptails), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, total_jobs);
+  hipLaunchKernelGGL(zn_k_encode_tables, dim3(total_jobs + total_ptails), dim3(64), 0, stream, one, d_segs, nseg, d_csize, d_type, d_descs, total_jobs, d_status_zero);
   zn_note_kernel("zn_k_encode_tables");
+  return true;                                   // (the table kernel has zeroed *d_status_zero)
 }
 
 void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_ptails,

@@ -87,9 +87,10 @@ struct ZnESeg {
 bool zn_encode_fused_ok(const ZnGeom& g, const void* d_src, const void* d_xr);    // d_xr: delta base or null
 // total_ptails ragged planes (partial last chunks, geometries the fused kernels do not take) ride along as further workgroups of the same
 // launches; d_planes / slot: their scratch planes (slot0 of a segment = its first slot)
-void zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
+// d_status_zero (may be null): the call's status word, zeroed by the table kernel; returns whether that kernel was launched
+bool zn_launch_encode_fused_stats(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_jobs,
                                   uint32_t total_ptails, uint8_t* d_planes, uint64_t slot,
-                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, hipStream_t stream);
+                                  uint32_t* d_csize, uint8_t* d_type, ZnEncDesc* d_descs, bool delta, uint32_t* d_status_zero, hipStream_t stream);
 void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t total_ptails,
                                  const uint8_t* d_planes, uint64_t slot,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
