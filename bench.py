@@ -94,6 +94,21 @@ def device_state_under_load(burst):
     try:
         burst()
         time.sleep(0.06)
+        best = _busiest_gpu_state(glob)
+        if best is not None:
+            time.sleep(0.10)                 # a second look 160 ms in: a box that throttles under sustained load shows it here
+            late = _busiest_gpu_state(glob)
+            if late is not None:
+                best["sclk_MHz_late"], best["power_W_late"] = late["sclk_MHz"], late["power_W"]
+        torch.cuda.synchronize()
+        return best
+    except Exception:       # noqa: BLE001 — a diagnostic, never a reason to fail the bench
+        torch.cuda.synchronize()
+        return None
+
+
+def _busiest_gpu_state(glob):
+    if True:
         best = None
         for hw in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
             def rd(name):
@@ -107,11 +122,7 @@ def device_state_under_load(burst):
                 p, cap, mclk, t = rd("power1_input"), rd("power1_cap"), rd("freq2_input"), rd("temp2_input")
                 best = {"sclk_MHz": round(sclk / 1e6), "mclk_MHz": None if mclk is None else round(mclk / 1e6), "power_W": None if p is None else round(p / 1e6),
                         "power_cap_W": None if cap is None else round(cap / 1e6), "temp_C": None if t is None else round(t / 1e3)}
-        torch.cuda.synchronize()
         return best
-    except Exception:       # noqa: BLE001 — a diagnostic, never a reason to fail the bench
-        torch.cuda.synchronize()
-        return None
 
 
 def rank_spread(td, device, my_ms, world):
