@@ -91,7 +91,10 @@ int zn_compress_dev(const void* d_src, size_t n, int num_buf, int bits_mode, int
 
 /* d_body: body_len bytes on the current device; d_dst receives orig_size bytes.
  * Asynchronous on `stream` unless `check` is non-zero, in which case the call
- * synchronises and returns ZN_E_CORRUPT / ZN_E_TYPE if a kernel flagged bad input. */
+ * synchronises and returns ZN_E_CORRUPT / ZN_E_TYPE if a kernel flagged bad input.
+ * Streams: calls on one stream are ordered by it; once a device has seen calls on more than one stream, every call records an event that the
+ * next one waits for on the device (the library's per-device workspace is shared).  Destroy a stream only after the asynchronous calls issued
+ * on it have finished (synchronise it, or ask zn_decode_status, first). */
 int zn_decompress_dev(const void* d_body, size_t body_len, int num_buf, int bits_mode,
                       int bytes_mode, size_t chunk, size_t orig_size, void* d_dst, void* stream,
                       int check);

@@ -105,6 +105,43 @@ def test_two_streams_share_the_device_workspace_safely(lib):
     assert torch.equal(oa, da) and torch.equal(ob, db)
 
 
+def test_workspace_order_between_streams_runs_of_calls_and_a_destroyed_stream(lib):
+    """As long as a device has seen one stream the workspace records no event (the stream orders the calls); the first call on a second stream synchronises
+    the device and switches to an event per call.  Runs of asynchronous calls on three streams, whole-chunk tensors (the small-input kernel) and ragged
+    ones; then a raw HIP stream that is used, synchronised and destroyed before the next call comes on another stream — the library never touches a stream
+    handle after the call it came with."""
+    import ctypes
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    specs = [("bf16", 32 * C, 2, 1, 10), ("fp32", 16 * C + 4, 4, 1, 220), ("bf16", 3 * C + 1000, 2, 1, 10), ("fp8", 9 * C, 1, 0, 10)]
+    data = [torch.frombuffer(bytearray(gen_bytes(k, nb, 7 + i)), dtype=torch.uint8).to(dev) for i, (k, nb, *_r) in enumerate(specs)]
+    bodies = [codec.compress_device(lib, d, P, rot, bm, C, 0.95).clone() for d, (_k, _n, P, rot, bm) in zip(data, specs)]
+    outs = [torch.zeros_like(d) for d in data]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    r = np.random.default_rng(5)
+    for _ in range(40):
+        s = streams[int(r.integers(3))]
+        with torch.cuda.stream(s):
+            for _k in range(int(r.integers(1, 5))):                  # a run of calls on this stream
+                i = int(r.integers(len(specs)))
+                _kind, nb, P, rot, bm = specs[i]
+                codec.decompress_device(lib, bodies[i], P, rot, bm, C, nb, out=outs[i], check=False)
+    torch.cuda.synchronize()
+    for o, d in zip(outs, data):
+        assert torch.equal(o, d)
+    hip = ctypes.CDLL("libamdhip64.so")
+    raw = ctypes.c_void_p()
+    assert hip.hipStreamCreate(ctypes.byref(raw)) == 0
+    outs[0].zero_()
+    lib.decompress_dev(bodies[0].data_ptr(), bodies[0].numel(), 2, 1, 10, C, specs[0][1], outs[0].data_ptr(), stream=raw.value, check=False)
+    assert hip.hipStreamSynchronize(raw) == 0 and hip.hipStreamDestroy(raw) == 0
+    assert torch.equal(outs[0], data[0])
+    outs[1].zero_()
+    codec.decompress_device(lib, bodies[1], 4, 1, 220, C, specs[1][1], out=outs[1], check=True)      # the previous stream no longer exists
+    assert torch.equal(outs[1], data[1])
+
+
 @pytest.mark.parametrize("group", [1, 2, 3, 4])
 def test_fused_decode_chunk_groups(lib, group, decode_group, request):
     """Workgroups decode `group` consecutive chunks; mixed Huffman / raw / RLE / two-Huffman-plane chunks, short last group."""

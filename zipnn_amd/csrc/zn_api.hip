@@ -40,7 +40,8 @@ struct Workspace {
   uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;   // pinned: body lengths of a batched compress
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
   uint32_t* h_status = nullptr;
-  hipEvent_t busy = nullptr;     // recorded after the last launch that touches the workspace
+  hipEvent_t busy = nullptr;     // orders the workspace between streams (ws_acquire / ws_release)
+  hipStream_t only_stream = nullptr; bool have_stream = false, multi = false;   // one stream so far (its handle is only ever COMPARED) / several: an event per call
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
   ZnHostPipe pipe2;              // a second one: the pipelined host path downloads slice i - 1 while it uploads slice i + 1
   hipStream_t cstream = nullptr; // … and codes slice i on a stream of its own
@@ -80,14 +81,26 @@ int ws_host_words(Workspace& w) {
   return ZN_OK;
 }
 
-// The workspace is shared by every call on the device.  Host-side the mutex serialises them; device-side a
-// call on another stream must not start before the previous call's kernels are done with the buffers.
+// The workspace is shared by every call on the device.  Host-side the mutex serialises them; device-side a call on another stream must not
+// start before the previous call's kernels are done with the buffers: an event recorded behind every call, waited for by the next.  That
+// record costs 3.5-6 us of a 60-120 us decode call (measured), and calls that follow each other on ONE stream are ordered by the stream itself:
+// as long as the device's workspace has only ever seen one stream, nothing is recorded (`mark` excepted: a batched call's pinned segment table
+// is rewritten from the HOST by the next batched call, which waits for the event).  The first call on a second stream synchronises the device
+// once and switches the workspace to event-per-call for good.  (No stream handle is ever used after the call it came with: the caller may
+// have destroyed it — hipEventRecord on a destroyed stream crashes, tried.)
 int ws_acquire(Workspace& w, hipStream_t stream) {
-  if (!w.busy) { ZN_HIP(hipEventCreateWithFlags(&w.busy, hipEventDisableTiming)); return ZN_OK; }
+  if (!w.busy) ZN_HIP(hipEventCreateWithFlags(&w.busy, hipEventDisableTiming));
+  if (!w.multi) {
+    if (!w.have_stream || stream == w.only_stream) return ZN_OK;
+    ZN_HIP(hipDeviceSynchronize());              // a second stream: whatever the first one still holds of the workspace is over after this
+    w.multi = true;
+    return ZN_OK;
+  }
   ZN_HIP(hipStreamWaitEvent(stream, w.busy, 0));
   return ZN_OK;
 }
-int ws_release(Workspace& w, hipStream_t stream) {
+int ws_release(Workspace& w, hipStream_t stream, bool mark = false) {
+  if (!w.multi) { w.only_stream = stream; w.have_stream = true; if (!mark) return ZN_OK; }
   ZN_HIP(hipEventRecord(w.busy, stream));
   return ZN_OK;
 }
@@ -256,7 +269,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   }
   ZN_HIP(hipGetLastError());
   ZN_HIP(hipMemcpyAsync(w.h_totals, d_totals, (count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));     // body lengths + the status word
-  if ((rc = ws_release(w, stream))) return rc;
+  if ((rc = ws_release(w, stream, table))) return rc;
   ZN_HIP(hipStreamSynchronize(stream));
   for (size_t i = 0; i < count; i++) items[i].body_len = (size_t)w.h_totals[i];
   if ((uint32_t)w.h_totals[count]) return ZN_E_CORRUPT;   // internal consistency check of the encoder failed
@@ -385,7 +398,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   }
   ZN_HIP(hipGetLastError());
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-  if ((rc = ws_release(w, stream))) return rc;
+  if ((rc = ws_release(w, stream, table))) return rc;
   if (check) {
     ZN_HIP(hipStreamSynchronize(stream));
     const uint32_t st = *w.h_status;
@@ -1225,7 +1238,7 @@ int zn_release_workspace(void) {
     zn_host_pipe_release(w.pipe);
     zn_host_pipe_release(w.pipe2);
     if (w.cstream) { (void)hipStreamSynchronize(w.cstream); (void)hipStreamDestroy(w.cstream); w.cstream = nullptr; }
-    if (w.busy) { (void)hipEventSynchronize(w.busy); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
+    if (w.busy) { (void)hipDeviceSynchronize(); (void)hipEventDestroy(w.busy); w.busy = nullptr; w.have_stream = false; w.multi = false; }
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   return ZN_OK;
