@@ -303,7 +303,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if (count && !items) return ZN_E_ARG;
   std::vector<ZnSeg> segs[3];                    // by plane count: 1, 2, 4
   uint64_t pk_of[3] = {0, 0, 0}, k_of[3] = {0, 0, 0}; uint64_t wg_of[3] = {0, 0, 0}, tail_of[3] = {0, 0, 0};
-  bool delta_of[3] = {false, false, false};
+  bool delta_of[3] = {false, false, false}, rest_ok[3] = {true, true, true};
   uint64_t total_chunks = 0;
   bool any_delta = false;
   uint64_t full_chunks = 0; bool all_rotated = true;
@@ -330,6 +330,10 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     sg.body = (const uint8_t*)it.d_body; sg.body_len = it.body_len; sg.dst = (uint8_t*)it.d_dst;
     sg.xr = (const uint8_t*)it.d_delta;
     if (sg.xr) delta_of[q] = true;
+    // (a LARGE call in a geometry the fused kernel takes no chunk of — its rule: whole rows per stream, a 16-byte aligned destination — goes to the generic
+    //  KERNELS, which spread it over the whole chip with one wave per plane; the fused kernel's rest instance decodes the odd chunk, or the odd small tensor)
+    { const uint64_t unit = 64ull * (sg.g.P == 1 ? 16u : 8u);
+      if ((it.chunk % (4ull * sg.g.P * unit) != 0 || (((uintptr_t)it.d_dst) & 15u) != 0) && total_chunks > 1024u) rest_ok[q] = false; }
     sg.chunk0 = k_of[q]; sg.desc0 = pk_of[q]; sg.wg0 = (uint32_t)wg_of[q]; sg.ncg = ncg;
     sg.tail0 = (uint32_t)tail_of[q]; sg.has_tail = (it.orig_size % it.chunk) != 0 ? 1u : 0u;   // partial last chunk
     if (sg.has_tail) tail_of[q] += sg.g.P;
@@ -391,7 +395,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     // (behind the wide kernel, in launches without partial chunks, the fused kernel's rest instance also does the generic kernels' job)
     const bool rest = zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
-                                             d_tail_done, delta_of[q], wide, status_zeroed, d_descs, stream);
+                                             d_tail_done, delta_of[q], wide, status_zeroed, rest_ok[q] ? d_descs : nullptr, stream);
     status_zeroed = true;
     if (!rest) zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
