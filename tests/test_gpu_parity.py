@@ -397,11 +397,16 @@ def test_safetensors_file_through_hbm_batched_both_ways(lib, tmp_path):
                "w_fp16": (torch.randn(300, 1001, generator=g) * 0.02).half(),
                "w_fp32": torch.randn(513, 400, generator=g) * 0.02,
                "ids": torch.arange(1000), "tiny": torch.randn(3, generator=g).to(torch.bfloat16),
-               "w_fp8": (torch.randn(200, 3000, generator=g) * 0.02).to(torch.float8_e4m3fn)}
+               "w_fp8": (torch.randn(200, 3000, generator=g) * 0.02).to(torch.float8_e4m3fn),
+               "noise": torch.randint(0, 256, (40000,), generator=g, dtype=torch.uint8).view(torch.float16),     # does not shrink: stored as it is
+               "empty": torch.empty(0, 7, dtype=torch.bfloat16)}
     src = os.path.join(tmp_path, "m.safetensors")
     save_file(tensors, src, {"format": "pt"})
-    znn = safetensors_io.compress_safetensors_file(src, device="cuda:0")
+    znn = safetensors_io.compress_safetensors_file(src, device="cuda:0")          # one upload, one batched compress, one download (_compress_file_on_device)
     assert os.path.getsize(znn) < os.path.getsize(src)
+    per_tensor = safetensors_io.compress_safetensors_file(src, out_path=os.path.join(tmp_path, "p.znn.safetensors"), device="cuda:0", batched=False)
+    from test_plugin_simt import _same_safetensors_container
+    assert _same_safetensors_container(znn, per_tensor)                            # the same file as tensor by tensor
     assert "zn_k_encode_emit" in lib.last_kernels()
     loaded = safetensors_io.load_file(znn, device="cuda:0")
     for k, v in tensors.items():

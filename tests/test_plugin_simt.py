@@ -332,3 +332,30 @@ def test_load_file_unmaps_the_file_on_a_helper_thread_and_reports_its_phases(use
     assert not pend[0].is_alive()
     out2 = safetensors_io.load_file(znn + ".moved", device="cpu")       # joins and drops the previous call's helper
     assert pend[0] not in safetensors_io._PENDING_CLOSERS and torch.equal(out2["w"], sd["w"])
+
+
+def _same_safetensors_container(a, b):
+    """Two safetensors files with the same header (as JSON objects: safetensors writes the metadata map in hash order, which differs from run to run) and
+    the same data section."""
+    import json
+    da, db = open(a, "rb").read(), open(b, "rb").read()
+    na, nb = int.from_bytes(da[:8], "little"), int.from_bytes(db[:8], "little")
+    return json.loads(da[8:8 + na]) == json.loads(db[8:8 + nb]) and da[8 + na:] == db[8 + nb:]
+
+
+def test_file_compress_through_one_upload_one_batch_one_download_writes_the_same_file(use_simt, tmp_path):
+    """_compress_file_on_device (what compress_safetensors_file does for a cuda device: the data section up in one transfer, one batched compress into an
+    arena with a gap in front of every body, the arena down in one transfer, headers written into the gaps) produces byte for byte the file of the
+    per-tensor path — compressed tensors, a tensor that does not shrink, integers, an empty and a tiny one, the metadata list in the same order."""
+    from safetensors.torch import save_file
+    from zipnn_amd import safetensors_io
+    g = torch.Generator().manual_seed(3)
+    tensors = {"w_bf16": (torch.randn(70, 1000, generator=g) * 0.02).to(torch.bfloat16), "w_fp32": torch.randn(51, 400, generator=g) * 0.02,
+               "w_fp16": (torch.randn(30, 1001, generator=g) * 0.02).half(), "ids": torch.arange(100), "tiny": torch.randn(3, generator=g).to(torch.bfloat16),
+               "noise": torch.randint(0, 256, (4000,), generator=g, dtype=torch.uint8).view(torch.float16), "empty": torch.empty(0, 7, dtype=torch.bfloat16)}
+    src = str(tmp_path / "m.safetensors"); save_file(tensors, src, {"format": "pt", "who": "me"})
+    a = safetensors_io._compress_file_on_device(src, str(tmp_path / "a.znn.safetensors"), torch.device("cpu"), None)
+    b = safetensors_io.compress_safetensors_file(src, out_path=str(tmp_path / "b.znn.safetensors"), device="cpu")
+    assert _same_safetensors_container(a, b)
+    out = safetensors_io.load_file(a, device="cpu")
+    assert all(torch.equal(out[k].view(torch.uint8) if out[k].numel() else out[k], tensors[k].view(torch.uint8) if tensors[k].numel() else tensors[k]) for k in tensors)

@@ -167,10 +167,12 @@ def decompress_device_batch(lib, items, check=True, into=None):
     return outs
 
 
-def compress_device_batch(lib, items):
+def compress_device_batch(lib, items, gap=0, return_arena=False):
     """Many tensors, one launch per stage (zn_compress_batch_dev), one read-back of all lengths.
     items: iterable of (flat_uint8_device_tensor, num_buf, bits_mode, bytes_mode, chunk, threshold[, delta]).
-    Returns the list of body tensors (uint8, same device; slices of one arena)."""
+    Returns the list of body tensors (uint8, same device; slices of one arena).
+    gap: bytes left free in FRONT of every body (a multiple of 256: the bodies stay 256-byte aligned) — room for the frame header when the arena goes
+    to the host in one piece; return_arena: -> (arena, [offset of each body in it], [body lengths]) instead of the slices."""
     items = list(items)
     deltas = [(it[6].contiguous() if len(it) > 6 and it[6] is not None else None) for it in items]
     items = [(it[0].contiguous(),) + tuple(it[1:6]) for it in items]
@@ -181,8 +183,11 @@ def compress_device_batch(lib, items):
             raise ValueError("delta base must be a uint8 tensor of the same length on the same device")
     dev = items[0][0].device
     caps = [max(lib.compress_bound(f.numel(), nb, ch, 0), 16) for (f, nb, _, _, ch, _) in items]
+    if gap % 256:
+        raise ValueError("gap must be a multiple of 256")
     offs, o = [], 0
     for c in caps:
+        o += gap
         offs.append(o); o += (c + 255) // 256 * 256
     arena = torch.empty(max(o, 16), dtype=torch.uint8, device=dev)
     base = arena.data_ptr()
@@ -190,4 +195,6 @@ def compress_device_batch(lib, items):
         lens = lib.compress_batch_dev(((f.data_ptr() if f.numel() else 0, f.numel(), nb, bi, by, ch, th, base + b0, c,
                                         d.data_ptr() if (d is not None and f.numel()) else None)
                                        for (f, nb, bi, by, ch, th), c, b0, d in zip(items, caps, offs, deltas)), _stream_handle(arena))
+    if return_arena:
+        return arena, offs, lens
     return [arena[b0:b0 + n] for b0, n in zip(offs, lens)]
