@@ -14,10 +14,16 @@ template <int KEY>
 __device__ __forceinline__ uint64_t zn_seg_key(const ZnSeg& s) { return KEY == 0 ? (uint64_t)s.wg0 : KEY == 1 ? s.desc0 : KEY == 2 ? s.chunk0 : (uint64_t)s.tail0; }
 template <int KEY>
 __device__ __forceinline__ ZnSeg zn_find_seg(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b) {
-  if (segs == nullptr) return one;
-  uint32_t lo = 0, hi = nseg;                 // invariant: key(lo) ≤ b, key(hi) > b (hi == nseg: past the end)
-  while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (zn_seg_key<KEY>(segs[mid]) <= b) lo = mid; else hi = mid; }
-  return segs[lo];
+  // (a struct VALUE that is overwritten, not a choice between two struct ADDRESSES: returning `one` or `segs[lo]` made the compiler keep the
+  //  by-value kernel argument in private memory — every thread of every workgroup wrote its 96 bytes to scratch and read them back: 24 KB per
+  //  workgroup of the fused kernel, 96 KB per workgroup of the wide one, +37 % HBM writes on a 64 MiB decode; profiles/r04_decode_experiments.txt)
+  ZnSeg r = one;
+  if (segs != nullptr) {
+    uint32_t lo = 0, hi = nseg;               // invariant: key(lo) ≤ b, key(hi) > b (hi == nseg: past the end)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (zn_seg_key<KEY>(segs[mid]) <= b) lo = mid; else hi = mid; }
+    r = segs[lo];
+  }
+  return r;
 }
 
 // ---------------------------------------------------------------------------

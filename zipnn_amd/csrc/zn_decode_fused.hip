@@ -853,7 +853,10 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
-  if (blockIdx.x < ntail) { zn_decode_tail_wg(L, one, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return; }
+  // (`one` goes to the real functions of the cold paths — the tail workgroups, the rest instance's generic code — as a COPY made on that path: with its own
+  //  address escaping, the by-value kernel argument lived in private memory and EVERY thread of EVERY workgroup stored its 96 bytes to scratch in the prologue and
+  //  loaded them back — 24 KB of HBM writes per workgroup, 2.4 % of the kernel's writes at 4 GiB, 11 % at 64 MiB; profiles/r04_decode_experiments.txt)
+  if (blockIdx.x < ntail) { const ZnSeg one_c = one; zn_decode_tail_wg(L, one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return; }
   const uint32_t wg = blockIdx.x - ntail;      // workgroup index among the full-chunk groups
   // (the segment comes back through private memory — a kernel argument or a table entry, chosen at run time — which makes
   //  every field per-lane data to the compiler: 64-bit pointers in vector registers, spilled and reloaded once per chunk,
@@ -875,9 +878,10 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 #define ZN_REST_CHUNK(c_) do { if constexpr (REST) { \
     static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS"); \
     __syncthreads(); \
-    if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one, segs, nseg, S.desc0 + (uint64_t)wave * g.K + (c_), descs_rest, status, nullptr, lane); \
+    const ZnSeg one_c_ = one; \
+    if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c_, segs, nseg, S.desc0 + (uint64_t)wave * g.K + (c_), descs_rest, status, nullptr, lane); \
     __threadfence(); __syncthreads(); \
-    for (uint32_t sub_ = 0; sub_ < ZN_MERGE_SUB; sub_++) zn_merge_chunk_item<P>(one, segs, nseg, S.chunk0 + (c_), sub_, descs_rest, nullptr); \
+    for (uint32_t sub_ = 0; sub_ < ZN_MERGE_SUB; sub_++) zn_merge_chunk_item<P>(one_c_, segs, nseg, S.chunk0 + (c_), sub_, descs_rest, nullptr); \
     __syncthreads(); } } while (0)
 #define ZN_SET_DONE(c_, v_) do { if (tid == 0) { done[c_] = (v_); if (!(v_)) atomicAdd(status + 1 + (P == 1 ? 0 : P == 2 ? 1 : 2), 1u); } if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + (c_)] = (v_); } while (0)
   const uint32_t ncg = S.ncg;

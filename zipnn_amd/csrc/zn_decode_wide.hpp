@@ -315,7 +315,8 @@ __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, cons
   // they run beside the full chunks and not behind them
   if (blockIdx.x < ntail) {
     if (threadIdx.x >= ZN_F_THREADS) return;
-    zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one, segs, nseg, blockIdx.x, tail_scratch, tail_done, status);
+    const ZnSeg one_c = one;                       // (a copy on this path only: see zn_k_decode_fused)
+    zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status);
     return;
   }
   const uint32_t wg = blockIdx.x - ntail;
