@@ -107,13 +107,10 @@ void zn_note_kernel(const char* name);
 // which tensor of a batched compress launch does grid index `b` belong to?  (last segment with key ≤ b; wave-uniform)
 #define ZN_DEF_EFIND(NAME, FIELD)                                                                                           \
   __device__ __forceinline__ ZnESeg NAME(const ZnESeg& one, const ZnESeg* __restrict__ segs, uint32_t nseg, uint64_t b) { \
-    ZnESeg r = one;      /* (a value that is overwritten, not a choice between two addresses: see zn_find_seg) */                \
-    if (segs != nullptr) {                                                                                                 \
-      uint32_t lo = 0, hi = nseg;                                                                                          \
-      while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)segs[mid].FIELD <= b) lo = mid; else hi = mid; } \
-      r = segs[lo];                                                                                                        \
-    }                                                                                                                      \
-    return r;                                                                                                              \
+    if (segs == nullptr) return one;                                                                                       \
+    uint32_t lo = 0, hi = nseg;                                                                                            \
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((uint64_t)segs[mid].FIELD <= b) lo = mid; else hi = mid; } \
+    return segs[lo];                                                                                                       \
   }
 ZN_DEF_EFIND(zn_efind_chunk, chunk0)
 ZN_DEF_EFIND(zn_efind_job, job0)
