@@ -206,11 +206,19 @@ typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 #define ZN_F_NT_LOADS 1
 #endif
 #if ZN_F_NT_LOADS && !defined(ZN_SIMT_EMULATOR)
+#define ZN_LD_RAW32(p) __builtin_nontemporal_load((const zn_u32u*)(p))
 #define ZN_LD_RAW64(p) __builtin_nontemporal_load((const zn_u64u*)(p))
 #define ZN_LD_STREAM32(p) __builtin_nontemporal_load((const uint32_t*)(p))
 #else
+#define ZN_LD_RAW32(p) (*(const zn_u32u*)(p))
 #define ZN_LD_RAW64(p) (*(const zn_u64u*)(p))
 #define ZN_LD_STREAM32(p) (*(const uint32_t*)(p))
+#endif
+// the four-plane rows' stores (ZN_F_SPLIT4): non-temporal unless ZN_F_SPLIT4_PLAIN
+#if defined(ZN_F_SPLIT4_PLAIN) || defined(ZN_SIMT_EMULATOR)
+#define ZN_ST128_4(p, a, b, c, d) (*(uint4*)(p) = make_uint4((a), (b), (c), (d)))
+#else
+#define ZN_ST128_4(p, a, b, c, d) ZN_ST128(p, a, b, c, d)
 #endif
 
 struct ZnFusedPlane { uint64_t off; uint32_t kind; uint32_t csize; };   // off: body offset (RAW/HUF) or byte value (RLE)
@@ -301,6 +309,13 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 #ifndef ZN_F_RB4
 #define ZN_F_RB4 2
 #endif
+  // Four planes: a lane's 8 symbols of a row are 32 output bytes = two 16-byte stores; as ONE run of 8 symbols each store instruction writes 16 bytes at a stride
+  // of 32 (half of every 32-byte sector).  ZN_F_SPLIT4: the lane owns two runs of 4 symbols, [4 lane, +4) and [256 + 4 lane, +4) of the row's 512, so that each
+  // store instruction writes 1 KB contiguous (whole sectors, whole lines) and can be non-temporal.
+#ifndef ZN_F_SPLIT4
+#define ZN_F_SPLIT4 1
+#endif
+  constexpr bool SPLIT = (P == 4) && (ZN_F_SPLIT4 != 0);
   // (two planes: 4 rows per batch, a tile's ~6 rows in two batches.  8 rows — one batch — keeps 16 more registers in flight
   //  through the compaction; every build of that variant spilled somewhere in the tile loop and ran between 1.61 and 2.2 ms
   //  on the 4 GiB config depending on where, 4 rows ran 1.60 ms three builds in a row; with the tile loop spill-free 3 rows
@@ -331,8 +346,13 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
       // (a wave-uniform base + a 32-bit lane offset: the compiler then addresses with a scalar base register and one vector
       //  offset instead of keeping — and spilling — a 64-bit pointer per lane and row)
       const uint8_t* au = rawq[p] + (first_row_sym + (uint32_t)r * UNIT);
-      const uint8_t* a = au + (uint32_t)EPL * lane_v;
-      for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
+      if constexpr (SPLIT) {
+        const uint8_t* a = au + 4u * lane_v;
+        pre[r][p][0] = ZN_LD_RAW32(a); pre[r][p][1 % EW] = ZN_LD_RAW32(a + UNIT / 2u);
+      } else {
+        const uint8_t* a = au + (uint32_t)EPL * lane_v;
+        for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(a + 8 * k); pre[r][p][2 * k] = (uint32_t)t; pre[r][p][2 * k + 1] = (uint32_t)(t >> 32); }
+      }
     }
   };
   auto fetch_row = [&](uint32_t first_row_sym, int r) { fetch_row_to(pre, first_row_sym, r); };
@@ -358,15 +378,19 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         const int r = grp * XG + i;
         for (int k = 0; k < XW; k++) xd[grp & 1][i][k] = 0;
         if (xq && r < RB && r < nrows) {
-          const uint8_t* a = xq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane) * P;
-          for (int k = 0; k < XW / 4; k++) { const uint4 t = *(const uint4*)(a + 16 * k); xd[grp & 1][i][4 * k] = t.x; xd[grp & 1][i][4 * k + 1] = t.y; xd[grp & 1][i][4 * k + 2] = t.z; xd[grp & 1][i][4 * k + 3] = t.w; }
+          const uint8_t* a = SPLIT ? xq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT) * P + 16u * lane
+                                   : xq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT + (uint32_t)EPL * lane) * P;
+          for (int k = 0; k < XW / 4; k++) { const uint4 t = *(const uint4*)(a + (SPLIT ? (UNIT / 2u) * P : 16u) * k); xd[grp & 1][i][4 * k] = t.x; xd[grp & 1][i][4 * k + 1] = t.y; xd[grp & 1][i][4 * k + 2] = t.z; xd[grp & 1][i][4 * k + 3] = t.w; }
         }
       }
     };
     if (X) load_delta(0);
     for (int r = 0; r < RB; r++) if (r < nrows) {
       for (int p = 0; p < P; p++) {
-        if (p == H) { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
+        if (p == H) {
+          if constexpr (SPLIT) { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT >> 2) + lane; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + (UNIT / 8u) * k]; ring[i + (UNIT / 8u) * k] = 0; } }
+          else { const uint32_t i = ((stage_row0 + (uint32_t)r) * UNIT + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[r][p][k] = ring[i + k]; ring[i + k] = 0; } }
+        }
         else if (pl[p].kind == ZN_KIND_RLE) { ZN_NO_IFCVT; for (int k = 0; k < EW; k++) pre[r][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }   // (a branch: as selects this cost every row two VALU ops)
       }
     }
@@ -383,7 +407,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     for (int r = 0; r < RB; r++) if (r < nrows) {
       if (X && r % XG == 0 && r + XG < RB) load_delta(r / XG + 1);
       const uint32_t* xr_ = xd[(r / XG) & 1][r % XG];
-      uint8_t* o = (outq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT) * P) + (uint32_t)EPL * lane_v * (uint32_t)P;   // (uniform base + lane offset)
+      uint8_t* o = (outq + (uint64_t)(first_row_sym + (uint32_t)r * UNIT) * P) + (SPLIT ? 16u : (uint32_t)EPL * (uint32_t)P) * lane_v;   // (uniform base + lane offset)
       if (P == 1) {
         if (X) ZN_ST128(o, pre[r][0][0] ^ xr_[0], pre[r][0][1 % EW] ^ xr_[1 % XW], pre[r][0][2 % EW] ^ xr_[2 % XW], pre[r][0][3 % EW] ^ xr_[3 % XW]);
         else ZN_ST128(o, pre[r][0][0], pre[r][0][1 % EW], pre[r][0][2 % EW], pre[r][0][3 % EW]);
@@ -402,7 +426,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           x[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u); x[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
           x[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u); x[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
           if (X) for (int k = 0; k < 4; k++) x[k] ^= xr_[(4 * half + k) % XW];
-          *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);   // (two half-line stores per lane: NOT non-temporal, the L2 merges them — nt cost 40 % here)
+          if constexpr (SPLIT) ZN_ST128_4(o + (UNIT / 2u) * P * half, x[0], x[1], x[2], x[3]);        // (1 KB contiguous per store instruction: whole sectors)
+          else *(uint4*)(o + 16 * half) = make_uint4(x[0], x[1], x[2], x[3]);   // (two half-line stores per lane: NOT non-temporal, the L2 merges them — nt cost 40 % here)
         }
       }
     }

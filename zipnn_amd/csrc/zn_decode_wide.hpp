@@ -56,6 +56,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g
                                               const uint8_t* js, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4) {
   constexpr int EPL = (P == 1) ? 16 : 8, EW = EPL / 4;
   constexpr uint32_t UNIT = 64u * EPL;
+  constexpr bool SPLIT = (P == 4) && (ZN_F_SPLIT4 != 0);      // four planes: a lane owns two runs of 4 symbols of a row (whole-sector stores; see zn_fused_wave)
   constexpr int RB = (P == 2) ? 8 : 4;      // rows of one flush batch: a wave's share of a round (the staging buffer holds ≤ 31 rows of 512 symbols, ≤ 15 of 1024) in one batch (two for 4 planes)
   constexpr int TF = ZN_F_TF(ZN_W_D), TB = 3, UF = (32 * ZN_W_D - 31) / 11;
   constexpr int32_t TD = ZN_W_TD;
@@ -230,8 +231,9 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g
         if (i < rows_total) {
           const uint32_t a = JF + i * UNIT;
           for (int p = 0; p < P; p++) if (p != H && pl[p].kind == ZN_KIND_RAW) {
-            const uint8_t* au = rawq[p] + a; const uint8_t* ap = au + (uint32_t)EPL * lane_v;
-            for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(ap + 8 * k); pre[rr][p][2 * k] = (uint32_t)t; pre[rr][p][2 * k + 1] = (uint32_t)(t >> 32); }
+            const uint8_t* au = rawq[p] + a;
+            if constexpr (SPLIT) { const uint8_t* ap = au + 4u * lane_v; pre[rr][p][0] = ZN_LD_RAW32(ap); pre[rr][p][1 % EW] = ZN_LD_RAW32(ap + UNIT / 2u); }
+            else { const uint8_t* ap = au + (uint32_t)EPL * lane_v; for (int k = 0; k < EW / 2; k++) { const uint64_t t = ZN_LD_RAW64(ap + 8 * k); pre[rr][p][2 * k] = (uint32_t)t; pre[rr][p][2 * k + 1] = (uint32_t)(t >> 32); } }
           }
         }
       }
@@ -259,8 +261,8 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g
           const uint32_t a = JF + i * UNIT, ra = a & (ZN_W_RING - 1u);
           for (int p = 0; p < P; p++) {
             if (p == H) {
-              const uint32_t ix = (ra + (uint32_t)EPL * lane) >> 2;
-              for (int k = 0; k < EW; k++) { pre[rr][p][k] = ring[ix + k]; ring[ix + k] = 0; }
+              if constexpr (SPLIT) { const uint32_t ix = (ra >> 2) + lane; for (int k = 0; k < EW; k++) { pre[rr][p][k] = ring[ix + (UNIT / 8u) * k]; ring[ix + (UNIT / 8u) * k] = 0; } }
+              else { const uint32_t ix = (ra + (uint32_t)EPL * lane) >> 2; for (int k = 0; k < EW; k++) { pre[rr][p][k] = ring[ix + k]; ring[ix + k] = 0; } }
               if (ra == 0u && lane == 0) { pre[rr][p][0] |= ring[ZN_W_RING / 4u]; ring[ZN_W_RING / 4u] = 0; }
             } else if (pl[p].kind == ZN_KIND_RLE) { for (int k = 0; k < EW; k++) pre[rr][p][k] = ((uint32_t)pl[p].off & 0xFFu) * 0x01010101u; }
           }
@@ -271,7 +273,7 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g
               pre[rr][(P >= 2) ? P - 2 : 0][k] = ZN_BFI(0x7F7F7F7Fu, lo, hi << 7);
             }
           }
-          uint8_t* o = (outq + (uint64_t)a * P) + (uint32_t)EPL * lane_v * (uint32_t)P;
+          uint8_t* o = (outq + (uint64_t)a * P) + (SPLIT ? 16u : (uint32_t)EPL * (uint32_t)P) * lane_v;
           if (P == 1) {
             ZN_ST128(o, pre[rr][0][0], pre[rr][0][1 % EW], pre[rr][0][2 % EW], pre[rr][0][3 % EW]);
           } else if (P == 2) {
@@ -283,8 +285,10 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g
               const int k = half % EW;
               const uint32_t ab_lo = __builtin_amdgcn_perm(pre[rr][1 % P][k], pre[rr][0][k], 0x05010400u), ab_hi = __builtin_amdgcn_perm(pre[rr][1 % P][k], pre[rr][0][k], 0x07030602u);
               const uint32_t cd_lo = __builtin_amdgcn_perm(pre[rr][3 % P][k], pre[rr][2 % P][k], 0x05010400u), cd_hi = __builtin_amdgcn_perm(pre[rr][3 % P][k], pre[rr][2 % P][k], 0x07030602u);
-              *(uint4*)(o + 16 * half) = make_uint4(__builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u), __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u),
-                                                    __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u), __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u));
+              const uint32_t y0 = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u), y1 = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);
+              const uint32_t y2 = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u), y3 = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+              if constexpr (SPLIT) ZN_ST128_4(o + (UNIT / 2u) * P * half, y0, y1, y2, y3);
+              else *(uint4*)(o + 16 * half) = make_uint4(y0, y1, y2, y3);
             }
           }
         }
