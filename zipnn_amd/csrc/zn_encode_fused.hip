@@ -501,13 +501,26 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
   uint32_t written = 0;        // stream bytes already stored
   // tiles from the END of the segment to its start: huff0 packs the last symbol first
   for (int32_t base = (int32_t)seg - ZN_E_TILE; base >= 0; base -= ZN_E_TILE) {
-    // this lane's 32 consecutive elements = 32·P source bytes
+    // this lane's 32 elements = 32·P source bytes.  ZN_E_SPLIT: TWO runs of 16 — elements [16 l, +16) of the tile's lower half (d[0 .. 4P)) and of its upper half
+    // (d[4P .. 8P)) — instead of one run of 32: a raw plane's 32 bytes per lane then leave as two 16-byte stores that each write 1 KB contiguous across the wave
+    // (whole 32-byte sectors); as one run, each non-temporal store wrote half of every sector (the emit kernel's 8 % write surplus: profiles/r04_decode_experiments.txt)
+#ifndef ZN_E_SPLIT
+#define ZN_E_SPLIT 1
+#endif
+    constexpr uint32_t RUN = ZN_E_SPLIT ? ZN_E_SPL / 2u : ZN_E_SPL;          // consecutive elements of a run
+    constexpr uint32_t HALF = ZN_E_SPLIT ? ZN_E_TILE / 2u : 0u;              // element distance between the lane's two runs
     uint32_t d[8 * P];
-    const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + ZN_E_SPL * lane);
-    for (int k = 0; k < 2 * P; k++) { const uint4 x = ZN_LD_EMIT(a + 16 * k); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w; }
+    const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + RUN * lane);
+    for (int k = 0; k < 2 * P; k++) {
+      const uint8_t* ak = ZN_E_SPLIT ? a + (k >= P ? (uint64_t)P * HALF + 16 * (k - P) : 16 * k) : a + 16 * k;
+      const uint4 x = ZN_LD_EMIT(ak); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w;
+    }
     if (X && chunk_xr) {
       const uint8_t* xa = chunk_xr + (a - chunk_src);
-      for (int k = 0; k < 2 * P; k++) { const uint4 x = ZN_LD_EMIT(xa + 16 * k); d[4 * k] ^= x.x; d[4 * k + 1] ^= x.y; d[4 * k + 2] ^= x.z; d[4 * k + 3] ^= x.w; }
+      for (int k = 0; k < 2 * P; k++) {
+        const uint8_t* xk = ZN_E_SPLIT ? xa + (k >= P ? (uint64_t)P * HALF + 16 * (k - P) : 16 * k) : xa + 16 * k;
+        const uint4 x = ZN_LD_EMIT(xk); d[4 * k] ^= x.x; d[4 * k + 1] ^= x.y; d[4 * k + 2] ^= x.z; d[4 * k + 3] ^= x.w;
+      }
     }
     for (int k = 0; k < 8 * P; k++) d[k] = zn_rot_fwd<P>(d[k], g.rot);
     // raw planes: 32 bytes per lane, contiguous across the wave
@@ -519,14 +532,15 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
           for (int t = 0; t < 4; t++) { const int e = 4 * j + t, k = P * e + p; v |= ((d[k >> 2] >> (8 * (k & 3))) & 0xFFu) << (8 * t); }
           o[j] = v;
         }
-        uint8_t* r = body + off[p] + (uint64_t)wave * seg + (uint32_t)base + ZN_E_SPL * lane;
+        uint8_t* r = body + off[p] + (uint64_t)wave * seg + (uint32_t)base + RUN * lane;
+        uint8_t* r2 = ZN_E_SPLIT ? r + HALF : r + 16;                  // (the second run's 16 bytes / the second half of the one run)
         zn_eu128u s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
 #if !defined(ZN_SIMT_EMULATOR)                  // non-temporal: the payload is written once and not read back here
         typedef uint32_t zn_ev4u_u __attribute__((ext_vector_type(4), aligned(1)));
         __builtin_nontemporal_store((zn_ev4u_u){o[0], o[1], o[2], o[3]}, (zn_ev4u_u*)r);
-        __builtin_nontemporal_store((zn_ev4u_u){o[4], o[5], o[6], o[7]}, (zn_ev4u_u*)(r + 16));
+        __builtin_nontemporal_store((zn_ev4u_u){o[4], o[5], o[6], o[7]}, (zn_ev4u_u*)r2);
 #else
-        *(zn_eu128u*)r = s0; *(zn_eu128u*)(r + 16) = s1;
+        *(zn_eu128u*)r = s0; *(zn_eu128u*)r2 = s1;
 #endif
       }
     }
@@ -551,15 +565,19 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
       qv[i] = ((uint64_t)pv[0] << pn[1]) | pv[1];
       qn[i] = pn[0] + pn[1];
     }
-    // bit offset of every quad inside the lane (quad 7 lowest), and the lane's total
-    uint32_t qo[8]; uint32_t T = 0;
-    for (int i = 7; i >= 0; i--) { qo[i] = T; T += qn[i]; }
-    // bit offset of this lane in the tile: lanes are packed from lane 63 down to lane 0
-    uint32_t total = 0;
+    // bit offset of every quad inside its run (the run's last quad lowest), and the run totals
+    uint32_t qo[8]; uint32_t T = 0, TB = 0;
+    if (ZN_E_SPLIT) { for (int i = 7; i >= 4; i--) { qo[i] = TB; TB += qn[i]; } for (int i = 3; i >= 0; i--) { qo[i] = T; T += qn[i]; } }
+    else for (int i = 7; i >= 0; i--) { qo[i] = T; T += qn[i]; }
+    // bit offset of this lane's run(s) in the tile: the stream is written backwards, so the tile's upper half comes first, and in a half the lanes are packed
+    // from lane 63 down to lane 0
+    uint32_t total = 0, totalB = 0, bB = 0;
+    if (ZN_E_SPLIT) { const uint32_t exclB = zn_wave_excl_scan_u32(TB, &totalB); bB = carry + (totalB - exclB - TB); }
     const uint32_t excl = zn_wave_excl_scan_u32(T, &total);
-    const uint32_t b = carry + (total - excl - T);
+    const uint32_t b = carry + totalB + (total - excl - T);
+    total += totalB;
     for (int i = 0; i < 8; i++) {
-      const uint32_t bp = b + qo[i], idx = bp >> 5, sh = bp & 31u;
+      const uint32_t bp = ((ZN_E_SPLIT && i >= 4) ? bB : b) + qo[i], idx = bp >> 5, sh = bp & 31u;
       const uint64_t lo = qv[i] << sh;                                  // bits 0-63 of the shifted quad
       const uint32_t w2 = (uint32_t)(((qv[i] >> 32) << sh) >> 32);      // bits 64-75 (quad < 2^44)
       atomicOr(&buf[idx], (uint32_t)lo);
