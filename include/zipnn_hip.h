@@ -185,27 +185,36 @@ int zn_merge_range_bodies(const void* const* bodies, const size_t* body_lens, co
 int zn_copy_to_device(void* d_dst, const void* src, size_t n);
 int zn_copy_to_host(void* dst, const void* d_src, size_t n);
 
-/* Tuning knob: chunks one workgroup of the fused decoder takes, 1..4; 0 (default) = automatic (4 when the tensor has enough chunks
- * to fill every workgroup slot of the device with groups, fewer for small tensors).  Process-wide.  Returns 0 or ZN_E_ARG. */
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * DEVELOPER / TEST KNOBS — not part of the drop-in boundary.  The four setters below are process-wide mutable state: they exist so that
+ * the test-suite and the A/B scripts can force every kernel form on every input (tests/, scripts/) and so that a frame can be made
+ * byte-identical to a PyPI wheel's; a production caller never needs them — every default is "automatic", and the bytes a call produces
+ * or accepts do not depend on the first three.  They are NOT synchronised with calls in flight: set them before the first call of a
+ * process (or between calls, from the one thread that drives the library) — never while another host thread is inside an entry point.
+ * One host thread per GPU, as the multi-device entry points use the library, is safe with the defaults.
+ * ------------------------------------------------------------------------------------------------------------------------- */
+
+/* chunks one workgroup of the fused decoder takes, 1..4; 0 (default) = automatic (4 when the tensor has enough chunks
+ * to fill every workgroup slot of the device with groups, fewer for small tensors).  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_group(int chunks_per_workgroup);
 
-/* Tuning knob: the small-input form of the decoder (one workgroup per chunk, four or two waves per huff0 stream) — 0 = never,
+/* the small-input form of the decoder (one workgroup per chunk, four or two waves per huff0 stream) — 0 = never,
  * 1 (default) = automatic: calls whose tensors are all split with the sign rotate (bits_mode 1 with 2 or 4 byte planes: bf16, fp32), are whole
- * multiples of their chunk size, have no delta base and at most one (16-wave form) or two (8-wave form) chunks per compute unit of the device; 2 / 3 = every call without a
- * delta base, 16- / 8-wave form.  The bytes produced are the same in every mode.  Process-wide.  Returns 0 or ZN_E_ARG. */
+ * multiples of their chunk size, have no delta base and few chunks per compute unit of the device; 2 / 3 = every call without a
+ * delta base, 16- / 8-wave form.  The bytes produced are the same in every mode.  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_wide(int mode);
 
-/* Tuning knob of the host-buffer entry points (zn_compress / zn_decompress): slices of the three-stage pipeline
- * upload | code | download that large pageable buffers can go through (both PCIe directions busy at once).  0 (default) = automatic
- * (compress: 4-8 slices from 192 MiB up; decompress: one shot — measured: no gain there), 1 = never, 2..64 = that many, both
- * directions.  Process-wide.  Returns 0 or ZN_E_ARG. */
+/* slices of the three-stage pipeline upload | code | download that large pageable buffers can go through in the host-buffer entry points
+ * (zn_compress / zn_decompress).  0 (default) = automatic (compress: 4-8 slices from 192 MiB up; decompress: one shot — measured: no gain
+ * there), 1 = never, 2..64 = that many, both directions.  Returns 0 or ZN_E_ARG. */
 int zn_set_host_slices(int slices);
 
 /* Which huff0 the compressed bytes imitate where the two in circulation differ — the FSE-coded tree description of a plane, when one
  * of its code-weight values is rare enough to round below one FSE cell: 0 (default) = zstd >= 1.4.7 (a full cell, "+1"; what the
  * reference writes when built against a current libzstd, oracle/_ref), 1 = the FiniteStateEntropy library the reference's PyPI wheels
  * bundle (/root/reference/setup.py:23-28; the "less than one" marker, "-1").  Every huff0 decoder — this library's included — reads both;
- * with 1 the frames are byte-identical to a wheel's.  Process-wide.  Returns 0 or ZN_E_ARG. */
+ * with 1 the frames are byte-identical to a wheel's.  (The one knob that changes bytes; read once per compress call, at its start.)
+ * Returns 0 or ZN_E_ARG. */
 int zn_set_legacy_tree_descriptions(int on);
 
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */

@@ -64,7 +64,7 @@ def test_safetensors_file_roundtrip_and_plugin(use_simt, tmp_path):
                 got = f.get_tensor(k)
                 assert got.dtype == v.dtype and torch.equal(got.view(torch.uint8), v.contiguous().view(torch.uint8)), k
             assert f.get_slice("ids")[:10].tolist() == list(range(10))
-            assert f.get_slice("w_bf16") is NotImplementedError      # reference behaviour, zipnn.py:1617
+            assert torch.equal(f.get_slice("w_bf16")[10:60].view(torch.uint8), tensors["w_bf16"][10:60].contiguous().view(torch.uint8))   # (the reference returns NotImplementedError here, zipnn.py:1617; chunk-range decode: test_get_slice_* below)
         with safetensors.safe_open(znn_path, framework="pt", device="cpu") as f:   # keyword form used by newer callers
             assert torch.equal(f.get_tensor("w_fp32"), tensors["w_fp32"])
     finally:
@@ -359,3 +359,120 @@ def test_file_compress_through_one_upload_one_batch_one_download_writes_the_same
     assert _same_safetensors_container(a, b)
     out = safetensors_io.load_file(a, device="cpu")
     assert all(torch.equal(out[k].view(torch.uint8) if out[k].numel() else out[k], tensors[k].view(torch.uint8) if tensors[k].numel() else tensors[k]) for k in tensors)
+
+
+def _st_file(tmp_path, tensors, name="m"):
+    from safetensors.torch import save_file
+    from zipnn_amd.safetensors_io import compress_safetensors_file
+    src = os.path.join(tmp_path, name + ".safetensors")
+    save_file(tensors, src, {"format": "pt"})
+    return compress_safetensors_file(src)
+
+
+def test_get_slice_of_a_compressed_tensor_decodes_only_the_covering_chunks(use_simt, tmp_path):
+    """SafeOpen.get_slice on a compressed tensor (the reference returns NotImplementedError, zipnn.py:1615-1617):
+    slices equal get_tensor(name)[index] bit for bit, on every dtype, for the index forms a tensor-parallel loader uses (row ranges,
+    a column range behind a full first dimension, an int, a step), and a row range decodes only the chunks that cover it."""
+    from zipnn_amd import zipnn as Z
+    g = torch.Generator().manual_seed(21)
+    tensors = {"w_bf16": (torch.randn(1000, 640, generator=g) * 0.02).to(torch.bfloat16),        # 1.28 MB: 5 chunks, the last one partial
+               "w_fp32": torch.randn(500, 300, generator=g) * 0.02,                              # 600 KB: 3 chunks
+               "w_fp16": (torch.randn(700, 256, generator=g) * 0.02).half(),
+               "w_fp8": (torch.randn(600, 512, generator=g) * 0.02).to(torch.float8_e4m3fn),     # 128 KiB chunks
+               "vec": (torch.randn(5000, generator=g) * 0.02).to(torch.bfloat16), "ids": torch.arange(64)}
+    out = _st_file(tmp_path, tensors)
+    same = lambda a, b: a.dtype == b.dtype and a.shape == b.shape and a.contiguous().reshape(-1).view(torch.uint8).numpy().tobytes() == b.contiguous().reshape(-1).view(torch.uint8).numpy().tobytes()  # noqa: E731
+    with Z.SafeOpen(out, framework="pt", device="cpu") as f:
+        assert f.get_slice("ids")[3:5].tolist() == [3, 4]                 # plain tensors: safetensors' own slice object
+        for k in ("w_bf16", "w_fp32", "w_fp16", "w_fp8", "vec"):
+            assert k in f.compressed_tensors_metadata
+            v = tensors[k]
+            s = f.get_slice(k)
+            assert s.get_shape() == list(v.shape) and s.get_dtype() == {"w_bf16": "BF16", "w_fp32": "F32", "w_fp16": "F16", "w_fp8": "F8_E4M3", "vec": "BF16"}[k]
+            rows = v.shape[0]
+            for idx in [slice(0, rows), slice(rows // 2, rows), slice(1, 2), slice(rows - 3, None), slice(7, 7), slice(None, None, 3), 5, -1,
+                        slice(rows // 4, rows // 2)]:
+                assert same(s[idx], v[idx]), (k, idx)
+            if v.dim() == 2:
+                cols = v.shape[1]
+                for idx in [(slice(None), slice(0, cols // 2)), (slice(10, 20), slice(cols // 2, cols)), (3, slice(1, 9)), (Ellipsis, slice(0, 4)), (slice(5, 50, 5), 2)]:
+                    assert same(s[idx], v[idx]), (k, idx)
+        # only the covering chunks are decoded: rows 400 .. 449 of the bf16 matrix are bytes [512000, 576000) = chunks 1 .. 2 of 256 KiB
+        s = f.get_slice("w_bf16")
+        part = s[400:450]
+        assert s.last_chunk_range == (1, 3) and part.untyped_storage().nbytes() <= 2 * 256 * 1024
+        assert same(part, tensors["w_bf16"][400:450])
+        _ = s[999:1000]
+        assert s.last_chunk_range == (4, 5)                                 # the partial last chunk alone
+        s8 = f.get_slice("w_fp8"); _ = s8[0:256]
+        assert s8.last_chunk_range == (0, 1)                                # 256 rows x 512 bytes = the first 128 KiB chunk of an fp8 tensor
+        with pytest.raises(IndexError):
+            s[1000]
+    os.environ["ZIPNN_AMD_REFERENCE_GET_SLICE"] = "1"
+    try:
+        with Z.SafeOpen(out, framework="pt", device="cpu") as f:
+            assert f.get_slice("w_bf16") is NotImplementedError            # the reference's answer, on request
+    finally:
+        del os.environ["ZIPNN_AMD_REFERENCE_GET_SLICE"]
+
+
+def test_read_ahead_failures_fall_back_to_the_per_tensor_path(use_simt, tmp_path, monkeypatch):
+    """whatever goes wrong inside the plugin's read-ahead (one corrupt frame in the file, an allocation that does not fit)
+    only switches the read-ahead off — every healthy tensor still loads, and the error surfaces for the tensor that has it, as with the
+    reference's per-tensor semantics (zipnn.py:1592-1626).  The read-ahead's tensors own their allocations (no shared arena)."""
+    from zipnn_amd import zipnn as Z
+    from zipnn_amd import safetensors_io
+    from zipnn_amd._capi import ZnError
+    tensors = _model(8)
+    out = _st_file(tmp_path, tensors)
+    with Z.SafeOpen(out, framework="pt", device="cpu") as f:
+        f._read_ahead()
+        assert isinstance(f._ahead, dict)
+        t = f._ahead["w_fp8"]
+        assert t.untyped_storage().nbytes() <= t.numel() + 64               # (10 000 bytes of fp8: its own allocation, not a view of an arena of all of them)
+    meta, layout, data_start = safetensors_io._read_layout(out)
+    lo, hi = layout["w_fp32"][2], layout["w_fp32"][3]
+    blob = bytearray(open(out, "rb").read())
+    for i in range(data_start + hi - 2000, data_start + hi - 1000):      # damage the payload of ONE frame (its header stays valid)
+        blob[i] ^= 0xA5
+    bad = os.path.join(tmp_path, "bad.znn.safetensors")
+    open(bad, "wb").write(blob)
+    with Z.SafeOpen(bad, framework="pt", device="cpu") as f:
+        f._read_ahead()
+        assert f._ahead is False                                             # the batched decode reported the damage: read-ahead off
+        for k in ("w_bf16", "w_fp16", "w_fp8", "tiny", "ids"):
+            assert torch.equal(f.get_tensor(k).view(torch.uint8), tensors[k].contiguous().view(torch.uint8)), k
+        try:
+            got = f.get_tensor("w_fp32")                                     # damaged streams either fail to decode or decode to other bytes
+            assert not torch.equal(got, tensors["w_fp32"])
+        except (ZnError, RuntimeError, MemoryError):
+            pass
+    # an allocation failure inside the read-ahead
+    def boom(*a, **k):
+        raise MemoryError("no room")
+    monkeypatch.setattr(safetensors_io, "decode_file_on_device", boom)
+    with Z.SafeOpen(out, framework="pt", device="cpu") as f:
+        f._read_ahead()
+        assert f._ahead is False
+        assert torch.equal(f.get_tensor("w_bf16").view(torch.uint8), tensors["w_bf16"].contiguous().view(torch.uint8))
+
+
+def test_frame_heads_from_a_file_are_validated(use_simt):
+    """fast_frame_params reads untrusted bytes — a short head, an impossible chunk exponent, a shape that does not
+    match the original length all raise ValueError (the loaders fall back to / report through the per-tensor path)."""
+    from zipnn_amd import ZipNN
+    from zipnn_amd.zipnn import fast_frame_params
+    t = (torch.randn(40, 50) * 0.02).to(torch.bfloat16)
+    frame = bytes(ZipNN(input_format="torch").compress(t))
+    fp = fast_frame_params(memoryview(frame))
+    assert fp[5] == 4000 and tuple(fp[7]) == (40, 50) and fp[1] == 2
+    with pytest.raises(ValueError):
+        fast_frame_params(memoryview(frame[:20]))
+    with pytest.raises(ValueError):
+        fast_frame_params(memoryview(frame[:33]))                            # the shape extension is cut off
+    b = bytearray(frame); b[14] = 255
+    with pytest.raises(ValueError):
+        fast_frame_params(memoryview(bytes(b)))
+    b = bytearray(frame); b[34] = 41                                         # shape (41, 50): 4100 bytes, the header says 4000
+    with pytest.raises(ValueError):
+        fast_frame_params(memoryview(bytes(b)))

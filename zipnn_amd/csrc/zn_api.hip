@@ -1152,6 +1152,7 @@ int zn_decode_status(void* stream_) {
     int rc;
     if ((rc = ws_host_words(w))) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    if (w.multi && w.busy) ZN_HIP(hipStreamWaitEvent(stream, w.busy, 0));      // (several streams on this device: behind the last call's kernels, whichever stream they ran on — ADVICE r4)
     ZN_HIP(hipMemcpyAsync(w.h_status, (uint32_t*)w.buf[WS_WORDS] + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ZN_HIP(hipStreamSynchronize(stream));
     const uint32_t st = *w.h_status;

@@ -200,7 +200,7 @@ def _contiguous_strides(shape):
 _PENDING_CLOSERS = []      # helper threads still unmapping the file of an earlier decode_file_on_device call
 
 
-def decode_file_on_device(filename, device, compressed_only=False, timings=None):
+def decode_file_on_device(filename, device, compressed_only=False, timings=None, use_arena=None):
     """The batched loader behind load_file and behind the plugin's read-ahead (SafeOpen.get_tensor): the file's data section
     crosses PCIe ONCE, as it lies on disk, through the library's pinned multi-threaded transfer; every compressed tensor is then
     decoded by ONE batched launch (zn_decompress_batch_dev) from where its frame landed in HBM into one output arena (every
@@ -210,7 +210,8 @@ def decode_file_on_device(filename, device, compressed_only=False, timings=None)
     container names a dtype this parser does not know.
     The uncompressed tensors of the file are COPIED out of the uploaded section, so that nothing keeps the compressed bytes
     resident once the decode has run; the decoded tensors share the arena (they live and die together in a model load; set
-    ZIPNN_AMD_LOAD_ARENA=0 for one allocation per tensor)."""
+    ZIPNN_AMD_LOAD_ARENA=0, or pass use_arena=False, for one allocation per tensor — what the plugin's read-ahead does, whose
+    consumers may keep any subset of a shard)."""
     import contextlib
     import mmap
     import threading
@@ -232,7 +233,8 @@ def decode_file_on_device(filename, device, compressed_only=False, timings=None)
         mm = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) if size else None
     view = memoryview(mm) if mm is not None else None
     head_len = 32 + 1 + 9 * 255                        # header + the largest shape extension (zipnn._frame_head)
-    use_arena = os.environ.get("ZIPNN_AMD_LOAD_ARENA", "1") != "0"
+    if use_arena is None:                              # (load_file: everything is returned together; SafeOpen's read-ahead passes False)
+        use_arena = os.environ.get("ZIPNN_AMD_LOAD_ARENA", "1") != "0"
     try:
         # ---- host side: one pass over the mapping ----
         plan, total = [], 0                            # (name, lo + body_off, hi, fp, arena offset)

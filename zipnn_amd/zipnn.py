@@ -499,17 +499,34 @@ _HEAD_WINDOW = HEADER_LEN + 1 + 9 * 8       # header + the shape extension of a 
 def fast_frame_params(mv):
     """What ZipNN.frame_params returns, straight from the head of one frame (host bytes: header + shape extension) and without
     a ZipNN instance — the batched loaders parse hundreds of frames per file (same fields as ZipNN._retrieve_header,
-    reference zipnn.py:396-438).  -> (body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape)"""
+    reference zipnn.py:396-438).  -> (body_off, num_buf, bits_mode, bytes_mode, chunk, orig_size, torch_dtype, shape).
+    The bytes come from a file: anything that does not add up (a head shorter than the header, a chunk exponent no frame can
+    carry, a shape whose bytes are not orig_size) raises ValueError — the callers fall back to, or report through, the
+    per-tensor path."""
+    if len(mv) < HEADER_LEN:
+        raise ValueError("frame shorter than its header")
     if mv[0] != 0x5A or mv[1] != 0x4E:
         raise ValueError("Header should start with ZN")
     dt = dtype_from_code(mv[15])
+    if mv[14] > 40:
+        raise ValueError("compression chunk exponent out of range")
     chunk = 1 << mv[14]
     if dt.planes == 1 and chunk > FP8_CHUNK_CAP:
         chunk = FP8_CHUNK_CAP
+    orig_size = int.from_bytes(mv[16:24], "little")
     shape, ext = None, 0
     if mv[8] in (EnumFormat.TORCH.value, EnumFormat.NUMPY.value):
-        shape, ext = unpack_shape(mv[HEADER_LEN:])
-    return (HEADER_LEN + ext, dt.planes, mv[6], mv[5], chunk, int.from_bytes(mv[16:24], "little"), dt.torch, shape)
+        import struct
+        try:
+            shape, ext = unpack_shape(mv[HEADER_LEN:])
+        except (IndexError, struct.error):
+            raise ValueError("frame shorter than its shape extension")
+        numel = 1
+        for d in shape:
+            numel *= int(d)
+        if numel * dt.planes != orig_size:         # (a plane per byte of an element on every dtype this path codes)
+            raise ValueError("frame shape does not match its original length")
+    return (HEADER_LEN + ext, dt.planes, mv[6], mv[5], chunk, orig_size, dt.torch, shape)
 
 
 def _frame_head(frame):
@@ -587,6 +604,97 @@ def decompress_safetensors_tensor(tensor, device="cpu"):
     return znn.decompress(tensor.contiguous(), decompress_cpu_gpu=device if device is not None else "cpu")
 
 
+_ST_DTYPE_NAME = {"float32": "F32", "float16": "F16", "bfloat16": "BF16", "float8_e4m3fn": "F8_E4M3", "float8_e5m2": "F8_E5M2"}
+
+
+class CompressedSlice:
+    """`SafeOpen.get_slice(name)` of a compressed tensor: the protocol of safetensors' own slice object (`get_shape()`,
+    `get_dtype()`, indexing), served by chunk-range decode.  Rows a .. b-1 of a tensor are the contiguous bytes
+    [a, b) x row_bytes of the frame's original buffer; the frame's chunks are independent (own size-table entries, own huff0
+    blocks: reference csrc/zipnn_core.c:929-1028 walks them one by one), so only the chunks that cover those bytes are uploaded
+    and decoded (zn_decompress_range_dev: re-based size tables, that range's payload slices through the pinned pipe) and the
+    result is a view of that range.  Indices on later dimensions are applied to the decoded rows; an index on the first
+    dimension that is not an int or a step-1 slice decodes the whole tensor.  The reference answers NotImplementedError here
+    (zipnn/zipnn.py:1615-1617); tensor-parallel loaders call exactly this."""
+
+    def __init__(self, opener, name):
+        self._o, self._name = opener, name
+        info = opener.compressed_tensors_metadata[name]
+        self._dtype_name = str(info.get("dtype", ""))
+        self._shape = [int(d) for d in json.loads(info.get("shape", "[]"))]
+        self._frame = self._keep = self._fp = None
+        self.last_chunk_range = None           # (chunk_lo, chunk_hi) of the last index operation — what it decoded
+
+    def get_shape(self):
+        return list(self._shape)
+
+    def get_dtype(self):
+        return _ST_DTYPE_NAME.get(self._dtype_name, self._dtype_name.upper())
+
+    def _load(self):
+        if self._frame is None:
+            t = self._o._host_reader().get_tensor(self._name)          # the frame: a 1-D uint8 tensor in host memory
+            self._keep = t.contiguous().reshape(-1)
+            self._frame = memoryview(self._keep.numpy())
+            self._fp = fast_frame_params(self._frame[:HEADER_LEN + 1 + 9 * 255])
+
+    def _device(self):
+        d = self._o._device
+        if isinstance(d, int):
+            d = f"cuda:{d}"
+        want = torch.device(d)
+        if want.type == "cuda" or not torch.cuda.is_available():
+            return want, want                   # (without a GPU the library is the emulated one and "device memory" is host memory: tests)
+        return torch.device("cuda", codec.current_device()), want      # a CPU target: decoded in HBM, the rows come back
+
+    def __getitem__(self, idx):
+        self._load()
+        body_off, P, bits, byts, chunk, n, tdt, shape = self._fp
+        shape = tuple(int(d) for d in (shape if shape is not None else self._shape))
+        work, want = self._device()
+        if not isinstance(idx, tuple):
+            idx = (idx,)
+        rows = shape[0] if shape else 0
+        first, rest = (idx[0], idx[1:]) if idx else (slice(None), ())
+        a, b, lead = 0, rows, None              # decode rows [a, b); `lead` then indexes the first dimension of what was decoded
+        if not shape or rows == 0 or n == 0:
+            lead, rest = None, idx              # (a scalar or an empty tensor: nothing to range over)
+        elif isinstance(first, bool) or first is None or first is Ellipsis or not isinstance(first, (int, slice)):
+            rest = idx                          # (masks, lists, a leading Ellipsis / None: the whole tensor, the index as given)
+        elif isinstance(first, int):
+            r = first + rows if first < 0 else first
+            if not 0 <= r < rows:
+                raise IndexError(f"index {first} is out of bounds for dimension 0 with size {rows}")
+            a, b, lead = r, r + 1, 0
+        else:
+            lo, hi, step = first.indices(rows)
+            if step == 1:
+                a, b, lead = lo, max(hi, lo), slice(None)
+            elif step > 1 and hi > lo:
+                a, b, lead = lo, hi, slice(None, None, step)
+            else:
+                rest = idx                      # (negative steps: the whole tensor, torch reports what it does not index)
+        row_bytes = n // rows if rows else 0
+        byte_lo, byte_hi = a * row_bytes, b * row_bytes
+        if byte_hi <= byte_lo:
+            self.last_chunk_range = (0, 0)
+            t = torch.empty((max(b - a, 0),) + shape[1:], dtype=tdt, device=want) if shape else torch.empty((), dtype=tdt, device=want)
+        else:
+            c_lo, c_hi = byte_lo // chunk, (byte_hi + chunk - 1) // chunk
+            self.last_chunk_range = (c_lo, c_hi)
+            base = c_lo * chunk
+            buf = torch.empty(min(c_hi * chunk, n) - base, dtype=torch.uint8, device=work)
+            dev_index = work.index if (work.type == "cuda" and work.index is not None) else (codec.current_device() if work.type == "cuda" else 0)
+            if work.type == "cuda":
+                torch.cuda.current_stream(work).synchronize()      # (`buf` may be a block that kernels queued earlier still use)
+            _capi.lib().decompress_range_dev(self._frame[body_off:], P, bits, byts, chunk, n, c_lo, c_hi, dev_index, buf.data_ptr())
+            t = buf[byte_lo - base: byte_hi - base].view(tdt).reshape((b - a,) + shape[1:])
+            if want != work:
+                t = t.to(want)
+        sel = (() if lead is None else (lead,)) + tuple(rest)
+        return t[sel] if sel else t
+
+
 class SafeOpen:
     """`safetensors.safe_open` wrapper that decompresses tensors named in the file's
     `znn_compressed_vectors` metadata on access (reference zipnn.py:1592-1626).  Unlike the
@@ -613,21 +721,28 @@ class SafeOpen:
         every compressed tensor of the file with ONE batched launch (safetensors_io.decode_file_on_device); get_tensor then
         serves from the cache, dropping each entry as it is handed out.  A consumer that walks the file through the reference's
         API (zipnn.py:1592-1626: one decompress per get_tensor) gets the batched path's speed.  Files larger than
-        ZIPNN_AMD_READAHEAD_BYTES (default 32 GiB; 0 switches it off) and containers the batched loader does not parse keep the
-        per-tensor path."""
+        ZIPNN_AMD_READAHEAD_BYTES (default 32 GiB, and never more than half of the device's free memory; 0 switches it off) and
+        containers the batched loader does not parse keep the per-tensor path.  Every tensor of the cache owns its allocation
+        (no shared arena: a consumer that keeps one tensor of a shard does not pin the decoded bytes of all the others), and
+        ANY failure of the read-ahead — a corrupt frame somewhere in the file, an allocation that does not fit — only switches
+        it off: the per-tensor path then reports the error for the tensor that actually has it, as the reference does."""
         import os
         from . import safetensors_io
         self._ahead = False
         try:
             limit = int(os.environ.get("ZIPNN_AMD_READAHEAD_BYTES", str(32 << 30)))
+            dev = self._device if not isinstance(self._device, int) else f"cuda:{self._device}"
+            if limit > 0 and torch.device(dev).type == "cuda" and torch.cuda.is_available():
+                limit = min(limit, torch.cuda.mem_get_info(torch.device(dev))[0] // 2)
             if limit <= 0 or os.path.getsize(self._filename) > limit:
                 return
-            dev = self._device if not isinstance(self._device, int) else f"cuda:{self._device}"
-            got = safetensors_io.decode_file_on_device(self._filename, dev, compressed_only=True)
+            got = safetensors_io.decode_file_on_device(self._filename, dev, compressed_only=True, use_arena=False)
             if got is not None:
                 self._ahead = got
-        except (OSError, ValueError, KeyError):
-            self._ahead = False                # (anything odd about the container: the per-tensor path reports it properly)
+        except Exception as e:                 # noqa: BLE001 — (anything: the per-tensor path reports it properly, for the tensor it belongs to)
+            self._ahead = False
+            if isinstance(e, (MemoryError, getattr(torch.cuda, "OutOfMemoryError", MemoryError))) and torch.cuda.is_available():
+                torch.cuda.empty_cache()
 
     def _host_reader(self):
         if str(self._device) == "cpu":
@@ -651,9 +766,16 @@ class SafeOpen:
         return decompress_safetensors_tensor(self._host_reader().get_tensor(name), device=dev)
 
     def get_slice(self, name):
+        """A lazily indexed view of one tensor.  The reference has none for compressed tensors (it returns — does not raise —
+        NotImplementedError, zipnn.py:1615-1617), which leaves a tensor-parallel loader, whose API this is, with nothing.  Chunks are
+        independent, so here a compressed tensor is sliced by CHUNK RANGE: `f.get_slice(name)[a:b]` decodes only the chunks that
+        hold rows a .. b-1 (CompressedSlice, zn_decompress_range_dev).  ZIPNN_AMD_REFERENCE_GET_SLICE=1 restores the reference's answer."""
         if name not in self.compressed_tensors_metadata:
             return self._f.get_slice(name)
-        return NotImplementedError   # sic: the reference returns (does not raise) it, zipnn.py:1617
+        import os
+        if os.environ.get("ZIPNN_AMD_REFERENCE_GET_SLICE", "0") == "1":
+            return NotImplementedError   # sic: the reference returns (does not raise) it, zipnn.py:1617
+        return CompressedSlice(self, name)
 
     def __enter__(self):
         self._f.__enter__()
