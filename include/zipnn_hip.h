@@ -186,10 +186,10 @@ int zn_copy_to_device(void* d_dst, const void* src, size_t n);
 int zn_copy_to_host(void* dst, const void* d_src, size_t n);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
- * DEVELOPER / TEST KNOBS — not part of the drop-in boundary.  The four setters below are process-wide mutable state: they exist so that
+ * DEVELOPER / TEST KNOBS — not part of the drop-in boundary.  The setters below are process-wide mutable state: they exist so that
  * the test-suite and the A/B scripts can force every kernel form on every input (tests/, scripts/) and so that a frame can be made
  * byte-identical to a PyPI wheel's; a production caller never needs them — every default is "automatic", and the bytes a call produces
- * or accepts do not depend on the first three.  They are NOT synchronised with calls in flight: set them before the first call of a
+ * or accepts do not depend on them (zn_set_legacy_tree_descriptions excepted).  They are NOT synchronised with calls in flight: set them before the first call of a
  * process (or between calls, from the one thread that drives the library) — never while another host thread is inside an entry point.
  * One host thread per GPU, as the multi-device entry points use the library, is safe with the defaults.
  * ------------------------------------------------------------------------------------------------------------------------- */
@@ -208,6 +208,13 @@ int zn_set_decode_wide(int mode);
  * (zn_compress / zn_decompress).  0 (default) = automatic (compress: 4-8 slices from 192 MiB up; decompress: one shot — measured: no gain
  * there), 1 = never, 2..64 = that many, both directions.  Returns 0 or ZN_E_ARG. */
 int zn_set_host_slices(int slices);
+
+/* the one-pass encoder (full chunks histogrammed, coded and placed by one workgroup each, the chunk's second read aimed at the Infinity Cache) —
+ * 0 = never (the four-kernel encoder only), 1 (default; ZIPNN_AMD_ONEPASS=0/1/2 in the environment changes the default) = automatic: calls whose
+ * bf16-like tensors (two planes, sign rotate) bring at least 6144 full chunks — where it has measured faster —, 2 = every call with full chunks.
+ * The four-kernel encoder is the fall-back for tensors whose planes other than the last do not all stay raw.  The bytes produced are the same in
+ * every mode.  Returns 0 or ZN_E_ARG. */
+int zn_set_encode_onepass(int mode);
 
 /* Which huff0 the compressed bytes imitate where the two in circulation differ — the FSE-coded tree description of a plane, when one
  * of its code-weight values is rare enough to round below one FSE cell: 0 (default) = zstd >= 1.4.7 (a full cell, "+1"; what the

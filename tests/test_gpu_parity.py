@@ -64,7 +64,15 @@ def test_tree_descriptions_written_by_the_wave_on_hardware(lib):
     chunk = 16384
     d = _tree_description_planes(chunk)
     want = O.compress_frame(HDR, d, 1, 0, 10, chunk, threads=4)
-    got = bytes(lib.compress(HDR, d, 1, 0, 10, chunk, 0.95))
+    lib.set_encode_onepass(True)
+    try:
+        got = bytes(lib.compress(HDR, d, 1, 0, 10, chunk, 0.95))          # the table job inside the one-pass encoder (wave 0 of a four-wave workgroup)
+        assert got == want
+        assert "zn_k_encode_onepass" in lib.last_kernels()
+        lib.set_encode_onepass(False)
+        got = bytes(lib.compress(HDR, d, 1, 0, 10, chunk, 0.95))          # … and as the table kernel's one-wave workgroup
+    finally:
+        lib.set_encode_onepass(1)
     assert got == want
     assert "zn_k_encode_tables" in lib.last_kernels()
     assert bytes(lib.decompress(got[32:], 1, 0, 10, chunk, len(d))) == d
@@ -407,7 +415,7 @@ def test_safetensors_file_through_hbm_batched_both_ways(lib, tmp_path):
     per_tensor = safetensors_io.compress_safetensors_file(src, out_path=os.path.join(tmp_path, "p.znn.safetensors"), device="cuda:0", batched=False)
     from test_plugin_simt import _same_safetensors_container
     assert _same_safetensors_container(znn, per_tensor)                            # the same file as tensor by tensor
-    assert "zn_k_encode_emit" in lib.last_kernels()
+    assert "zn_k_encode_emit" in lib.last_kernels() or "zn_k_encode_onepass" in lib.last_kernels()
     loaded = safetensors_io.load_file(znn, device="cuda:0")
     for k, v in tensors.items():
         assert loaded[k].dtype == v.dtype and loaded[k].shape == v.shape and loaded[k].is_cuda
@@ -1052,3 +1060,38 @@ def test_get_slice_of_compressed_tensors_decodes_chunk_ranges_in_hbm(lib, tmp_pa
     with Z.SafeOpen(znn, framework="pt", device="cpu") as f:       # host target: decoded in HBM, the rows come back
         got = f.get_slice("w")[7:9]
         assert not got.is_cuda and torch.equal(got, tensors["w"][7:9])
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16", "fp32", "fp8"])
+def test_onepass_encoder_on_hardware(lib, dtype):
+    """The one-pass encoder (zn_k_encode_onepass: histogram, code table, decoupled look-back and emit of a chunk by one workgroup; the chunk's second
+    read aimed at the Infinity Cache) forced on for every dtype: 96 MiB + a partial last chunk — more chunks than workgroups fit the chip at once, so the
+    look-back really waits on running predecessors — equals the oracle's body byte for byte, equals the four-kernel encoder's, and decodes back.
+    Then a tensor that breaks its layout speculation (every plane compressible): the four-kernel encoder takes over, same bytes."""
+    from zipnn_amd import codec
+    n = 96 * KB * KB + 250_000
+    x, P, rot, bm, chunk = _dtype_case(dtype, n // 4 * 4, 99)
+    flat = codec.flat_bytes(x.cuda())
+    raw = x.view(torch.uint8).reshape(-1).numpy()
+    want = O.compress_frame(bytes(32), raw, P, rot, bm, chunk, threads=8)[32:]
+    try:
+        lib.set_encode_onepass(2)
+        for rep in range(2):                                   # (twice: the look-back words carry a generation tag, nothing is zeroed between calls)
+            one = codec.compress_device(lib, flat, P, rot, bm, chunk, 0.95)
+            assert "zn_k_encode_onepass" in lib.last_kernels() and "speculation failed" not in lib.last_kernels()
+            assert one.cpu().numpy().tobytes() == want
+        lib.set_encode_onepass(0)
+        four = codec.compress_device(lib, flat, P, rot, bm, chunk, 0.95)
+        assert "zn_k_encode_onepass" not in lib.last_kernels() and torch.equal(four, one)
+        out = codec.decompress_device(lib, one, P, rot, bm, chunk, raw.size)
+        assert torch.equal(out.cpu(), torch.from_numpy(raw))
+        if P > 1:
+            lib.set_encode_onepass(2)
+            g = torch.Generator().manual_seed(5)
+            z = torch.zeros(8 * KB * KB, dtype=torch.uint8)
+            z[::7] = torch.randint(0, 4, (z[::7].numel(),), generator=g, dtype=torch.uint8)       # sparse: every plane is Huffman-coded
+            zb = codec.compress_device(lib, z.cuda(), P, rot, bm, chunk, 0.95)
+            assert "speculation failed" in lib.last_kernels()
+            assert zb.cpu().numpy().tobytes() == O.compress_frame(bytes(32), z.numpy(), P, rot, bm, chunk, threads=8)[32:]
+    finally:
+        lib.set_encode_onepass(1)

@@ -176,9 +176,12 @@ ENC = [("bf16", 3 * C + 100, 2, 1, 10, C), ("fp16", 2 * C, 2, 0, 10, C), ("fp32"
        ("bf16", 3 * 8192, 2, 1, 10, 8192)]
 
 
+@pytest.mark.parametrize("onepass", [True, False], ids=["onepass", "four-kernel"])
 @pytest.mark.parametrize("case", ENC, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}-c{c[5]}")
-def test_fused_encode_path_bit_exact(simt_lib, case):
-    """Full chunks go through zn_k_encode_stats/_emit (when the geometry allows) and must equal the oracle."""
+def test_fused_encode_path_bit_exact(simt_lib, case, onepass):
+    """Full chunks go through the one-pass encoder (zn_k_encode_onepass: histogram, table, look-back, emit by one workgroup per chunk; when its
+    layout speculation fails — `const`: RLE planes — the four-kernel encoder redoes the call) or, with the knob off, through
+    zn_k_encode_stats/_tables/_emit; either way the body must equal the oracle's."""
     kind, nb, P, rot, bm, chunk = case
     d = _gen2(kind, nb, 21)
     want = O.compress_frame(HDR, d, P, rot, bm, chunk)
@@ -188,10 +191,50 @@ def test_fused_encode_path_bit_exact(simt_lib, case):
     src16[off:off + nb] = src                                    # 16-byte aligned "device" buffer
     cap = simt_lib.compress_bound(nb, P, chunk, 0)
     body = torch.zeros(cap, dtype=torch.uint8)
-    used = simt_lib.compress_dev(src16.data_ptr() + off, nb, P, rot, bm, chunk, 0.95, body.data_ptr(), cap)
+    simt_lib.set_encode_onepass(onepass)
+    try:
+        used = simt_lib.compress_dev(src16.data_ptr() + off, nb, P, rot, bm, chunk, 0.95, body.data_ptr(), cap)
+    finally:
+        simt_lib.set_encode_onepass(1)
     assert body[:used].numpy().tobytes() == want[32:]
+    k = simt_lib.last_kernels()
     if chunk % 16384 == 0 and chunk % (8192 * P) == 0 and chunk // P <= 128 * 1024:
-        assert "zn_k_encode_stats" in simt_lib.last_kernels() and "zn_k_encode_emit" in simt_lib.last_kernels()
+        K = (nb + chunk - 1) // chunk
+        mis = any(want[32 + i] != 0 for i in range((P - 1) * K))              # a plane in front of the last one is not stored raw: not what weights look like
+        if onepass:
+            assert "zn_k_encode_onepass" in k
+            assert ("speculation failed" in k) == mis
+        if not onepass or mis:
+            assert "zn_k_encode_stats" in k and "zn_k_encode_emit" in k
+        else:
+            assert "zn_k_encode_emit" not in k.replace("zn_k_encode_emit+tail", "")
+
+
+def test_onepass_encoder_look_back_across_many_chunks_and_batches(simt_lib):
+    """The one-pass encoder's running sum (decoupled look-back, 64 predecessors per step): tensors of more chunks than one step covers, a batch
+    whose tensors each restart the sum, a tensor with a partial last chunk (its ragged planes ride in the three fused launches), two calls in a
+    row (the look-back words carry a generation tag and are never zeroed) — bodies equal the oracle's."""
+    from zipnn_amd import codec
+    c = 16384
+    specs = [("bf16", 150 * c, 2, 1, 10, c), ("fp32", 70 * 2 * c + 4 * 77, 4, 1, 220, 2 * c), ("fp8", 131 * c + 5, 1, 1, 10, c), ("fp16", 65 * c, 2, 0, 10, c),
+             ("bf16", c, 2, 1, 10, c), ("bf16", 3 * c - 2, 2, 1, 10, c)]
+    data = [_gen2(k, nb, 40 + i) for i, (k, nb, *_r) in enumerate(specs)]
+    simt_lib.set_encode_onepass(True)
+    for rep in range(2):
+        items = [(torch.frombuffer(bytearray(d), dtype=torch.uint8), P, rot, bm, ch, 0.95) for d, (_, _, P, rot, bm, ch) in zip(data, specs)]
+        bodies = codec.compress_device_batch(simt_lib, items)
+        assert simt_lib.last_kernels().count("zn_k_encode_onepass") == 3        # one launch per plane count
+        for b, d, (k, nb, P, rot, bm, ch) in zip(bodies, data, specs):
+            assert b.numpy().tobytes() == O.compress_frame(HDR, d, P, rot, bm, ch)[32:], (k, nb)
+    try:
+        one = codec.compress_device(simt_lib, torch.frombuffer(bytearray(data[0]), dtype=torch.uint8), 2, 1, 10, c, 0.95)
+    finally:
+        simt_lib.set_encode_onepass(1)
+    assert one.numpy().tobytes() == O.compress_frame(HDR, data[0], 2, 1, 10, c)[32:]
+    # automatic mode: a bf16 tensor of ZN_ONEPASS_MIN_CHUNKS full chunks takes the one-pass kernel, a smaller one the four-kernel encoder
+    small = _gen2("bf16", 6144 * 1024, 77)                                 # 6144 chunks of 1 KiB (not a fused geometry: never one-pass)
+    simt_lib.compress(HDR, small, 2, 1, 10, 1024, 0.95)
+    assert "zn_k_encode_onepass" not in simt_lib.last_kernels()
 
 
 def test_batched_decode_matches_per_tensor_decode(simt_lib):
@@ -718,7 +761,15 @@ def test_tree_descriptions_written_by_the_wave_match_the_oracle(simt_lib):
     m2_before = O.lib().zo_debug_m2_calls()
     want = O.compress_frame(HDR, d, 1, 0, 10, chunk, threads=1)
     m2 = O.lib().zo_debug_m2_calls() - m2_before
-    got = simt_lib.compress(HDR, d, 1, 0, 10, chunk, 0.95)
+    simt_lib.set_encode_onepass(True)
+    try:
+        got = simt_lib.compress(HDR, d, 1, 0, 10, chunk, 0.95)             # the table job inside the one-pass encoder (wave 0 of a four-wave workgroup)
+        assert bytes(got) == want
+        assert "zn_k_encode_onepass" in simt_lib.last_kernels()
+        simt_lib.set_encode_onepass(False)
+        got = simt_lib.compress(HDR, d, 1, 0, 10, chunk, 0.95)             # … and as the table kernel's one-wave workgroup
+    finally:
+        simt_lib.set_encode_onepass(1)
     assert bytes(got) == want
     assert "zn_k_encode_tables" in simt_lib.last_kernels()
     types, cum, payload = sharding._parse(np.frombuffer(want[32:], dtype=np.uint8), 1, nchunks)
@@ -742,7 +793,7 @@ def test_ragged_planes_are_coded_inside_the_fused_launches(simt_lib):
         d = gen_bytes(kind, nb, 5)
         assert bytes(simt_lib.compress(HDR, d, P, rot, bm, chunk, 0.95)) == O.compress_frame(HDR, d, P, rot, bm, chunk)
         k = simt_lib.last_kernels()
-        assert k.split(";") == ["zn_k_encode_stats+tail", "zn_k_encode_tables", "zn_k_scan_sizes", "zn_k_encode_emit+tail"], k
+        assert [x for x in k.split(";") if x != "zn_k_encode_onepass"] == ["zn_k_encode_stats+tail", "zn_k_encode_tables", "zn_k_scan_sizes", "zn_k_encode_emit+tail"], k      # (the full chunks: the one-pass kernel, or the same launches)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ class ZnLib:
         L.zn_set_host_slices.argtypes = [ci]
         L.zn_set_decode_group.restype = ci
         L.zn_set_decode_group.argtypes = [ci]
+        L.zn_set_encode_onepass.restype = ci
+        L.zn_set_encode_onepass.argtypes = [ci]
         L.zn_set_decode_wide.restype = ci
         L.zn_set_decode_wide.argtypes = [ci]
         L.zn_compress_dev.restype = ci
@@ -269,6 +271,11 @@ class ZnLib:
     def set_legacy_tree_descriptions(self, on):
         """zn_set_legacy_tree_descriptions: True = write tree descriptions the way the reference's PyPI wheels do (-1 markers)."""
         self._check(self._L.zn_set_legacy_tree_descriptions(1 if on else 0))
+
+    def set_encode_onepass(self, mode):
+        """Developer / test knob (zn_set_encode_onepass): 0 / False = the four-kernel encoder only, 1 = automatic (default: large bf16 calls), 2 / True =
+        every call with full chunks through the one-pass encoder."""
+        self._check(self._L.zn_set_encode_onepass(2 if mode is True else 0 if mode is False else int(mode)))
 
     def set_decode_wide(self, mode):
         """Tuning knob (zn_set_decode_wide): the small-input decoder — 0 never, 1 automatic (default), 2 / 3 every call without a delta base in its 16- / 8-wave form."""

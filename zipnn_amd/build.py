@@ -34,19 +34,39 @@ def is_stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_extension(force=False, verbose=False):
-    """Compile every kernel translation unit for gfx950 and link the C-ABI library."""
-    if not force and not is_stale():
+def build_extension(force=False, verbose=False, defines=(), out=None):
+    """Compile every kernel translation unit for gfx950 (one hipcc process per unit, side by side) and link the C-ABI library.
+    defines / out: a variant build for A/B runs on the GPU box (scripts/): extra -D flags, another output name."""
+    out = out or OUT
+    if not force and out == OUT and not is_stale():
         return OUT
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", OUT] + sources()
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = hipcc_path()
+    objdir = os.path.join(HERE, "build", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + [f"-D{d}" for d in defines]
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc] + flags + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return obj, r
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        res = list(ex.map(one, sources()))
+    for _, r in res:
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed building " + os.path.basename(out))
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + [o for o, _ in res]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building libzipnn_hip.so")
-    return OUT
+        raise RuntimeError("hipcc failed linking " + os.path.basename(out))
+    return out
 
 
 if __name__ == "__main__":

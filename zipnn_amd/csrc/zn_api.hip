@@ -14,6 +14,7 @@
 #include <string>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -34,8 +35,9 @@ thread_local std::string t_kernels;
 struct Workspace {
   size_t last_K = 0;             // chunks of the last decompress call (for zn_last_fused_chunks)
   size_t last_tails = 0;         // tail planes of the last decompress call (for zn_last_tail_planes)
-  void* buf[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  size_t cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  void* buf[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t cap[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t lb_gen = 0;           // generation tag of the one-pass encoder's look-back words (WS_LB): a launch only believes words of its own generation, so the array is never zeroed between calls
   ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched call (capacity in ZnSeg units)
   uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;   // pinned: body lengths of a batched compress
   uint64_t* h_total = nullptr;   // pinned host word for the length read-back
@@ -46,8 +48,8 @@ struct Workspace {
   ZnHostPipe pipe2;              // a second one: the pipelined host path downloads slice i - 1 while it uploads slice i + 1
   hipStream_t cstream = nullptr; // … and codes slice i on a stream of its own
 };
-enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_COUNT };
-static_assert(WS_COUNT == 12, "Workspace::buf size");
+enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_LB, WS_COUNT };
+static_assert(WS_COUNT == 13, "Workspace::buf size");
 
 // One lock PER DEVICE (the workspace tables of different devices share nothing): threads that drive different GPUs of a
 // node from one process — north_star's "independent HIP streams" — do not serialise each other.
@@ -162,6 +164,24 @@ int zn_set_legacy_tree_descriptions(int on) {
   return ZN_OK;
 }
 
+// The one-pass encoder (zn_k_encode_onepass): 0 = never (the four-kernel encoder only), 1 (default) = automatic — where it has measured faster: calls whose
+// two-plane, sign-rotated tensors (bf16) bring at least ZN_ONEPASS_MIN_CHUNKS full chunks (profiles/r05_encoder_onepass.txt: 4 GiB 2.17 vs 2.27 ms,
+// 2 GiB 1.145 vs 1.183, 1 GiB 0.633 vs 0.625; fp16 / fp32 / fp8 lose 9-30 % to it: longer table builds inside the workgroup) —, 2 = every call with
+// full chunks (tests).  ZIPNN_AMD_ONEPASS=0/1/2 in the environment sets the default of a process.  The four-kernel encoder takes over whenever the
+// one-pass kernel's layout speculation fails.  (Developer / test knob.)
+#define ZN_ONEPASS_MIN_CHUNKS 6144u
+static std::atomic<int> g_encode_onepass{-1};
+static int zn_encode_onepass_mode() {
+  int v = g_encode_onepass.load(std::memory_order_relaxed);
+  if (v < 0) { const char* e = getenv("ZIPNN_AMD_ONEPASS"); v = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1; g_encode_onepass.store(v, std::memory_order_relaxed); }
+  return v;
+}
+extern "C" int zn_set_encode_onepass(int mode) {
+  if (mode < 0 || mode > 2) return ZN_E_ARG;
+  g_encode_onepass.store(mode, std::memory_order_relaxed);
+  return ZN_OK;
+}
+
 // Compress `count` tensors: one launch per stage and plane count over all of them (a single tensor travels to the
 // kernels as an argument, a batch as a segment table), one read-back of all body lengths.
 static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t stream) {
@@ -218,7 +238,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   if ((rc = ws_reserve(w, WS_DESC, pc_all * sizeof(ZnEncDesc)))) return rc;
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   // (one slot more than there are tensors: the call's status word rides behind the body lengths, so that both come back in ONE copy)
-  if ((rc = ws_reserve(w, WS_TOTALS, (count + 1) * sizeof(uint64_t)))) return rc;
+  if ((rc = ws_reserve(w, WS_TOTALS, (count + 4) * sizeof(uint64_t)))) return rc;      // (… and the one-pass encoder's three ticket counters behind that)
   if ((rc = ws_host_words(w))) return rc;
   if (w.h_totals_cap < count + 1) {
     if (w.h_totals) { ZN_HIP(hipHostFree(w.h_totals)); w.h_totals = nullptr; w.h_totals_cap = 0; }
@@ -234,41 +254,83 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
       w.h_segs_cap = (need + sizeof(ZnSeg) - 1) / sizeof(ZnSeg);
     }
   }
+  // The one-pass encoder takes the full chunks of the call when every tensor's prefix sums fit its look-back words (40 bits)
+  const int op_mode = zn_encode_onepass_mode();
+  bool op_of[3] = {false, false, false};         // by plane count: this call's full chunks of that plane count go through the one-pass kernel
+  for (int q = 0; q < 3; q++) {
+    if (op_mode == 0 || chunks_of[q] == 0) continue;
+    bool ok = true, rot = true;
+    for (const ZnESeg& sg : segs[q]) { if (sg.g.n >= (1ull << 38)) ok = false; if (sg.nfull && !sg.g.rot) rot = false; }
+    op_of[q] = ok && (op_mode == 2 || (q == 1 && rot && chunks_of[q] >= ZN_ONEPASS_MIN_CHUNKS));
+  }
+  const bool onepass = op_of[0] || op_of[1] || op_of[2];
+  const uint64_t chunks_all = chunks_of[0] + chunks_of[1] + chunks_of[2];
+  if (onepass) {
+    const size_t had = w.cap[WS_LB];
+    if ((rc = ws_reserve(w, WS_LB, chunks_all * sizeof(uint64_t)))) return rc;
+    if (w.cap[WS_LB] != had) { ZN_HIP(hipMemset(w.buf[WS_LB], 0, w.cap[WS_LB])); w.lb_gen = 0; }      // (a fresh array: no word of any generation)
+  }
   if ((rc = ws_acquire(w, stream))) return rc;
   uint64_t* d_totals = (uint64_t*)w.buf[WS_TOTALS];
   uint32_t* d_status = (uint32_t*)(d_totals + count);
   uint32_t* d_csize = (uint32_t*)w.buf[WS_META_A]; uint8_t* d_type = (uint8_t*)w.buf[WS_META_B]; uint64_t* d_offs = (uint64_t*)w.buf[WS_META_C];
-  bool status_zeroed = false;                    // (by the first table kernel of the call; a memset only when none is launched)
   if (table) {
     ZN_HIP(hipEventSynchronize(w.busy));         // the previous batched call may still be reading the pinned staging
     ZnESeg* hs = (ZnESeg*)w.h_segs; size_t o = 0;
     for (int q = 0; q < 3; q++) for (const ZnESeg& sg : segs[q]) hs[o++] = sg;
     ZN_HIP(hipMemcpyAsync(w.buf[WS_SEGS], hs, nseg_all * sizeof(ZnESeg), hipMemcpyHostToDevice, stream));
   }
-  size_t seg_base = 0;
-  for (int stage = 0; stage < 3; stage++) {      // stats (fused + generic) for every plane count, then the scans, then emit / gather
-    seg_base = 0;
-    if (stage == 1 && !status_zeroed) { ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream)); status_zeroed = true; }
-    for (int q = 0; q < 3; q++) {
-      if (segs[q].empty()) continue;
-      const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
-      const ZnESeg* d_segs = table ? (const ZnESeg*)w.buf[WS_SEGS] + seg_base : nullptr;
-      const uint32_t nseg = (uint32_t)segs[q].size();
-      const ZnESeg& one = segs[q][0];
-      if (stage == 0) {
-        if (zn_launch_encode_fused_stats(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)jobs_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES], slot,
-                                         d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], status_zeroed ? nullptr : d_status, stream)) status_zeroed = true;
-      } else if (stage == 1) {
-        zn_launch_scan_sizes(one, d_segs, nseg, (uint32_t)scan_of[q], d_csize, d_type, d_offs, d_totals, stream);
-      } else {
-        zn_launch_encode_fused_emit(P, one, d_segs, nseg, (uint32_t)chunks_of[q], (uint32_t)ptails_of[q], (const uint8_t*)w.buf[WS_PLANES], slot,
-                                    d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, delta_of[q], stream);
+  // One pass over the launches; `op`: the full chunks through the one-pass encoder (their ragged planes, if any, through the ragged workgroups of the
+  // three fused launches), else everything through the four-kernel encoder.
+  auto launch_all = [&](bool op) -> int {
+    bool status_zeroed = false;                  // (by the first table kernel of the call; a memset only when none is launched — or in front of the one-pass kernel, which may set bits)
+    if (op) {
+      ZN_HIP(hipMemsetAsync(d_status, 0, 4 * sizeof(uint64_t), stream));      // the status word and the three ticket counters behind it
+      status_zeroed = true;
+    }
+    size_t seg_base = 0;
+    uint64_t lb_base = 0;
+    for (int stage = 0; stage < 3; stage++) {    // stats (fused + generic) for every plane count, then the scans, then emit / gather
+      seg_base = 0;
+      if (stage == 1 && !status_zeroed) { ZN_HIP(hipMemsetAsync(d_status, 0, sizeof(uint32_t), stream)); status_zeroed = true; }
+      for (int q = 0; q < 3; q++) {
+        if (segs[q].empty()) continue;
+        const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
+        const ZnESeg* d_segs = table ? (const ZnESeg*)w.buf[WS_SEGS] + seg_base : nullptr;
+        const uint32_t nseg = (uint32_t)segs[q].size();
+        const ZnESeg& one = segs[q][0];
+        const bool opq = op && op_of[q];
+        if (stage == 0) {
+          if (zn_launch_encode_fused_stats(P, one, d_segs, nseg, opq ? 0u : (uint32_t)chunks_of[q], opq ? 0u : (uint32_t)jobs_of[q], (uint32_t)ptails_of[q], (uint8_t*)w.buf[WS_PLANES], slot,
+                                           d_csize, d_type, (ZnEncDesc*)w.buf[WS_DESC], delta_of[q], status_zeroed ? nullptr : d_status, stream)) status_zeroed = true;
+          if (opq) {
+            w.lb_gen = (w.lb_gen + 1u) & 0x3FFFFFu;
+            if (w.lb_gen == 0) { ZN_HIP(hipMemsetAsync(w.buf[WS_LB], 0, w.cap[WS_LB], stream)); w.lb_gen = 1; }       // (the tag has wrapped: forget every older word)
+            zn_launch_encode_onepass(P, one, d_segs, nseg, (uint32_t)chunks_of[q], d_csize, d_type, (uint64_t*)w.buf[WS_LB] + lb_base,
+                                     (uint32_t*)(d_totals + count + 1 + q), d_status, w.lb_gen, delta_of[q], stream);
+            lb_base += chunks_of[q];
+          }
+        } else if (stage == 1) {
+          zn_launch_scan_sizes(one, d_segs, nseg, (uint32_t)scan_of[q], d_csize, d_type, d_offs, d_totals, opq ? d_status : nullptr, stream);
+        } else {
+          zn_launch_encode_fused_emit(P, one, d_segs, nseg, opq ? 0u : (uint32_t)chunks_of[q], (uint32_t)ptails_of[q], (const uint8_t*)w.buf[WS_PLANES], slot,
+                                      d_csize, d_type, d_offs, (const ZnEncDesc*)w.buf[WS_DESC], d_status, delta_of[q], stream);
+        }
+        seg_base += nseg;
       }
-      seg_base += nseg;
+    }
+    ZN_HIP(hipGetLastError());
+    ZN_HIP(hipMemcpyAsync(w.h_totals, d_totals, (count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));     // body lengths + the status word
+    return ZN_OK;
+  };
+  if ((rc = launch_all(onepass))) return rc;
+  if (onepass) {
+    ZN_HIP(hipStreamSynchronize(stream));
+    if ((uint32_t)w.h_totals[count] & ZN_DEV_MISSPEC) {           // a tensor that does not look like weights: its bytes are where a decoder would not look for them
+      if ((rc = launch_all(false))) return rc;
+      zn_note_kernel("(one-pass speculation failed: four-kernel encoder)");
     }
   }
-  ZN_HIP(hipGetLastError());
-  ZN_HIP(hipMemcpyAsync(w.h_totals, d_totals, (count + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));     // body lengths + the status word
   if ((rc = ws_release(w, stream, table))) return rc;
   ZN_HIP(hipStreamSynchronize(stream));
   for (size_t i = 0; i < count; i++) items[i].body_len = (size_t)w.h_totals[i];

@@ -22,6 +22,7 @@
 // device-side status bits OR-ed into the per-call status word
 #define ZN_DEV_BAD_TYPE 1u
 #define ZN_DEV_CORRUPT 2u
+#define ZN_DEV_MISSPEC 4u  // the one-pass encoder's layout speculation (every plane but the last stored raw) did not hold: the caller runs the four-kernel encoder
 
 // plane-chunk kinds resolved by the decoder from (type, stored size, plane length)
 #define ZN_KIND_RAW 0u   // type 0, or type 1 with csize == plane_len (HUF_decompress memcpy rule)
@@ -104,7 +105,7 @@ __device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P,
 #if defined(ZN_F_ABL) || defined(ZN_E_ABL)
 #error "ZN_F_ABL / ZN_E_ABL: the ablation code left the sources after round 3 (build commit 3c0f9d7 for it)"
 #endif
-#if defined(ZN_F_ONLY_HOT) || defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB)
+#if defined(ZN_F_ONLY_HOT) || defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB) || defined(ZN_OP_FAKE_LB) || defined(ZN_OP_PROBE_HALF_HIST)
 #error "developer-only macro (ZN_F_ONLY_HOT / ZN_PHASE_TIMERS) without ZN_DEV_BUILD: not a product configuration"
 #endif
 #if defined(ZN_F_P2_MASK) && (ZN_F_P2_MASK == 0)

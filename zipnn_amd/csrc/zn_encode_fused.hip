@@ -75,6 +75,42 @@ __device__ __forceinline__ uint32_t zn_wave_excl_scan_u32(uint32_t v, uint32_t* 
   return (uint32_t)x - v;
 }
 
+__device__ __forceinline__ uint64_t zn_wave_sum64_e(uint64_t v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+
+// Four consecutive elements (P dwords) -> one dword per byte plane, the reference's sign-bit rotate applied at PLANE level: byte p of dword-pair / dword
+// element e goes to byte e of pl[p]; with `rot` the two top planes exchange one bit per byte (data_manipulation_dtype16.c:10-20, dtype32.c:39-49:
+// top' = top << 1 | next.7, next' = top.7 << 7 | next & 0x7F) — two v_perm + four bit-field ops for four bf16 elements, where rotating every dword
+// and then picking bytes cost 14 + 10 (the encoder is VALU-bound: profiles/r05_encoder_pmc.txt).
+#if !defined(ZN_SIMT_EMULATOR)
+__device__ __forceinline__ uint32_t zn_ebfi(uint32_t mask, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(mask), "v"(a), "v"(b)); return d; }
+#else
+__device__ __forceinline__ uint32_t zn_ebfi(uint32_t mask, uint32_t a, uint32_t b) { return (a & mask) | (b & ~mask); }
+#endif
+template <int P>
+__device__ __forceinline__ void zn_split4(const uint32_t* d, uint32_t rot, uint32_t (&pl)[P]) {
+  if (P == 1) { pl[0] = d[0]; return; }
+  if (P == 2) {
+    pl[0] = __builtin_amdgcn_perm(d[1], d[0], 0x06040200u);        // the four low bytes
+    pl[1 % P] = __builtin_amdgcn_perm(d[1], d[0], 0x07050301u);    // the four high bytes
+  } else {
+    const uint32_t a = __builtin_amdgcn_perm(d[1], d[0], 0x05010400u), b = __builtin_amdgcn_perm(d[1], d[0], 0x07030602u);      // bytes 0,1 / 2,3 of elements 0,1
+    const uint32_t c = __builtin_amdgcn_perm(d[3 % (4 * P / 4)], d[2 % P], 0x05010400u), e = __builtin_amdgcn_perm(d[3 % P], d[2 % P], 0x07030602u);   // … of elements 2,3
+    pl[0] = __builtin_amdgcn_perm(c, a, 0x05040100u); pl[1 % P] = __builtin_amdgcn_perm(c, a, 0x07060302u);
+    pl[2 % P] = __builtin_amdgcn_perm(e, b, 0x05040100u); pl[3 % P] = __builtin_amdgcn_perm(e, b, 0x07060302u);
+  }
+  if (rot) {
+    const uint32_t top = pl[P - 1], nxt = pl[(P >= 2) ? P - 2 : 0];
+    pl[P - 1] = zn_ebfi(0xFEFEFEFEu, top << 1, nxt >> 7);
+    pl[(P >= 2) ? P - 2 : 0] = zn_ebfi(0x7F7F7F7Fu, nxt, top);
+  }
+}
+
 // rotated dword → the reference's forward bit reorder for this plane count
 template <int P> __device__ __forceinline__ uint32_t zn_rot_fwd(uint32_t u, uint32_t rot) {
   if (!rot) return u;
@@ -181,6 +217,94 @@ __device__ __forceinline__ void zn_encode_tail_stats(uint32_t* hist /* LDS: [256
   D->qcount[q][tid] = (uint16_t)cum;             // (a quarter of a huff0 block: ≤ 32 768 symbols)
 }
 
+#if !defined(ZN_SIMT_EMULATOR)
+#define ZN_STATS_FENCE(on) do { if (on) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define ZN_STATS_FENCE(on) do { } while (0)
+#endif
+// The histogram pass over one full chunk: thread = bin afterwards (tot[p] = count of byte value `tid` in plane p, qc[p][q] = … in quarter q).
+// NT: non-temporal loads (the stats kernel: one pure streaming read, -3 % on compress) — or plain ones (the one-pass encoder, whose second read of the
+// chunk is to be served by the Infinity Cache: a non-temporal first read leaves nothing there, profiles/r05_mall_reread.txt).
+template <int P, bool X, bool NT>
+__device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g, const uint8_t* cs0, const uint8_t* xcs0, uint32_t tid, uint32_t lane,
+                                               uint32_t (&tot)[P], uint32_t (&qc)[P][4]) {
+  constexpr uint32_t COLS = ZnStatsLds<P>::COLS;
+  constexpr uint32_t PAIRS = ZnStatsLds<P>::PAIRS;
+  for (int p = 0; p < P; p++) tot[p] = 0;
+  const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;       // 16-byte vectors per quarter (a multiple of 256)
+  uint32_t* hbase = &L.hist[0][lane & (COLS - 1u)];
+  // The loads of step i + 1 are issued before the bytes of step i are counted, across quarter ends too (the column
+  // sums and their barriers would otherwise run with nothing in flight): ZN_E_STATS_AHEAD.
+  const uint32_t qbytes = (uint32_t)(g.chunk / 4u);
+  auto ld = [&](const uint8_t* a) -> uint4 { return NT ? ZN_LD_STATS(a) : *(const uint4*)a; };
+  auto fetch = [&](uint4 (&xs)[4], uint32_t q, uint32_t v0) {
+    const uint8_t* qs = cs0 + (uint64_t)q * qbytes;
+    for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ld(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
+    if (X && xcs0) {
+      const uint8_t* xqs = xcs0 + (uint64_t)q * qbytes;
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nvec) { const uint4 t = ld(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
+    }
+  };
+  uint4 nx[4];
+  if (ZN_E_STATS_AHEAD) fetch(nx, 0u, tid);
+  for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
+  __syncthreads();
+  for (int q = 0; q < 4; q++) {
+    // 4 independent 16-byte loads in flight per thread per step, one step ahead
+    for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
+      uint4 xs[4];
+      if (!ZN_E_STATS_AHEAD) fetch(nx, (uint32_t)q, v0);
+      for (int u = 0; u < 4; u++) xs[u] = nx[u];
+      const uint32_t v1 = v0 + 4u * ZN_E_THREADS;
+      if (ZN_E_STATS_AHEAD) {
+        if (v1 < nvec) fetch(nx, (uint32_t)q, v1);
+        else if (q < 3) fetch(nx, (uint32_t)q + 1u, tid);
+      }
+      for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
+        // (the vector's 16 / P elements plane by plane: zn_split4 per four elements, then one counter per byte)
+        const uint32_t d[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
+        for (int k0 = 0; k0 < 4; k0 += P) {
+          uint32_t pl[P];
+          zn_split4<P>(d + k0, g.rot, pl);
+          for (int p = 0; p < P; p++)
+            for (int t = 0; t < 4; t++) {
+              const uint32_t b = (pl[p] >> (8 * t)) & 0xFFu;
+#if defined(ZN_OP_PROBE_HALF_HIST)               /* developer timing probe: only the last plane is counted (weights: the same decisions, half the LDS atomics) */
+              if (!NT && p != P - 1) continue;
+#endif
+              atomicAdd(hbase + (uint32_t)(p >> 1) * (256u * COLS) + b * COLS, (p & 1) ? 65536u : 1u);
+            }
+        }
+        ZN_STATS_FENCE(!NT);                     // (the one-pass kernel lives within 128 registers: one vector's sixteen counters at a time)
+      }
+    }
+    __syncthreads();
+    // sum the columns (column order staggered per thread so that the lanes of a wave read different banks)
+    // (two planes share a counter: one read serves both)
+    uint32_t cum[P];
+    for (int p = 0; p < P; p++) cum[p] = 0;
+    // (the thread index made opaque per quarter: the 32 staggered column addresses are loop-invariant, and the compiler kept all of them — 32 registers —
+    //  alive across the counting loops above: 164 registers for two planes, three workgroups per CU instead of the five the histogram's LDS allows)
+    uint32_t t_ = tid;
+#if !defined(ZN_SIMT_EMULATOR)
+    asm volatile("" : "+v"(t_));
+#endif
+    for (int pr = 0; pr < (int)PAIRS; pr++) {
+      for (uint32_t r0 = 0; r0 < COLS; r0 += 8u) {
+        uint32_t x[8];
+        for (uint32_t r = 0; r < 8u; r++) x[r] = L.hist[pr][t_ * COLS + ((r0 + r + t_) & (COLS - 1u))];
+        for (uint32_t r = 0; r < 8u; r++) {
+          if (P == 1) cum[0] += x[r];
+          else { cum[2 * pr] += x[r] & 0xFFFFu; cum[(2 * pr + 1) % P] += x[r] >> 16; }
+        }
+        ZN_STATS_FENCE(!NT);                     // (the one-pass kernel lives within 128 registers: eight columns at a time)
+      }
+    }
+    for (int p = 0; p < P; p++) { qc[p][q] = cum[p] - tot[p]; tot[p] = cum[p]; }
+    __syncthreads();
+  }
+}
+
 template <int P, bool X>
 __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                   uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
@@ -205,63 +329,10 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_stats(ZnESeg one, co
   const uint32_t n = (uint32_t)(g.chunk / P);                 // plane length of a full chunk (the host launches full, eligible chunks only)
   ZN_PT_DECL;
 
-  constexpr uint32_t COLS = ZnStatsLds<P>::COLS;
-  constexpr uint32_t PAIRS = ZnStatsLds<P>::PAIRS;
-
   uint32_t tot[P], qc[P][4];                                  // thread = bin: count so far / per quarter
-  for (int p = 0; p < P; p++) tot[p] = 0;
-  const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;       // 16-byte vectors per quarter (a multiple of 256)
-  uint32_t* hbase = &L.hist[0][lane & (COLS - 1u)];
-  // The loads of step i + 1 are issued before the bytes of step i are counted, across quarter ends too (the column
-  // sums and their barriers would otherwise run with nothing in flight): ZN_E_STATS_AHEAD.
   const uint8_t* cs0 = src + c * g.chunk;
   const uint8_t* xcs0 = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;
-  const uint32_t qbytes = (uint32_t)(g.chunk / 4u);
-  auto fetch = [&](uint4 (&xs)[4], uint32_t q, uint32_t v0) {
-    const uint8_t* qs = cs0 + (uint64_t)q * qbytes;
-    for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ZN_LD_STATS(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
-    if (X && xcs0) {
-      const uint8_t* xqs = xcs0 + (uint64_t)q * qbytes;
-      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nvec) { const uint4 t = ZN_LD_STATS(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
-    }
-  };
-  uint4 nx[4];
-  if (ZN_E_STATS_AHEAD) fetch(nx, 0u, tid);
-  for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
-  __syncthreads();
-  for (int q = 0; q < 4; q++) {
-    // 4 independent 16-byte loads in flight per thread per step, one step ahead
-    for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
-      uint4 xs[4];
-      if (!ZN_E_STATS_AHEAD) fetch(nx, (uint32_t)q, v0);
-      for (int u = 0; u < 4; u++) xs[u] = nx[u];
-      const uint32_t v1 = v0 + 4u * ZN_E_THREADS;
-      if (ZN_E_STATS_AHEAD) {
-        if (v1 < nvec) fetch(nx, (uint32_t)q, v1);
-        else if (q < 3) fetch(nx, (uint32_t)q + 1u, tid);
-      }
-      for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
-        const uint32_t d[4] = {zn_rot_fwd<P>(xs[u].x, g.rot), zn_rot_fwd<P>(xs[u].y, g.rot), zn_rot_fwd<P>(xs[u].z, g.rot), zn_rot_fwd<P>(xs[u].w, g.rot)};
-        for (int k = 0; k < 4; k++)
-          for (int t = 0; t < 4; t++) {
-            const uint32_t b = (d[k] >> (8 * t)) & 0xFFu;
-            const int p = (P == 1) ? 0 : (P == 2) ? (t & 1) : t;           // plane of byte t of a dword
-            atomicAdd(hbase + (uint32_t)(p >> 1) * (256u * COLS) + b * COLS, (p & 1) ? 65536u : 1u);
-          }
-      }
-    }
-    __syncthreads();
-    // sum the columns (column order staggered per thread so that the lanes of a wave read different banks)
-    for (int p = 0; p < P; p++) {
-      uint32_t cum = 0;
-      for (uint32_t r = 0; r < COLS; r++) {
-        const uint32_t x = L.hist[p >> 1][tid * COLS + ((r + tid) & (COLS - 1u))];
-        cum += (P == 1) ? x : ((x >> (16u * (uint32_t)(p & 1))) & 0xFFFFu);
-      }
-      qc[p][q] = cum - tot[p]; tot[p] = cum;
-    }
-    __syncthreads();
-  }
+  zn_stats_count<P, X, true>(L, g, cs0, xcs0, tid, lane, tot, qc);
   ZN_PT(0);   // zero + histograms
 
   // ---- per plane: largest count, highest symbol, and the cheap exits of HUF_compress ----
@@ -308,34 +379,21 @@ struct ZnTablesLds {
   uint32_t hl;
 };
 
-__global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
-                                                         uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
-                                                         ZnEncDesc* __restrict__ descs_all, uint32_t njobs, uint32_t* __restrict__ status_zero) {
-  __shared__ ZnTablesLds L;
-  // (the call's status word — set by the emit kernels, behind this launch — starts at zero: one memset node less in front of every compress call)
-  if (status_zero && blockIdx.x == 0 && threadIdx.x == 0) *status_zero = 0;
-  const bool ragged = blockIdx.x >= njobs;       // the jobs of the ragged planes come behind those of the full chunks
-  const ZnESeg S = ragged ? zn_efind_ptail(one, segs, nseg, blockIdx.x - njobs) : zn_efind_job(one, segs, nseg, blockIdx.x);
-  const ZnGeom g = S.g; const uint64_t nfull = S.nfull; const float threshold = S.threshold;
-  uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
-  ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
-  const uint32_t lane = threadIdx.x;
-  uint32_t p; uint64_t c;
-  if (ragged) { const uint64_t KL = g.K - nfull, pcl = (uint64_t)(blockIdx.x - njobs) - S.ptail0; p = (uint32_t)(pcl / KL); c = nfull + pcl % KL; }
-  else { const uint64_t job = blockIdx.x - S.job0; p = (uint32_t)(job / nfull); c = job % nfull; }
-  const uint64_t pc = (uint64_t)p * g.K + c;
-  if (!ragged && type_out[pc] != 2) return;
-  const uint32_t n = ragged ? zn_plane_len(zn_chunk_len(g, c), g.P, p) : (uint32_t)(g.chunk / g.P);
-  if (ragged && (n == 0u || n > ZN_HUF_BLOCK_MAX)) return;       // stored raw by its stats workgroups
-  const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
-  ZnEncDesc* D = descs + pc;
-  ZN_PT_DECL;
-
+// One table job by ONE WAVE: the per-quarter symbol counts of a plane (qcount[q][symbol]: global memory — the stats kernel's — or LDS — the
+// one-pass encoder's) -> the plane's type and stored size and, for a plane that is kept, its code table, tree description and stream sizes in *D.
+// WGSYNC: the wave is the whole workgroup (the table kernel: __syncthreads) — or one wave of a larger workgroup whose other waves wait at a later
+// barrier (wave-level ordering only: the LDS executes a wave's operations in program order).  `ragged`: the cheap exits of HUF_compress are taken
+// here (a full chunk's histogram pass has taken them already).  All 64 lanes call it together; type_o / cs_o are wave-uniform.
+#define ZN_TJ_SYNC() do { if (WGSYNC) __syncthreads(); else __builtin_amdgcn_wave_barrier(); } while (0)
+template <bool WGSYNC>
+__device__ __forceinline__ void zn_table_job(ZnTablesLds& L, const uint16_t (*qcount)[256], uint32_t n, uint64_t cap, float threshold, bool legacy, bool ragged,
+                                             ZnEncDesc* D, uint32_t lane, uint32_t& type_o, uint32_t& cs_o ZN_PT_PARAM) {
+  ZN_PT_SHARED;
   // symbol counts (lane handles symbols lane + 64 k), highest symbol
   uint32_t qv[4][4], cnt[4], max_sv = 0;
   for (int k = 0; k < 4; k++) {
     cnt[k] = 0;
-    for (int q = 0; q < 4; q++) { qv[q][k] = D->qcount[q][lane + 64u * (uint32_t)k]; cnt[k] += qv[q][k]; }
+    for (int q = 0; q < 4; q++) { qv[q][k] = qcount[q][lane + 64u * (uint32_t)k]; cnt[k] += qv[q][k]; }
     const uint64_t m = __ballot(cnt[k] != 0);
     if (m) max_sv = 64u * (uint32_t)k + 63u - (uint32_t)__builtin_clzll(m);
   }
@@ -347,14 +405,15 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d); if (m2 > mx) mx = m2; }
     if (mx == n) {                               // RLE (threshold rule of compression_worker, zipnn_core.c:371-385)
       const bool keep = 1.0 < (double)n * (double)threshold;
-      if (lane == 0) { type_out[pc] = keep ? 1 : 0; csize_out[pc] = keep ? 1u : n; if (keep) D->hdr[0] = (uint8_t)max_sv; }
+      if (lane == 0 && keep) D->hdr[0] = (uint8_t)max_sv;
+      type_o = keep ? 1u : 0u; cs_o = keep ? 1u : n;
       return;
     }
-    if (mx <= (n >> 7) + 4u) { if (lane == 0) { type_out[pc] = 0; csize_out[pc] = n; } return; }
+    if (mx <= (n >> 7) + 4u) { type_o = 0u; cs_o = n; return; }
   }
   for (uint32_t i = lane; i < 513u; i += 64u) { ZnHNode z; z.count = 0; z.parent = 0; z.byte = 0; z.nb = 0; L.nodes[i] = z; }
   __builtin_amdgcn_wave_barrier();
-  __syncthreads();
+  ZN_TJ_SYNC();
   // HUF_sort: a symbol's position is the number of symbols that sort before it (larger count, or equal
   // count and smaller symbol value).  Only symbols that occur can sort before one that occurs, so the
   // candidates are walked through the ballot masks (wave-uniform broadcast with v_readlane); symbols that
@@ -386,12 +445,12 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
       nz_before += (uint32_t)__popcll(nzm[k]);
     }
   }
-  __syncthreads();
+  ZN_TJ_SYNC();
   ZN_PT(2);   // counts + sort
   // the tree over the sorted leaves (serial on lane 0: the merge and the internal depths), code lengths and the first code value of
   // every length (lane-parallel): zn_wave_tree_from_sorted
   const uint32_t huff_log = zn_wave_tree_from_sorted(&L.S, L.nodes, (int)nz_total - 1, zn_optimal_table_log(ZN_HUF_LOG_DEFAULT, n, max_sv, 1), lane);
-  __syncthreads();
+  ZN_TJ_SYNC();
   ZN_PT(5);   // tree + code lengths
   // parallel: code length of every symbol (sorted position → symbol), zero beyond the highest symbol
   for (int k = 0; k < 4; k++) {
@@ -399,7 +458,7 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     if (i <= max_sv) L.S.nbits[L.nodes[1u + i].byte] = L.nodes[1u + i].nb;
     else { L.S.nbits[i] = 0; L.S.vals[i] = 0; }
   }
-  __syncthreads();
+  ZN_TJ_SYNC();
   // parallel: canonical values (symbols of one length in symbol order), huff0 weights and their histogram
   uint32_t wc[13];
   {
@@ -423,19 +482,19 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     for (uint32_t v = 0; v < 13u; v++) if (lane == v) L.S.wcount[v] = wc[v];
     if (lane == 13u) L.S.wcount[13] = 0;
   }
-  __syncthreads();
+  ZN_TJ_SYNC();
   ZN_PT(9);   // values + weights
   // the tree description: the whole wave, its serial chain on wave-uniform values (zn_wave_write_ctable)
   uint32_t cs = 0, hdr_len = 0; bool go = false;
   {
-    const int h = zn_wave_write_ctable(&L.S, max_sv, wc, lane, S.legacy_weights ? -1 : 1);
+    const int h = zn_wave_write_ctable(&L.S, max_sv, wc, lane, legacy ? -1 : 1);
     if (h < 0) cs = 0xFFFFFFFFu;               // huff0 error → fails the threshold test → raw
     else if ((uint32_t)h + 12u >= n) cs = 0;
     else if (cap - (uint32_t)h < 6u + 1u + 1u + 1u + 8u || n < 12u) cs = 0;      // (HUF_compress4X: a source of fewer than 12 bytes is not coded)
     else go = true;
     hdr_len = (uint32_t)(h > 0 ? h : 0);
   }
-  __syncthreads();
+  ZN_TJ_SYNC();
   ZN_PT(6);   // tree description
   uint32_t sz[4] = {0, 0, 0, 0};
   if (go) {
@@ -464,7 +523,36 @@ __global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESe
     for (uint32_t i = lane; i < 136u; i += 64u) D->hdr[i] = (i < hdr_len) ? L.S.hdr[i] : 0;
     if (lane == 0) { D->hdr_len = hdr_len; for (int k = 0; k < 4; k++) D->ssize[k] = sz[k]; }
   }
-  if (lane == 0) { type_out[pc] = keep ? 1 : 0; csize_out[pc] = keep ? cs : n; }
+  type_o = keep ? 1u : 0u; cs_o = keep ? cs : n;
+}
+#undef ZN_TJ_SYNC
+
+__global__ __launch_bounds__(64) void zn_k_encode_tables(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                         uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
+                                                         ZnEncDesc* __restrict__ descs_all, uint32_t njobs, uint32_t* __restrict__ status_zero) {
+  __shared__ ZnTablesLds L;
+  // (the call's status word — set by the emit kernels, behind this launch — starts at zero: one memset node less in front of every compress call)
+  if (status_zero && blockIdx.x == 0 && threadIdx.x == 0) *status_zero = 0;
+  const bool ragged = blockIdx.x >= njobs;       // the jobs of the ragged planes come behind those of the full chunks
+  const ZnESeg S = ragged ? zn_efind_ptail(one, segs, nseg, blockIdx.x - njobs) : zn_efind_job(one, segs, nseg, blockIdx.x);
+  const ZnGeom g = S.g; const uint64_t nfull = S.nfull; const float threshold = S.threshold;
+  uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
+  ZnEncDesc* __restrict__ descs = descs_all + S.pc0;
+  const uint32_t lane = threadIdx.x;
+  uint32_t p; uint64_t c;
+  if (ragged) { const uint64_t KL = g.K - nfull, pcl = (uint64_t)(blockIdx.x - njobs) - S.ptail0; p = (uint32_t)(pcl / KL); c = nfull + pcl % KL; }
+  else { const uint64_t job = blockIdx.x - S.job0; p = (uint32_t)(job / nfull); c = job % nfull; }
+  const uint64_t pc = (uint64_t)p * g.K + c;
+  if (!ragged && type_out[pc] != 2) return;
+  const uint32_t n = ragged ? zn_plane_len(zn_chunk_len(g, c), g.P, p) : (uint32_t)(g.chunk / g.P);
+  if (ragged && (n == 0u || n > ZN_HUF_BLOCK_MAX)) return;       // stored raw by its stats workgroups
+  const uint64_t cap = g.chunk;                  // HUF_compress dstCapacity at the call site (zipnn_core.c:366-368)
+  ZnEncDesc* D = descs + pc;
+  ZN_PT_DECL;
+
+  uint32_t ty = 0, cs = n;
+  zn_table_job<true>(L, D->qcount, n, cap, threshold, S.legacy_weights != 0, ragged, D, lane, ty, cs ZN_PT_PASS);
+  if (lane == 0) { type_out[pc] = (uint8_t)ty; csize_out[pc] = cs; }
   ZN_PT(3);   // sizes + descriptor
   ZN_PT_COUNT(18, 1);
   ZN_PT_FLUSH();
@@ -480,7 +568,9 @@ struct ZnEmitLds {
 };
 
 // H = plane to Huffman-encode in this pass (or -1: raw planes only); raw planes are written when `do_raw`.
-template <int P, bool X>
+// NT: non-temporal loads of the chunk (the one-pass encoder's second read: what the histogram pass left in the Infinity Cache is used once and should not
+// be re-allocated; the emit kernel's plain loads are the measured better choice there — its four strided loads per tile share cache lines)
+template <int P, bool X, bool NT = false>
 __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __restrict__ chunk_src, const uint8_t* __restrict__ chunk_xr, uint8_t* __restrict__ body,
                                              const uint64_t (&off)[P], const uint32_t (&kind)[P], int H, bool do_raw,
                                              const ZnEncDesc* D, const uint32_t* code, uint32_t* buf, uint32_t lane, uint32_t wave) {
@@ -513,33 +603,34 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
     const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + RUN * lane);
     for (int k = 0; k < 2 * P; k++) {
       const uint8_t* ak = ZN_E_SPLIT ? a + (k >= P ? (uint64_t)P * HALF + 16 * (k - P) : 16 * k) : a + 16 * k;
-      const uint4 x = ZN_LD_EMIT(ak); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w;
+      const uint4 x = NT ? zn_ldnt128(ak) : ZN_LD_EMIT(ak); d[4 * k] = x.x; d[4 * k + 1] = x.y; d[4 * k + 2] = x.z; d[4 * k + 3] = x.w;
     }
     if (X && chunk_xr) {
       const uint8_t* xa = chunk_xr + (a - chunk_src);
       for (int k = 0; k < 2 * P; k++) {
         const uint8_t* xk = ZN_E_SPLIT ? xa + (k >= P ? (uint64_t)P * HALF + 16 * (k - P) : 16 * k) : xa + 16 * k;
-        const uint4 x = ZN_LD_EMIT(xk); d[4 * k] ^= x.x; d[4 * k + 1] ^= x.y; d[4 * k + 2] ^= x.z; d[4 * k + 3] ^= x.w;
+        const uint4 x = NT ? zn_ldnt128(xk) : ZN_LD_EMIT(xk); d[4 * k] ^= x.x; d[4 * k + 1] ^= x.y; d[4 * k + 2] ^= x.z; d[4 * k + 3] ^= x.w;
       }
     }
-    for (int k = 0; k < 8 * P; k++) d[k] = zn_rot_fwd<P>(d[k], g.rot);
+    // the lane's 32 elements plane by plane: pl[p][j] = byte p of elements 4 j .. 4 j + 3 (rotate at plane level, zn_split4)
+    uint32_t pl[P][8];
+    for (int j = 0; j < 8; j++) {
+      uint32_t t4[P];
+      zn_split4<P>(d + P * j, g.rot, t4);
+      for (int p = 0; p < P; p++) pl[p][j] = t4[p];
+    }
     // raw planes: 32 bytes per lane, contiguous across the wave
     if (do_raw) {
       for (int p = 0; p < P; p++) if (kind[p] == 0u) {
-        uint32_t o[8];
-        for (int j = 0; j < 8; j++) {
-          uint32_t v = 0;
-          for (int t = 0; t < 4; t++) { const int e = 4 * j + t, k = P * e + p; v |= ((d[k >> 2] >> (8 * (k & 3))) & 0xFFu) << (8 * t); }
-          o[j] = v;
-        }
+        const uint32_t* o = pl[p];
         uint8_t* r = body + off[p] + (uint64_t)wave * seg + (uint32_t)base + RUN * lane;
         uint8_t* r2 = ZN_E_SPLIT ? r + HALF : r + 16;                  // (the second run's 16 bytes / the second half of the one run)
-        zn_eu128u s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
 #if !defined(ZN_SIMT_EMULATOR)                  // non-temporal: the payload is written once and not read back here
         typedef uint32_t zn_ev4u_u __attribute__((ext_vector_type(4), aligned(1)));
         __builtin_nontemporal_store((zn_ev4u_u){o[0], o[1], o[2], o[3]}, (zn_ev4u_u*)r);
         __builtin_nontemporal_store((zn_ev4u_u){o[4], o[5], o[6], o[7]}, (zn_ev4u_u*)r2);
 #else
+        zn_eu128u s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
         *(zn_eu128u*)r = s0; *(zn_eu128u*)r2 = s1;
 #endif
       }
@@ -556,7 +647,7 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
         for (int t = 0; t < 2; t++) {
           const int e = 4 * i + 2 * h + t;
           uint32_t sym = 0;
-          for (int p = 0; p < P; p++) if (p == H) { const int k = P * e + p; sym = (d[k >> 2] >> (8 * (k & 3))) & 0xFFu; }
+          for (int p = 0; p < P; p++) if (p == H) sym = (pl[p][e >> 2] >> (8 * (e & 3))) & 0xFFu;
           cw[t] = code[sym];
         }
         pv[h] = ((cw[0] & 0xFFFFu) << (cw[1] >> 16)) | (cw[1] & 0xFFFFu);
@@ -781,6 +872,199 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
   if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
 }
 
+// ---------------------------------------------------------------------------
+// The ONE-PASS encoder (round 5): histogram, code table, placement and emit of a chunk by ONE workgroup — N + C of HBM traffic instead of 2 N + C.
+//
+// The plane-major wire format puts a chunk's bytes behind the stored sizes of ALL chunks of the earlier planes and of the earlier chunks of its own
+// plane, which is why the four-kernel encoder above reads the tensor twice (sizes first, bytes second).  Two observations remove the second HBM read:
+//   * what weights look like: every plane but the LAST is stored raw in every chunk (bf16 / fp16: the low byte; fp32: the three low bytes; fp8 has one
+//     plane), so the base of plane p is K · planeLen · p and only the last plane needs a running sum — over the chunks BEFORE it, which a workgroup gets
+//     by decoupled look-back: every workgroup publishes {generation | state | size} as ONE 64-bit word (a relaxed agent-scope store: flag and value travel
+//     together, no fence, no hand-over of anything else), first its own size, then — once it has summed its predecessors' words — the inclusive prefix.
+//     Chunks are handed out by a ticket counter, so a workgroup only ever waits for workgroups that started before it.  The speculation is CHECKED: a
+//     chunk whose earlier planes are not raw sets ZN_DEV_MISSPEC (and the size scan compares the last plane's base with the speculated one); the caller
+//     then runs the four-kernel encoder, which overwrites everything.
+//   * the second read of the chunk, 40-100 us after the first, is served by the 256 MB Infinity Cache IF the first read allocates there (plain loads)
+//     and the second does not (non-temporal loads): measured with the access pattern alone, scripts/ubench/mallbench.hip, profiles/r05_mall_reread.txt —
+//     N read + N re-read + 0.66 N written in 1.51 ms at 4 workgroups per CU and 40 us between the reads, against 2.07 ms when the second read comes from HBM.
+// One workgroup = the stats kernel's histogram pass (zn_stats_count), the table kernel's job on wave 0 (zn_table_job), the look-back on wave 0, the emit
+// kernel's pass (zn_emit_pass).  Types and stored sizes go to the same arrays; zn_k_scan_sizes writes the wire-format tables from them as before.
+// Replaces compression_worker + prepare_python_return_buffer for full chunks (reference csrc/zipnn_core.c:294-390, :105-244).
+// ---------------------------------------------------------------------------
+#if defined(ZN_SIMT_EMULATOR)
+#define ZN_LB_LOAD(p) (*(volatile const uint64_t*)(p))
+#define ZN_LB_STORE(p, v) (*(volatile uint64_t*)(p) = (v))
+#define ZN_LB_SLEEP() ((void)0)
+#else
+#define ZN_LB_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ZN_LB_STORE(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ZN_LB_SLEEP() __builtin_amdgcn_s_sleep(4)
+#endif
+#define ZN_LB_VBITS 40u                   // look-back word: generation (22 bits) | state (2 bits: 1 = own size, 2 = inclusive prefix) | value (40 bits)
+#define ZN_LB_VMASK ((1ull << ZN_LB_VBITS) - 1ull)
+
+#ifndef ZN_OP_WGS
+#define ZN_OP_WGS 5                      // one-pass workgroups per CU: the histogram's 32 KiB of LDS allow five, which leaves each wave 96 registers
+#endif
+#ifndef ZN_OP_NT2
+#define ZN_OP_NT2 1                      // the second read non-temporal (0: plain — it then allocates in the caches like the first)
+#endif
+#ifndef ZN_OP_NT1
+#define ZN_OP_NT1 0                      // (developer A/B: 1 = the first read non-temporal as well — nothing is left in the Infinity Cache for the second)
+#endif
+template <int P>
+struct ZnOnePassLds {
+  union {
+    ZnStatsLds<P> st;                                                   // phase 1: the histogram columns (32 KiB) — and the ticket, in its first word, before that
+    struct { ZnEncDesc D; uint32_t pad_; uint16_t qc[P][4][256];       // then: the last plane's descriptor, the planes' per-quarter counts,
+             union { ZnTablesLds tab; ZnEmitLds<P> em; } u;             //       the table job's scratch / the emit pass's buffers,
+             uint32_t kind[4], csz[4], rle[4], need[4];                 //       per plane: 0 raw / 1 RLE / 2 huff0, stored size, the RLE byte, "wants a code table"
+             uint64_t excl; } b;
+  };
+};
+
+template <int P, bool X>
+__global__ __launch_bounds__(ZN_E_THREADS, ZN_OP_WGS) void zn_k_encode_onepass(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
+                                                                    uint32_t* __restrict__ csize_all, uint8_t* __restrict__ type_all,
+                                                                    uint64_t* __restrict__ lb_all, uint32_t* __restrict__ ticket,
+                                                                    uint32_t* __restrict__ status, uint32_t gen) {
+  __shared__ ZnOnePassLds<P> L;
+  static_assert(sizeof(ZnOnePassLds<P>) * ZN_OP_WGS <= 160u * 1024u, "ZN_OP_WGS one-pass workgroups per CU");
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  if (tid == 0) L.st.hist[0][0] = atomicAdd(ticket, 1u);  // chunks in ticket order: whoever a workgroup waits for below has started before it
+  __syncthreads();
+  const uint32_t sbid = L.st.hist[0][0];
+  __syncthreads();                                        // (the histogram pass zeroes that word)
+  const ZnESeg S = zn_efind_chunk(one, segs, nseg, sbid);
+  const ZnGeom g = S.g;
+  const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
+  const float threshold = S.threshold;
+  uint32_t* __restrict__ csize_out = csize_all + S.pc0; uint8_t* __restrict__ type_out = type_all + S.pc0;
+  const uint64_t c = sbid - S.chunk0;
+  const uint32_t n = (uint32_t)(g.chunk / P);
+  const uint8_t* chunk_src = src + c * g.chunk;
+  const uint8_t* chunk_xr = (X && S.xr) ? ZN_GLOBAL_PTR(const uint8_t, S.xr) + c * g.chunk : nullptr;
+  ZN_PT_DECL;
+  ZN_PT(10);  // ticket + segment
+
+  // ---- 1. histograms (plain loads: the lines stay in the Infinity Cache for step 4), 2. per plane: the cheap exits of HUF_compress ----
+  {
+    uint32_t tot[P], qc[P][4];
+    zn_stats_count<P, X, ZN_OP_NT1 != 0>(L.st, g, chunk_src, chunk_xr, tid, lane, tot, qc);
+    ZN_PT(11);  // histograms
+    uint32_t (*red_mx)[4] = (uint32_t (*)[4])&L.st.hist[0][0];
+    uint32_t (*red_hi)[4] = red_mx + P;
+    for (int p = 0; p < P; p++) {
+      uint32_t mx = tot[p], hi = tot[p] ? tid : 0u;
+      for (int d = 32; d >= 1; d >>= 1) { const uint32_t m2 = __shfl_xor(mx, d), h2 = __shfl_xor(hi, d); if (m2 > mx) mx = m2; if (h2 > hi) hi = h2; }
+      if (lane == 0) { red_mx[p][wave] = mx; red_hi[p][wave] = hi; }
+    }
+    __syncthreads();
+    if (tid < (uint32_t)P) {
+      const uint32_t p = tid;
+      uint32_t mx = 0, hi = 0;
+      for (int w = 0; w < 4; w++) { if (red_mx[p][w] > mx) mx = red_mx[p][w]; if (red_hi[p][w] > hi) hi = red_hi[p][w]; }
+      uint32_t kind = 0, cs = n, need = 0;
+      if (mx == n) { if (1.0 < (double)n * (double)threshold) { kind = 1; cs = 1u; } }            // RLE (threshold rule of compression_worker, zipnn_core.c:371-385)
+      else if (mx > (n >> 7) + 4u) need = 1;                                                      // (else: "probably not compressible", stored raw)
+      L.b.kind[p] = kind; L.b.csz[p] = cs; L.b.rle[p] = hi; L.b.need[p] = need;
+    }
+    __syncthreads();                             // (the maxima are read: the histogram's memory is free)
+    for (int p = 0; p < P; p++) for (int q = 0; q < 4; q++) L.b.qc[p][q][tid] = (uint16_t)qc[p][q];
+    __syncthreads();
+  }
+  ZN_PT(12);  // decisions + counts to LDS
+  // ---- … or a code table: one job after the other on wave 0 (nearly always the last plane's alone) ----
+  if (wave == 0) {
+    bool failed = false;                         // the speculation: a plane in front of the last one is kept
+#pragma nounroll
+    for (int p = 0; p < P; p++) {
+      if (p < P - 1 && L.b.kind[p]) failed = true;
+      if (!L.b.need[p] || failed) continue;        // (after a failure the work is thrown away anyway)
+      uint32_t ty = 0, cs = n;
+      zn_table_job<false>(L.b.u.tab, L.b.qc[p], n, g.chunk, threshold, S.legacy_weights != 0, false, &L.b.D, lane, ty, cs ZN_PT_PASS);
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) { L.b.kind[p] = ty ? 2u : 0u; L.b.csz[p] = cs; }
+      __builtin_amdgcn_wave_barrier();
+      if (p < P - 1 && ty) failed = true;
+    }
+    if (lane < (uint32_t)P) { const uint64_t pc = (uint64_t)lane * g.K + c; type_out[pc] = L.b.kind[lane] ? 1 : 0; csize_out[pc] = L.b.csz[lane]; }
+  }
+  __syncthreads();
+  ZN_PT(13);  // rest of the table job + barrier
+  uint32_t kind[P];
+  bool spec_ok = true;
+  for (int p = 0; p < P; p++) { kind[p] = L.b.kind[p]; if (p < P - 1 && kind[p]) spec_ok = false; }
+  const uint32_t csz_last = L.b.csz[P - 1];
+  if (!spec_ok && tid == 0) atomicOr(status, ZN_DEV_MISSPEC);
+
+  // ---- 3. where the last plane's bytes go: decoupled look-back over the chunks before this one (wave 0) ----
+  // (published on the failed path as well: the workgroups behind this one wait for the word)
+  if (wave == 0) {
+    uint64_t* lb = lb_all + sbid;
+    const uint64_t tag = (uint64_t)gen << (ZN_LB_VBITS + 2u);
+    const uint64_t mine = csz_last;
+    uint64_t excl = 0;
+#if defined(ZN_OP_FAKE_LB)                          /* developer timing probe (wrong offsets): what the kernel costs without the wait for its predecessors */
+    if (true) { excl = c * 44000ull; }
+    else
+#endif
+    if (c == 0) { if (lane == 0) ZN_LB_STORE(lb, tag | (2ull << ZN_LB_VBITS) | mine); }
+    else {
+      if (lane == 0) ZN_LB_STORE(lb, tag | (1ull << ZN_LB_VBITS) | mine);
+      int64_t j0 = (int64_t)c - 1;               // lane l looks at chunk j0 - l (of this tensor)
+      for (;;) {
+        const int64_t j = j0 - (int64_t)lane;
+        uint32_t fi;
+        uint64_t v;
+        for (;;) {
+          v = (j >= 0) ? ZN_LB_LOAD(lb - (c - (uint64_t)j)) : (tag | (2ull << ZN_LB_VBITS));       // in front of the tensor's first chunk: an inclusive prefix of zero
+          const bool ready = (v >> (ZN_LB_VBITS + 2u)) == (uint64_t)gen && ((v >> ZN_LB_VBITS) & 3ull) != 0ull;
+          const bool incl = ready && ((v >> ZN_LB_VBITS) & 3ull) == 2ull;
+          const uint64_t im = __ballot(incl), nm = __ballot(!ready);
+          fi = im ? (uint32_t)__builtin_ctzll(im) : 64u;                    // the nearest predecessor with an inclusive prefix
+          const uint64_t upto = fi >= 63u ? ~0ull : ((2ull << fi) - 1ull);     // lanes 0 .. fi
+          if (!(nm & upto)) break;               // everything up to it is published
+          ZN_LB_SLEEP();
+        }
+        excl += zn_wave_sum64_e((lane <= fi) ? (v & ZN_LB_VMASK) : 0ull);
+        if (fi < 64u) break;
+        j0 -= 64;
+      }
+      if (lane == 0) ZN_LB_STORE(lb, tag | (2ull << ZN_LB_VBITS) | ((excl + mine) & ZN_LB_VMASK));
+    }
+    if (lane == 0) L.b.excl = excl;
+  }
+  __syncthreads();
+  ZN_PT(14);  // look-back
+  if (!spec_ok) return;
+
+  // ---- 4. emit: the chunk again (Infinity Cache), raw planes to their speculated places, the last plane behind its predecessors ----
+  uint64_t off[P];
+  {
+    const uint64_t last_len = g.n - (g.K - 1u) * g.chunk;           // (K >= 1: this tensor has a full chunk)
+    uint64_t base = 9ull * P * g.K;
+    for (int p = 0; p < P; p++) {
+      off[p] = base + ((p < P - 1) ? c * (uint64_t)n : L.b.excl);
+      base += (g.K - 1u) * (uint64_t)n + zn_plane_len((uint32_t)last_len, (uint32_t)P, (uint32_t)p);
+    }
+  }
+  const int H = (kind[P - 1] == 2u) ? P - 1 : -1;
+  if (kind[P - 1] == 1u && tid == 0) body[off[P - 1]] = (uint8_t)L.b.rle[P - 1];
+  if (H >= 0) {                                  // tree description + jump table, the code table for the pass
+    const uint32_t hl = L.b.D.hdr_len;
+    for (uint32_t i = tid; i < hl; i += ZN_E_THREADS) body[off[P - 1] + i] = L.b.D.hdr[i];
+    if (tid < 3u) { const uint32_t s = L.b.D.ssize[tid]; body[off[P - 1] + hl + 2u * tid] = (uint8_t)s; body[off[P - 1] + hl + 2u * tid + 1u] = (uint8_t)(s >> 8); }
+    L.b.u.em.code[tid] = L.b.D.code[tid];        // (the table job's scratch is dead: the barrier behind the look-back)
+    __syncthreads();
+  }
+  const bool ok = zn_emit_pass<P, X, ZN_OP_NT2 != 0>(g, chunk_src, chunk_xr, body, off, kind, H, true, &L.b.D, L.b.u.em.code, L.b.u.em.buf[wave], lane, wave);
+  if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
+  ZN_PT(15);  // emit
+  ZN_PT_COUNT(17, 1);
+  ZN_PT_FLUSH();
+}
+
 #ifdef ZN_PHASE_TIMERS
 extern "C" int zn_debug_phase_read_enc(unsigned long long* out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
@@ -827,4 +1111,14 @@ void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs,
   else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
 #undef ZN_GO
   zn_note_kernel(delta ? (total_ptails ? "zn_k_encode_emit^delta+tail" : "zn_k_encode_emit^delta") : (total_ptails ? "zn_k_encode_emit+tail" : "zn_k_encode_emit"));
+}
+
+void zn_launch_encode_onepass(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t* d_csize, uint8_t* d_type,
+                              uint64_t* d_lb, uint32_t* d_ticket, uint32_t* d_status, uint32_t gen, bool delta, hipStream_t stream) {
+  if (total_chunks == 0) return;
+#define ZN_GO(P_, X_) hipLaunchKernelGGL((zn_k_encode_onepass<P_, X_>), dim3(total_chunks), dim3(ZN_E_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_lb, d_ticket, d_status, gen)
+  if (!delta) { if (P == 1) ZN_GO(1, false); else if (P == 2) ZN_GO(2, false); else ZN_GO(4, false); }
+  else { if (P == 1) ZN_GO(1, true); else if (P == 2) ZN_GO(2, true); else ZN_GO(4, true); }
+#undef ZN_GO
+  zn_note_kernel(delta ? "zn_k_encode_onepass^delta" : "zn_k_encode_onepass");
 }

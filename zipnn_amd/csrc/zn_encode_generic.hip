@@ -25,7 +25,7 @@ __device__ __forceinline__ uint64_t zn_wave_sum64(uint64_t v) {
 }
 __global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnESeg one, const ZnESeg* __restrict__ segs, uint32_t nseg,
                                                                    const uint32_t* __restrict__ csize_all, const uint8_t* __restrict__ type_all,
-                                                                   uint64_t* __restrict__ offs_all, uint64_t* __restrict__ total_all) {
+                                                                   uint64_t* __restrict__ offs_all, uint64_t* __restrict__ total_all, uint32_t* __restrict__ spec_status) {
   const ZnESeg S = zn_efind_scan(one, segs, nseg, blockIdx.x);
   const ZnGeom g = S.g; const uint64_t T = S.T;
   const uint32_t* __restrict__ csize = csize_all + S.pc0; const uint8_t* __restrict__ type = type_all + S.pc0;
@@ -80,6 +80,14 @@ __global__ __launch_bounds__(ZN_SCAN_THREADS) void zn_k_scan_sizes(ZnESeg one, c
       for (uint32_t q = 0; q < 4u; q++) if (q == p) pb = known[q];
       if ((uint64_t)p * K >= i0) pb = pb_s[p];
       offs[i] = base + x;
+      // the one-pass encoder placed the last plane behind P - 1 planes stored raw in every chunk: a stored size is never larger than its plane, so the
+      // sum in front of the last plane is the speculated one exactly when no plane in front of it was stored any other way
+      if (spec_status && S.nfull && g.P > 1u && i == (uint64_t)(g.P - 1u) * K) {
+        const uint32_t last_len = (uint32_t)(g.n - (K - 1u) * g.chunk);
+        uint64_t want = 0;
+        for (uint32_t q = 0; q + 1u < g.P; q++) want += (K - 1u) * (g.chunk / g.P) + zn_plane_len(last_len, g.P, q);
+        if (x != want) atomicOr(spec_status, ZN_DEV_MISSPEC);
+      }
       const uint64_t c = x + v - pb;
       if (aligned) *(uint64_t*)(cum + 8u * i) = c; else zn_st64(cum + 8u * i, c);
       body[i] = ty;
@@ -97,9 +105,9 @@ void zn_scan_geometry(uint64_t PK, uint64_t* T_out, uint32_t* blocks) {
 }
 
 void zn_launch_scan_sizes(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_blocks, const uint32_t* d_csize,
-                          const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, hipStream_t stream) {
+                          const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, uint32_t* d_spec_status, hipStream_t stream) {
   if (total_blocks == 0) return;
-  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(total_blocks), dim3(ZN_SCAN_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_total);
+  hipLaunchKernelGGL(zn_k_scan_sizes, dim3(total_blocks), dim3(ZN_SCAN_THREADS), 0, stream, one, d_segs, nseg, d_csize, d_type, d_offs, d_total, d_spec_status);
   zn_note_kernel("zn_k_scan_sizes");
 }
 

@@ -96,8 +96,14 @@ void zn_launch_encode_fused_emit(int P, const ZnESeg& one, const ZnESeg* d_segs,
                                  const uint32_t* d_csize, const uint8_t* d_type, const uint64_t* d_offs, const ZnEncDesc* d_descs,
                                  uint32_t* d_status, bool delta, hipStream_t stream);
 // per-tensor scan over ALL its chunks: types, cumSizes (into the body), payload offsets, total body length → d_total[total_idx]
+// d_spec_status (may be null): the launch's full chunks went through the one-pass encoder — the scan checks its layout speculation (the last plane starts where
+// all-raw earlier planes put it) and sets ZN_DEV_MISSPEC there when it does not hold
 void zn_launch_scan_sizes(const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_blocks, const uint32_t* d_csize,
-                          const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, hipStream_t stream);
+                          const uint8_t* d_type, uint64_t* d_offs, uint64_t* d_total, uint32_t* d_spec_status, hipStream_t stream);
+// the one-pass encoder over the launch's total_chunks full chunks (zn_k_encode_onepass): d_lb = total_chunks look-back words, d_ticket = a zeroed counter,
+// gen = the launch's generation tag (1 .. 2^22 - 1)
+void zn_launch_encode_onepass(int P, const ZnESeg& one, const ZnESeg* d_segs, uint32_t nseg, uint32_t total_chunks, uint32_t* d_csize, uint8_t* d_type,
+                              uint64_t* d_lb, uint32_t* d_ticket, uint32_t* d_status, uint32_t gen, bool delta, hipStream_t stream);
 void zn_scan_geometry(uint64_t PK, uint64_t* T, uint32_t* blocks);     // entries per block / number of blocks for PK entries
 
 // kernel-name log for zn_last_kernels()
