@@ -18,10 +18,11 @@ def load(path):
 def main():
     paths = sys.argv[1:]
     libs = [(os.path.basename(p), load(p)) for p in paths]
-    C = 262144
-    cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16), ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32), ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16)]
+    C0 = 262144
+    cases = [("bf16 4GiB", 4 << 30, 2, 1, 10, torch.bfloat16), ("fp32 1GiB", 1 << 30, 4, 1, 220, torch.float32), ("fp16 1GiB", 1 << 30, 2, 0, 10, torch.float16), ("fp8 1GiB", 1 << 30, 1, 0, 10, torch.float8_e4m3fn)]
     st = torch.cuda.current_stream().cuda_stream
     for name, n, P, rot, bm, dt in cases:
+        C = C0 if P > 1 else 131072
         es = torch.empty(0, dtype=dt).element_size()
         x = torch.empty(n // es, dtype=dt, device="cuda")
         g = torch.Generator(device="cuda"); g.manual_seed(5)

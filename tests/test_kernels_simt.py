@@ -264,7 +264,8 @@ TAILS = [("bf16", C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 1
 @pytest.mark.parametrize("case", TAILS, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
 def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
     """A big partial last chunk: its Huffman planes are decoded by the tail workgroups of zn_k_decode_fused (4 ragged streams into padded
-    scratch), the merge kernel interleaves; tiny / raw tails stay on the serial path.  Output == input."""
+    scratch), merge workgroups at the end of the SAME launch classify the chunk's planes and interleave them (round 5: the two generic launches
+    behind every ragged tensor are gone); tiny / raw tails are decoded serially by those workgroups.  Output == input."""
     kind, nb, P, rot, bm, chunk, want_tail_planes = case
     d = _gen2(kind, nb, 17)
     frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
@@ -272,7 +273,8 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
     out = torch.empty(nb, dtype=torch.uint8)
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
     assert out.numpy().tobytes() == d
-    assert simt_lib.last_kernels().split(";")[0] in ("zn_k_decode_fused+tail", "zn_k_decode_wide+tail")     # (wide: calls of at most one full chunk per CU)
+    # one launch: tail workgroups at its front, the chunk's merge workgroups at its end, no generic kernels behind it
+    assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
     assert simt_lib.last_tail_planes() == want_tail_planes
 
 
@@ -865,7 +867,7 @@ def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(s
     dt = d1 + d1[:1000]                                                             # a partial last chunk: its tail workgroup + merge set the pace either way
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
-    assert simt_lib.last_kernels().startswith("zn_k_decode_fused+tail;")
+    assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"            # (… inside ONE launch since round 5)
     f16 = O.compress_frame(HDR, d1, 2, 0, 10, C)                                    # no sign rotate (an fp16 layout): not in automatic mode
     assert bytes(simt_lib.decompress(f16[32:], 2, 0, 10, C, len(d1))) == d1
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest"

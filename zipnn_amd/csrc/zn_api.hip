@@ -419,7 +419,8 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if ((rc = ws_reserve(w, WS_ENC, all_pk))) return rc;                       // … and the same per (plane, chunk)
   const uint64_t all_tail = tail_of[0] + tail_of[1] + tail_of[2];
   if ((rc = ws_reserve(w, WS_PLANES, all_tail * ZN_TAIL_SLOT))) return rc;   // decoded Huffman planes of partial last chunks
-  if ((rc = ws_reserve(w, WS_META_A, all_tail))) return rc;                  // … and whether the tail kernel produced them
+  const size_t sync_off = (all_tail + 15u) & ~(size_t)15u;                   // … and whether the tail kernel produced them; behind that two flag words per tensor with a partial chunk
+  if ((rc = ws_reserve(w, WS_META_A, sync_off + 2u * sizeof(uint32_t) * all_tail))) return rc;
   if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
   if ((rc = ws_host_words(w))) return rc;
   if (table) {
@@ -436,7 +437,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   // status + the three "left to the generic kernels" counters (a wide call: its first kernel zeroes them)
   bool status_zeroed = false;
   if (!wide || all_tail) { ZN_HIP(hipMemsetAsync(d_status, 0, 4 * sizeof(uint32_t), stream)); status_zeroed = true; }
-  if (all_tail) ZN_HIP(hipMemsetAsync(w.buf[WS_META_A], 0, all_tail, stream));
+  if (all_tail) ZN_HIP(hipMemsetAsync(w.buf[WS_META_A], 0, sync_off + 2u * sizeof(uint32_t) * all_tail, stream));
   if (table) {
     // the previous batched call may still be reading the pinned staging: wait for it on the host
     ZN_HIP(hipEventSynchronize(w.busy));
@@ -457,7 +458,8 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     // (behind the wide kernel, in launches without partial chunks, the fused kernel's rest instance also does the generic kernels' job)
     const bool rest = zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
-                                             d_tail_done, delta_of[q], wide, status_zeroed, rest_ok[q] ? d_descs : nullptr, stream);
+                                             d_tail_done, delta_of[q], wide, status_zeroed, rest_ok[q] ? d_descs : nullptr,
+                                             tail_of[q] ? (uint32_t*)((uint8_t*)w.buf[WS_META_A] + sync_off) + 2u * tail_base : nullptr, stream);
     status_zeroed = true;
     if (!rest) zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
     seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];

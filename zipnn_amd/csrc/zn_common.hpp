@@ -34,6 +34,38 @@
 
 __device__ __forceinline__ uint32_t zn_hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 
+// Hand-over of a result between workgroups of ONE launch (MI355X_MICROARCH.md, inter-workgroup visibility): the producer's stores, a workgroup barrier,
+// then on one lane an agent-scope release fence, a drained store queue and a relaxed agent-scope update of the flag word; the consumer polls the word with
+// relaxed agent-scope loads on one lane (bounded: a launch never hangs on a flag), then an agent-scope acquire fence and a workgroup barrier before its loads.
+#if defined(ZN_SIMT_EMULATOR)
+#define ZN_FLAG_LOAD32(p) (*(volatile const uint32_t*)(p))
+#define ZN_FLAG_ADD32(p, v) (*(volatile uint32_t*)(p) += (v))
+#define ZN_FLAG_RELEASE() ((void)0)
+#define ZN_FLAG_ACQUIRE() ((void)0)
+#define ZN_FLAG_NAP() ((void)0)
+#define ZN_FLAG_CLOCK() 0ull
+#else
+#define ZN_FLAG_LOAD32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ZN_FLAG_ADD32(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ZN_FLAG_RELEASE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+#define ZN_FLAG_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define ZN_FLAG_NAP() __builtin_amdgcn_s_sleep(8)
+#define ZN_FLAG_CLOCK() __builtin_amdgcn_s_memrealtime()      /* 100 MHz */
+#endif
+// lane 0 of the calling wave waits until *p >= want; false after two seconds (the caller reports it: never a hang)
+__device__ __forceinline__ bool zn_flag_wait(const uint32_t* p, uint32_t want) {
+  const unsigned long long t0 = ZN_FLAG_CLOCK();
+  for (;;) {
+    if (ZN_FLAG_LOAD32(p) >= want) return true;
+#if defined(ZN_SIMT_EMULATOR)
+    return false;                                /* (blocks run one after the other: a flag that is not there yet never comes) */
+#else
+    if (ZN_FLAG_CLOCK() - t0 > 200000000ull) return false;
+    ZN_FLAG_NAP();
+#endif
+  }
+}
+
 // Byte-granular loads for metadata and bit-stream heads/tails, where the address has
 // no alignment guarantee (payload offsets are sums of arbitrary compressed sizes).
 __device__ __forceinline__ uint32_t zn_ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }

@@ -606,7 +606,8 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         ZN_PT_COUNT(17, __popcll(__ballot(mism)));
         ZN_DBG_COUNT(2);
         if (it == 0) note_mismatch();
-        if (mism) s = e_prev;                  // (every lane decodes again: the lanes run in lock-step anyway)
+        if (mism) s = e_prev;                  // (every lane decodes again: the lanes run in lock-step anyway; round 5 tried the mismatching lanes alone, exec-masked,
+                                               //  for the dense instance: fp8 1.354 vs 1.202 ms, fp16 0.576 vs 0.559 — the masks cost more than the conflict-free look-ups save)
       }
       if (DC) ZN_ASM_MARK("ZN_MARK scan");
       if (took && chained) {
@@ -742,9 +743,10 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
 // (b = index of the tail workgroup inside the launch; runs as the FIRST workgroups of zn_k_decode_fused, so that
 // the one-workgroup job overlaps the decode of the full chunks instead of following it)
 __device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t b,
-                                  uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status) {
+                                  uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status, uint32_t* tail0_out) {
   ZnFusedLds& L = *ZN_LDS_PTR(ZnFusedLds, &L_);     // (this is a real call: keep the LDS accesses DS operations)
   const ZnSeg S = zn_find_seg<3>(one, segs, nseg, b);
+  *tail0_out = S.tail0;
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body); const uint64_t body_len = S.body_len;
   const uint8_t* body_end = body + body_len;
@@ -873,15 +875,57 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                   uint32_t* __restrict__ status, uint32_t ntail,
                                                                   uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done, uint32_t only_pending,
-                                                                  ZnPlaneDesc* __restrict__ descs_rest) {
+                                                                  ZnPlaneDesc* __restrict__ descs_rest, uint32_t nchunk_wg, uint32_t merge_per,
+                                                                  uint32_t* __restrict__ tailsync) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnFusedLds L;
 
+  // Round 5: the partial last chunk of a tensor is FINISHED inside this launch (REST instance, tailsync != null).  Its Huffman planes are decoded by the tail
+  // workgroups at the front of the grid, as before; `merge_per` workgroups per such tensor at the END of the grid wait for them (tailsync[2 t]: tail workgroups of
+  // tensor t that are through), classify the chunk's planes (the generic path's own item function, every one for itself) and merge its planes into the output
+  // (the generic merge's item function, its 64 sub-ranges dealt out) — the two generic launches behind every call of a ragged tensor (20-30 us) are gone.
+  // The tail workgroups have the lowest block indices and the merge workgroups are few: the wait is for workgroups that run or have run (and it is bounded).
+  if (REST && tailsync && blockIdx.x >= ntail + nchunk_wg) {
+    const uint32_t m = blockIdx.x - (ntail + nchunk_wg), tt = m / merge_per, jm = m % merge_per;
+    const ZnSeg one_c = one;
+    const ZnSeg S = zn_find_seg<3>(one_c, segs, nseg, (uint64_t)tt * (uint32_t)P);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint64_t c = S.g.K - 1u;
+    __shared__ uint32_t ok_s, serial_s;
+    if (tid == 0) { ok_s = zn_flag_wait(tailsync + 2u * tt, (uint32_t)P) ? 1u : 0u; serial_s = 0; ZN_FLAG_ACQUIRE(); }      // (one lane's acquire drops this CU's L1 lines: the tail workgroups' bytes come from L2)
+    __syncthreads();
+    if (!ok_s) { if (tid == 0) atomicOr(status, ZN_DEV_CORRUPT); return; }
+    static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS");
+    // every merge workgroup classifies the chunk's planes for itself (the same descriptors from all of them: raw / RLE / decoded by the tail workgroups) …
+    if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane, true, &serial_s);
+    __syncthreads();
+    if (tid == 0) ZN_FLAG_ACQUIRE();             // (the descriptors were written by other waves of this CU: read them from L2, not from a stale L1 line)
+    __syncthreads();
+    uint32_t sub = jm, nsub = merge_per;           // this workgroup's share of the chunk's words
+    if (serial_s) {
+      // … unless a huff0 plane is left for the serial decoder (a tiny plane, tableLog 12, a block the tail workgroup gave up on): ONE workgroup does the chunk
+      if (jm != 0u) return;
+      if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane);
+      __threadfence(); __syncthreads();
+      sub = 0; nsub = 1;
+    }
+    zn_merge_chunk_item<P>(one_c, segs, nseg, S.chunk0 + c, sub, descs_rest, tail_scratch, nsub);
+    return;
+  }
+
   // (`one` goes to the real functions of the cold paths — the tail workgroups, the rest instance's generic code — as a COPY made on that path: with its own
   //  address escaping, the by-value kernel argument lived in private memory and EVERY thread of EVERY workgroup stored its 96 bytes to scratch in the prologue and
   //  loaded them back — 24 KB of HBM writes per workgroup, 2.4 % of the kernel's writes at 4 GiB, 11 % at 64 MiB; profiles/r04_decode_experiments.txt)
-  if (blockIdx.x < ntail) { const ZnSeg one_c = one; zn_decode_tail_wg(L, one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status); return; }
+  if (blockIdx.x < ntail) {
+    const ZnSeg one_c = one; uint32_t tail0 = 0;
+    zn_decode_tail_wg(L, one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status, &tail0);
+    if (REST && tailsync) {                      // (every tail workgroup of the tensor reports, whatever it found: the merge workgroups count them)
+      __syncthreads();
+      if (threadIdx.x == 0) { ZN_FLAG_RELEASE(); ZN_FLAG_ADD32(tailsync + 2u * (tail0 / (uint32_t)P), 1u); }
+    }
+    return;
+  }
   const uint32_t wg = blockIdx.x - ntail;      // workgroup index among the full-chunk groups
   // (the segment comes back through private memory — a kernel argument or a table entry, chosen at run time — which makes
   //  every field per-lane data to the compiler: 64-bit pointers in vector registers, spilled and reloaded once per chunk,
@@ -968,6 +1012,10 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     if (j > 0) __syncthreads();              // the previous chunk's tables are no longer in use
     ZN_PT(21);  // wait for the slowest wave of the previous chunk
     const uint32_t what = zn_uniform(L.what[j]);          // (what comes out of LDS or HBM below is wave-uniform: scalar registers, scalar branches)
+    if (REST && tailsync && what == 0u && S.has_tail && c == g.K - 1u) {              // the partial last chunk: the tail + merge workgroups of this launch
+      if (tid == 0) done[c] = 0; if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + c] = 0;
+      continue;
+    }
     if (what == 0u) { ZN_REST_CHUNK(c); ZN_SET_DONE(c, 0); continue; }
     const int h = (int)what - 2;
     ZnFusedPlane pl[P];
@@ -1113,10 +1161,16 @@ extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
 
 bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, hipStream_t stream) {
-  // the rest instance: every launch without tail workgroups and delta bases (its tile loops run as fast as the plain instance's — measured, 160 MiB .. 4 GiB —
-  // and the two generic launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9)
-  if (!(ntail == 0 && !delta)) d_descs_rest = nullptr;
+                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, uint32_t* d_tailsync, hipStream_t stream) {
+  // the rest instance: every launch without delta bases (its tile loops run as fast as the plain instance's — measured, 160 MiB .. 4 GiB — and the two generic
+  // launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9); partial last chunks (ntail > 0) are finished by merge workgroups at the
+  // end of the same launch (d_tailsync: two zeroed words per tensor with a partial chunk) — except behind the wide kernel, which keeps the generic launches
+  if (delta || (ntail != 0 && (wide || !d_tailsync))) d_descs_rest = nullptr;
+  const uint32_t ntt = ntail / (uint32_t)P;      // tensors with a partial last chunk
+  uint32_t merge_per = 0;
+  if (d_descs_rest && ntail) { merge_per = 32u; while (merge_per > 1u && (uint64_t)merge_per * ntt > 4096u) merge_per >>= 1; }
+  else d_tailsync = nullptr;
+  const uint32_t nchunk_wg = total_wg;
   if (total_wg == 0) return false;
   const uint32_t only_pending = wide ? 1u : 0u;
   if (wide) {
@@ -1130,11 +1184,12 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
     ntail = 0;                                   // (done: the launch below has none)
   }
   total_wg += ntail;                             // the tail workgroups come first
-#define ZN_GO(P_, X_, R_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_, R_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, only_pending, d_descs_rest)
+  total_wg += merge_per * ntt;                   // … and the merge workgroups of the partial chunks last
+#define ZN_GO(P_, X_, R_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_, R_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, only_pending, d_descs_rest, nchunk_wg, merge_per, d_tailsync)
   if (d_descs_rest) { if (P == 1) ZN_GO(1, false, true); else if (P == 2) ZN_GO(2, false, true); else ZN_GO(4, false, true); }
   else if (!delta) { if (P == 1) ZN_GO(1, false, false); else if (P == 2) ZN_GO(2, false, false); else ZN_GO(4, false, false); }
   else { if (P == 1) ZN_GO(1, true, false); else if (P == 2) ZN_GO(2, true, false); else ZN_GO(4, true, false); }
 #undef ZN_GO
-  zn_note_kernel(d_descs_rest ? "zn_k_decode_fused^rest" : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
+  zn_note_kernel(d_descs_rest ? (ntail ? "zn_k_decode_fused^rest+tail+merge" : "zn_k_decode_fused^rest") : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
   return d_descs_rest != nullptr;
 }

@@ -57,7 +57,7 @@ struct ZnPlanesLds {
 // several waves of a workgroup may each run an item of their own on an LDS instance of their own)
 __device__ inline void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b,
                                             ZnPlaneDesc* __restrict__ descs_all, uint32_t* __restrict__ status,
-                                            const uint8_t* __restrict__ tail_done, uint32_t lane) {
+                                            const uint8_t* __restrict__ tail_done, uint32_t lane, bool classify_only = false, uint32_t* wants_serial = nullptr) {
   uint16_t* lut = L.lut; uint8_t* sh_w = L.sh_w; uint8_t* sh_symlist = L.sh_symlist; uint8_t* sh_cell = L.sh_cell;
   uint32_t* sh_rank_start = L.sh_rank_start; uint32_t* sh_sym_start = L.sh_sym_start;
   const ZnSeg S = zn_find_seg<1>(one, segs, nseg, b);
@@ -87,6 +87,9 @@ __device__ inline void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, co
     d.kind = ZN_KIND_HUFS; d.off = (uint64_t)(S.tail0 + p) * ZN_TAIL_SLOT;       // already decoded by the tail workgroups of zn_k_decode_fused
   }
 
+  // classify_only (the merge workgroups of a partial last chunk, zn_k_decode_fused: every one of them classifies for itself): a huff0 block that is still to be
+  // decoded serially is reported instead (*wants_serial, LDS: one of the workgroups then does the whole chunk) and nothing is written
+  if (classify_only && !bad && d.kind == ZN_KIND_HUF) { if (lane == 0) atomicOr(wants_serial, 1u); return; }
   if (!bad && d.kind == ZN_KIND_HUF) {
     const uint8_t* src = body + m.off;
     const ZnWaveStats st = zn_wave_read_stats(src, m.csize, body + body_len, lane, sh_w, sh_symlist, sh_rank_start, sh_sym_start, sh_cell);
@@ -135,7 +138,7 @@ __device__ __forceinline__ uint32_t zn_plane_byte(const ZnPlaneDesc& d, const ui
 template <int P>
 #define ZN_MERGE_SUB 64u      // a chunk is merged by 64 workgroup-items (one not-done chunk = a partial tail: 250 µs by one workgroup, 45 µs by 16, four byte-gathering iterations per thread by 64)
 __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint64_t b, uint32_t sub,
-                                                    const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ tails) {
+                                                    const ZnPlaneDesc* __restrict__ descs_all, const uint8_t* __restrict__ tails, uint32_t nsub = ZN_MERGE_SUB) {
   const ZnSeg S = zn_find_seg<2>(one, segs, nseg, b);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ body = ZN_GLOBAL_PTR(const uint8_t, S.body);
@@ -149,7 +152,7 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
   for (int p = 0; p < P; p++) d[p] = descs[(uint64_t)p * g.K + c];
   const uint32_t nwords = clen / 4u;
   // whole 32-bit words: gather P-way, undo the rotate (applies to clen/4 words — all of them)
-  const uint32_t w_lo = (uint32_t)(((uint64_t)nwords * sub) / ZN_MERGE_SUB), w_hi = (uint32_t)(((uint64_t)nwords * (sub + 1u)) / ZN_MERGE_SUB);
+  const uint32_t w_lo = (uint32_t)(((uint64_t)nwords * sub) / nsub), w_hi = (uint32_t)(((uint64_t)nwords * (sub + 1u)) / nsub);      // (sub-range `sub` of `nsub`)
   for (uint32_t wi = w_lo + threadIdx.x; wi < w_hi; wi += blockDim.x) {
     uint32_t w = 0;
     for (uint32_t t = 0; t < 4; t++) {
@@ -163,7 +166,7 @@ __device__ __forceinline__ void zn_merge_chunk_item(const ZnSeg& one, const ZnSe
     else for (uint32_t t = 0; t < 4; t++) out[4ull * wi + t] = (uint8_t)(w >> (8 * t));
   }
   // trailing clen % 4 bytes are never rotated (reference rotates len/4 words only)
-  if (sub == ZN_MERGE_SUB - 1u && threadIdx.x < (clen & 3u)) {
+  if (sub == nsub - 1u && threadIdx.x < (clen & 3u)) {
     const uint32_t j = 4u * nwords + threadIdx.x;
     out[j] = (uint8_t)(zn_plane_byte(d[j % P], body, out, tails, j, j / P) ^ (xo ? (uint32_t)xo[j] : 0u));
   }

@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, cons
   if (blockIdx.x < ntail) {
     if (threadIdx.x >= ZN_F_THREADS) return;
     const ZnSeg one_c = one;                       // (a copy on this path only: see zn_k_decode_fused)
-    zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status);
+    uint32_t tail0_unused = 0;
+    zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status, &tail0_unused);
     return;
   }
   const uint32_t wg = blockIdx.x - ntail;

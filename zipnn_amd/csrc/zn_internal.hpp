@@ -44,7 +44,8 @@ uint32_t zn_decode_fused_group(uint64_t K);     // chunks per workgroup for a te
 // tail_done[i] = 1 where that worked — the generic kernels take it from there.
 bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32_t nseg, uint32_t total_wg,
                             uint8_t* d_done, uint8_t* d_pdone, uint32_t* d_status, uint32_t ntail, uint8_t* d_tail_scratch,
-                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
+                            uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, uint32_t* d_tailsync, hipStream_t stream);     // delta: some tensor of the launch has ZnSeg::xr
+// d_tailsync (may be null): two zeroed words per tensor with a partial last chunk — with d_descs_rest the launch then finishes those chunks itself (merge workgroups at its end)
 // wide = 4 / 2 (waves per stream): the launch's segments have ncg == 1 and zn_k_decode_wide (zn_decode_wide.hpp, small inputs) goes first;
 // !status_zeroed: … and zeroes the status words (the call's first launch: the caller then leaves out its memset);
 // d_descs_rest (used when the launch has no tail workgroups and no delta base): the fused kernel's `rest` instance decodes what it does not take with the generic
