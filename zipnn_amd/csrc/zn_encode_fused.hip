@@ -590,16 +590,22 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
   uint32_t carry = 0;          // bits already in buf[0] from the previous tile (< 32)
   uint32_t written = 0;        // stream bytes already stored
   // tiles from the END of the segment to its start: huff0 packs the last symbol first
-  for (int32_t base = (int32_t)seg - ZN_E_TILE; base >= 0; base -= ZN_E_TILE) {
-    // this lane's 32 elements = 32·P source bytes.  ZN_E_SPLIT: TWO runs of 16 — elements [16 l, +16) of the tile's lower half (d[0 .. 4P)) and of its upper half
-    // (d[4P .. 8P)) — instead of one run of 32: a raw plane's 32 bytes per lane then leave as two 16-byte stores that each write 1 KB contiguous across the wave
-    // (whole 32-byte sectors); as one run, each non-temporal store wrote half of every sector (the emit kernel's 8 % write surplus: profiles/r04_decode_experiments.txt)
+  // this lane's 32 elements of a tile = 32·P source bytes.  ZN_E_SPLIT: TWO runs of 16 — elements [16 l, +16) of the tile's lower half (d[0 .. 4P)) and of its upper half
+  // (d[4P .. 8P)) — instead of one run of 32: a raw plane's 32 bytes per lane then leave as two 16-byte stores that each write 1 KB contiguous across the wave
+  // (whole 32-byte sectors); as one run, each non-temporal store wrote half of every sector (the emit kernel's 8 % write surplus: profiles/r04_decode_experiments.txt)
 #ifndef ZN_E_SPLIT
 #define ZN_E_SPLIT 1
 #endif
-    constexpr uint32_t RUN = ZN_E_SPLIT ? ZN_E_SPL / 2u : ZN_E_SPL;          // consecutive elements of a run
-    constexpr uint32_t HALF = ZN_E_SPLIT ? ZN_E_TILE / 2u : 0u;              // element distance between the lane's two runs
-    uint32_t d[8 * P];
+#ifndef ZN_E_PREFETCH
+#define ZN_E_PREFETCH 1                   // the NEXT tile's source vectors are requested before this tile is packed (the emit kernel; the one-pass kernel has no registers for them)
+#endif
+  constexpr uint32_t RUN = ZN_E_SPLIT ? ZN_E_SPL / 2u : ZN_E_SPL;          // consecutive elements of a run
+  constexpr uint32_t HALF = ZN_E_SPLIT ? ZN_E_TILE / 2u : 0u;              // element distance between the lane's two runs
+#ifndef ZN_E_PREFETCH_NT
+#define ZN_E_PREFETCH_NT 1                // … in the one-pass kernel as well (its four-workgroups-per-CU build: 128 registers; 4 GiB bf16 2.223 -> 2.185 ms against five workgroups without)
+#endif
+  constexpr bool AHEAD = (ZN_E_PREFETCH != 0) && !X && (!NT || ZN_E_PREFETCH_NT != 0);
+  auto load_tile = [&](uint32_t (&d)[8 * P], int32_t base) {
     const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + RUN * lane);
     for (int k = 0; k < 2 * P; k++) {
       const uint8_t* ak = ZN_E_SPLIT ? a + (k >= P ? (uint64_t)P * HALF + 16 * (k - P) : 16 * k) : a + 16 * k;
@@ -612,6 +618,13 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
         const uint4 x = NT ? zn_ldnt128(xk) : ZN_LD_EMIT(xk); d[4 * k] ^= x.x; d[4 * k + 1] ^= x.y; d[4 * k + 2] ^= x.z; d[4 * k + 3] ^= x.w;
       }
     }
+  };
+  uint32_t dnext[8 * P];
+  if (AHEAD && (int32_t)seg - ZN_E_TILE >= 0) load_tile(dnext, (int32_t)seg - ZN_E_TILE);
+  for (int32_t base = (int32_t)seg - ZN_E_TILE; base >= 0; base -= ZN_E_TILE) {
+    uint32_t d[8 * P];
+    if (AHEAD) { for (int k = 0; k < 8 * P; k++) d[k] = dnext[k]; if (base - ZN_E_TILE >= 0) load_tile(dnext, base - ZN_E_TILE); }
+    else load_tile(d, base);
     // the lane's 32 elements plane by plane: pl[p][j] = byte p of elements 4 j .. 4 j + 3 (rotate at plane level, zn_split4)
     uint32_t pl[P][8];
     for (int j = 0; j < 8; j++) {
@@ -904,7 +917,8 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
 #define ZN_LB_VMASK ((1ull << ZN_LB_VBITS) - 1ull)
 
 #ifndef ZN_OP_WGS
-#define ZN_OP_WGS 5                      // one-pass workgroups per CU: the histogram's 32 KiB of LDS allow five, which leaves each wave 96 registers
+#define ZN_OP_WGS 4                      // one-pass workgroups per CU: the histogram's 32 KiB of LDS allow five (96 registers a wave); the time is the same from two to five
+                                         // (profiles/r05_encoder_onepass.txt), and four leave the registers for the emit pass's next tile (ZN_E_PREFETCH_NT)
 #endif
 #ifndef ZN_OP_NT2
 #define ZN_OP_NT2 1                      // the second read non-temporal (0: plain — it then allocates in the caches like the first)
