@@ -361,6 +361,7 @@ int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream_) {
 
 // Decode `count` tensors in one set of launches per plane count.  A single tensor travels to the kernels as an
 // argument; a batch as a segment table in device memory.
+#define ZN_REST_MAX_CHUNKS 2048u          // (512 MiB of 256 KiB chunks)
 static int decompress_items(const zn_batch_item* items, size_t count, hipStream_t stream, int check) {
   if (count && !items) return ZN_E_ARG;
   std::vector<ZnSeg> segs[3];                    // by plane count: 1, 2, 4
@@ -457,6 +458,10 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     // (behind the wide kernel, in launches without partial chunks, the fused kernel's rest instance also does the generic kernels' job)
+    // (round 5, three boxes, interleaved: at 4 GiB the plain instance + the two generic launches behind it decode 1.0-1.4 % FASTER than the rest instance alone —
+    //  1.445 / 1.445 / 1.500 against 1.460 / 1.466 / 1.516 ms, profiles/r05_rest_instance_ab.txt —: the generic path's code in its cold paths costs the rest instance
+    //  twelve spilled registers.  What it saves is two launches, ≈ 4-8 us: it is the instance of calls of up to ZN_REST_MAX_CHUNKS chunks.)
+    if (total_chunks > ZN_REST_MAX_CHUNKS) rest_ok[q] = false;
     const bool rest = zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
                                              d_tail_done, delta_of[q], wide, status_zeroed, rest_ok[q] ? d_descs : nullptr,
                                              tail_of[q] ? (uint32_t*)((uint8_t*)w.buf[WS_META_A] + sync_off) + 2u * tail_base : nullptr, stream);

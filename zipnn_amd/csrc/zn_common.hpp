@@ -137,7 +137,7 @@ __device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P,
 #if defined(ZN_F_ABL) || defined(ZN_E_ABL)
 #error "ZN_F_ABL / ZN_E_ABL: the ablation code left the sources after round 3 (build commit 3c0f9d7 for it)"
 #endif
-#if defined(ZN_F_ONLY_HOT) || defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB) || defined(ZN_OP_FAKE_LB) || defined(ZN_OP_PROBE_HALF_HIST)
+#if defined(ZN_F_ONLY_HOT) || defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB) || defined(ZN_OP_FAKE_LB) || defined(ZN_OP_PROBE_HALF_HIST) || defined(ZN_F_NO_REST)
 #error "developer-only macro (ZN_F_ONLY_HOT / ZN_PHASE_TIMERS) without ZN_DEV_BUILD: not a product configuration"
 #endif
 #if defined(ZN_F_P2_MASK) && (ZN_F_P2_MASK == 0)

@@ -1166,6 +1166,9 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   // launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9); partial last chunks (ntail > 0) are finished by merge workgroups at the
   // end of the same launch (d_tailsync: two zeroed words per tensor with a partial chunk) — except behind the wide kernel, which keeps the generic launches
   if (delta || (ntail != 0 && (wide || !d_tailsync))) d_descs_rest = nullptr;
+#if defined(ZN_F_NO_REST)                        /* developer A/B (scripts/ab_libs.py): the plain instance + the generic launches, as before round 4 */
+  d_descs_rest = nullptr;
+#endif
   const uint32_t ntt = ntail / (uint32_t)P;      // tensors with a partial last chunk
   uint32_t merge_per = 0;
   if (d_descs_rest && ntail) { merge_per = 32u; while (merge_per > 1u && (uint64_t)merge_per * ntt > 4096u) merge_per >>= 1; }
