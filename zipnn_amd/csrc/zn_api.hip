@@ -47,6 +47,7 @@ struct Workspace {
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
   ZnHostPipe pipe2;              // a second one: the pipelined host path downloads slice i - 1 while it uploads slice i + 1
   hipStream_t cstream = nullptr; // … and codes slice i on a stream of its own
+  hipStream_t dstream = nullptr; hipEvent_t dfork = nullptr, djoin = nullptr;   // a mixed batched decode: the one-plane tensors' launches run on this stream beside the others'
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_LB, WS_COUNT };
 static_assert(WS_COUNT == 13, "Workspace::buf size");
@@ -362,6 +363,15 @@ int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream_) {
 // Decode `count` tensors in one set of launches per plane count.  A single tensor travels to the kernels as an
 // argument; a batch as a segment table in device memory.
 #define ZN_REST_MAX_CHUNKS 2048u          // (512 MiB of 256 KiB chunks)
+// A batch that mixes one-plane tensors (fp8: dense codes, the decode is LDS-bound at a fifth of the HBM roofline) with two- / four-plane ones (memory-bound) decodes
+// the two kinds CONCURRENTLY: the one-plane launches go to a second stream, forked from and joined to the caller's with events, so that the dispatcher fills a CU with
+// workgroups of both kernels — one kind waits on LDS look-ups while the other waits on HBM.  ZIPNN_AMD_DECODE_OVERLAP=0 keeps everything on the caller's stream.
+static int zn_decode_overlap_on() {
+  static std::atomic<int> v{-1};
+  int x = v.load(std::memory_order_relaxed);
+  if (x < 0) { const char* e = getenv("ZIPNN_AMD_DECODE_OVERLAP"); x = (e && e[0] >= '0' && e[0] <= '9') ? e[0] - '0' : 1; v.store(x, std::memory_order_relaxed); }
+  return x;
+}
 static int decompress_items(const zn_batch_item* items, size_t count, hipStream_t stream, int check) {
   if (count && !items) return ZN_E_ARG;
   std::vector<ZnSeg> segs[3];                    // by plane count: 1, 2, 4
@@ -447,9 +457,29 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     ZN_HIP(hipMemcpyAsync(w.buf[WS_SEGS], w.h_segs, nseg_all * sizeof(ZnSeg), hipMemcpyHostToDevice, stream));
   }
   size_t seg_base = 0; uint64_t k_base = 0, pk_base = 0, tail_base = 0;
-  for (int q = 0; q < 3; q++) {
+  const hipStream_t stream_main = stream;
+  const bool overlap = zn_decode_overlap_on() && k_of[0] >= 512u && k_of[1] + k_of[2] >= 512u;      // (both kinds fill the chip: below that the fork and join cost more than they hide)
+  if (overlap) {
+    if (!w.dstream) {
+      const int mode = zn_decode_overlap_on();   // (developer A/B: 3 / 4 = the second stream at the highest / lowest priority)
+      int lo = 0, hi = 0;
+      if (mode >= 3 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) ZN_HIP(hipStreamCreateWithPriority(&w.dstream, hipStreamNonBlocking, mode == 3 ? hi : lo));
+      else ZN_HIP(hipStreamCreateWithFlags(&w.dstream, hipStreamNonBlocking));
+    }
+    if (!w.dfork) ZN_HIP(hipEventCreateWithFlags(&w.dfork, hipEventDisableTiming));
+    if (!w.djoin) ZN_HIP(hipEventCreateWithFlags(&w.djoin, hipEventDisableTiming));
+    ZN_HIP(hipEventRecord(w.dfork, stream_main));          // behind the memsets and the segment table
+    ZN_HIP(hipStreamWaitEvent(w.dstream, w.dfork, 0));
+  }
+  const bool fp8_last = overlap && zn_decode_overlap_on() == 2;
+  size_t seg_b[3]; uint64_t k_b[3], pk_b[3], tail_b[3];          // where plane count q starts in the launch-wide arrays
+  for (int q = 0; q < 3; q++) { seg_b[q] = seg_base; k_b[q] = k_base; pk_b[q] = pk_base; tail_b[q] = tail_base; seg_base += segs[q].size(); k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q]; }
+  for (int qi = 0; qi < 3; qi++) {
+    const int q = fp8_last ? (qi + 1) % 3 : qi;
     if (segs[q].empty()) continue;
     const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
+    stream = (overlap && q == 0) ? w.dstream : stream_main;
+    seg_base = seg_b[q]; k_base = k_b[q]; pk_base = pk_b[q]; tail_base = tail_b[q];
     const ZnSeg* d_segs = table ? (const ZnSeg*)w.buf[WS_SEGS] + seg_base : nullptr;
     const uint32_t nseg = (uint32_t)segs[q].size();
     uint8_t* d_done = (uint8_t*)w.buf[WS_META_B] + k_base;
@@ -467,8 +497,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
                                              tail_of[q] ? (uint32_t*)((uint8_t*)w.buf[WS_META_A] + sync_off) + 2u * tail_base : nullptr, stream);
     status_zeroed = true;
     if (!rest) zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
-    seg_base += nseg; k_base += k_of[q]; pk_base += pk_of[q]; tail_base += tail_of[q];
   }
+  stream = stream_main;
+  if (overlap) { ZN_HIP(hipEventRecord(w.djoin, w.dstream)); ZN_HIP(hipStreamWaitEvent(stream_main, w.djoin, 0)); }
   ZN_HIP(hipGetLastError());
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if ((rc = ws_release(w, stream, table))) return rc;
@@ -1301,7 +1332,7 @@ int zn_release_workspace(void) {
     std::lock_guard<std::mutex> hk(g_host_mu[d]);
     std::lock_guard<std::mutex> lk(g_dev_mu[d]);
     Workspace& w = g_ws[d];
-    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr || w.pipe2.pin[0] != nullptr || w.cstream != nullptr;
+    bool any = w.h_total != nullptr || w.busy != nullptr || w.h_segs != nullptr || w.h_totals != nullptr || w.pipe.pin[0] != nullptr || w.pipe2.pin[0] != nullptr || w.cstream != nullptr || w.dstream != nullptr;
     for (int i = 0; i < WS_COUNT; i++) any = any || w.buf[i];
     if (!any) continue;
     if (hipSetDevice(d) != hipSuccess) { (void)hipGetLastError(); continue; }
@@ -1312,6 +1343,9 @@ int zn_release_workspace(void) {
     zn_host_pipe_release(w.pipe);
     zn_host_pipe_release(w.pipe2);
     if (w.cstream) { (void)hipStreamSynchronize(w.cstream); (void)hipStreamDestroy(w.cstream); w.cstream = nullptr; }
+    if (w.dstream) { (void)hipStreamSynchronize(w.dstream); (void)hipStreamDestroy(w.dstream); w.dstream = nullptr; }
+    if (w.dfork) { (void)hipEventDestroy(w.dfork); w.dfork = nullptr; }
+    if (w.djoin) { (void)hipEventDestroy(w.djoin); w.djoin = nullptr; }
     if (w.busy) { (void)hipDeviceSynchronize(); (void)hipEventDestroy(w.busy); w.busy = nullptr; w.have_stream = false; w.multi = false; }
   }
   if (prev >= 0) (void)hipSetDevice(prev);
