@@ -460,12 +460,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   const hipStream_t stream_main = stream;
   const bool overlap = zn_decode_overlap_on() && k_of[0] >= 512u && k_of[1] + k_of[2] >= 512u;      // (both kinds fill the chip: below that the fork and join cost more than they hide)
   if (overlap) {
-    if (!w.dstream) {
-      const int mode = zn_decode_overlap_on();   // (developer A/B: 3 / 4 = the second stream at the highest / lowest priority)
-      int lo = 0, hi = 0;
-      if (mode >= 3 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess) ZN_HIP(hipStreamCreateWithPriority(&w.dstream, hipStreamNonBlocking, mode == 3 ? hi : lo));
-      else ZN_HIP(hipStreamCreateWithFlags(&w.dstream, hipStreamNonBlocking));
-    }
+    if (!w.dstream) ZN_HIP(hipStreamCreateWithFlags(&w.dstream, hipStreamNonBlocking));      // (equal priority: a higher or a lower one for this stream measured 4-5 % slower, profiles/r05_llama8b_overlap.txt)
     if (!w.dfork) ZN_HIP(hipEventCreateWithFlags(&w.dfork, hipEventDisableTiming));
     if (!w.djoin) ZN_HIP(hipEventCreateWithFlags(&w.djoin, hipEventDisableTiming));
     ZN_HIP(hipEventRecord(w.dfork, stream_main));          // behind the memsets and the segment table
