@@ -724,7 +724,7 @@ def main():
                                   "frac": round(c_achieved / HBM_PEAK_GBPS, 4), "kernel": encode_kernels,
                                   "avg_call_ms": round(c["avg"], 4), "min_call_ms": round(c["min"], 4), "median_call_ms": round(c["median"], 4),
                                   "algorithmic_bytes": alg,
-                                  "note": "events bracket the whole zn_compress_dev call: four kernels + one 8-byte length read-back"},
+                                  "note": "events bracket the whole zn_compress_dev call — the one-pass encoder + the size scan for a bf16 call of this size (zn_k_encode_onepass: N + C over HBM, the chunk's second read aimed at the Infinity Cache), the four-kernel encoder (2 N + C) otherwise: see `kernel` — + one read-back of length and status"},
             "kernels": {"decompress": decode_kernels, "compress": encode_kernels},
         }
         if share:

@@ -47,7 +47,7 @@ struct Workspace {
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
   ZnHostPipe pipe2;              // a second one: the pipelined host path downloads slice i - 1 while it uploads slice i + 1
   hipStream_t cstream = nullptr; // … and codes slice i on a stream of its own
-  hipStream_t dstream = nullptr; hipEvent_t dfork = nullptr, djoin = nullptr;   // a mixed batched decode: the one-plane tensors' launches run on this stream beside the others'
+  hipStream_t dstream = nullptr, dstream2 = nullptr; hipEvent_t dfork = nullptr, djoin = nullptr, djoin2 = nullptr;   // a mixed batched decode: the one-plane tensors' launches on one of these streams, the others' on the other
 };
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_LB, WS_COUNT };
 static_assert(WS_COUNT == 13, "Workspace::buf size");
@@ -460,11 +460,17 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   const hipStream_t stream_main = stream;
   const bool overlap = zn_decode_overlap_on() && k_of[0] >= 512u && k_of[1] + k_of[2] >= 512u;      // (both kinds fill the chip: below that the fork and join cost more than they hide)
   if (overlap) {
-    if (!w.dstream) ZN_HIP(hipStreamCreateWithFlags(&w.dstream, hipStreamNonBlocking));      // (equal priority: a higher or a lower one for this stream measured 4-5 % slower, profiles/r05_llama8b_overlap.txt)
+    // (TWO streams of our own, created one behind the other — the runtime deals its hardware queues out in turn, so these two do not share one; the caller's stream
+    //  may share a queue with either: under torch.distributed, with RCCL's streams in the process, the caller's stream + ONE new stream ran the two kinds one after the
+    //  other.  Equal priorities: a higher or a lower one for the fp8 stream measured 4-5 % slower, profiles/r05_llama8b_overlap.txt)
+    if (!w.dstream) ZN_HIP(hipStreamCreateWithFlags(&w.dstream, hipStreamNonBlocking));
+    if (!w.dstream2) ZN_HIP(hipStreamCreateWithFlags(&w.dstream2, hipStreamNonBlocking));
+    if (!w.djoin2) ZN_HIP(hipEventCreateWithFlags(&w.djoin2, hipEventDisableTiming));
     if (!w.dfork) ZN_HIP(hipEventCreateWithFlags(&w.dfork, hipEventDisableTiming));
     if (!w.djoin) ZN_HIP(hipEventCreateWithFlags(&w.djoin, hipEventDisableTiming));
     ZN_HIP(hipEventRecord(w.dfork, stream_main));          // behind the memsets and the segment table
     ZN_HIP(hipStreamWaitEvent(w.dstream, w.dfork, 0));
+    ZN_HIP(hipStreamWaitEvent(w.dstream2, w.dfork, 0));
   }
   const bool fp8_last = overlap && zn_decode_overlap_on() == 2;
   size_t seg_b[3]; uint64_t k_b[3], pk_b[3], tail_b[3];          // where plane count q starts in the launch-wide arrays
@@ -473,7 +479,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     const int q = fp8_last ? (qi + 1) % 3 : qi;
     if (segs[q].empty()) continue;
     const int P = q == 0 ? 1 : q == 1 ? 2 : 4;
-    stream = (overlap && q == 0) ? w.dstream : stream_main;
+    stream = !overlap ? stream_main : (q == 0 ? w.dstream : w.dstream2);
     seg_base = seg_b[q]; k_base = k_b[q]; pk_base = pk_b[q]; tail_base = tail_b[q];
     const ZnSeg* d_segs = table ? (const ZnSeg*)w.buf[WS_SEGS] + seg_base : nullptr;
     const uint32_t nseg = (uint32_t)segs[q].size();
@@ -494,7 +500,10 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (!rest) zn_launch_decode_generic(P, segs[q][0], d_segs, nseg, pk_of[q], k_of[q], d_descs, d_status, d_done, d_pdone, d_tails, d_tail_done, stream);
   }
   stream = stream_main;
-  if (overlap) { ZN_HIP(hipEventRecord(w.djoin, w.dstream)); ZN_HIP(hipStreamWaitEvent(stream_main, w.djoin, 0)); }
+  if (overlap) {
+    ZN_HIP(hipEventRecord(w.djoin, w.dstream)); ZN_HIP(hipStreamWaitEvent(stream_main, w.djoin, 0));
+    ZN_HIP(hipEventRecord(w.djoin2, w.dstream2)); ZN_HIP(hipStreamWaitEvent(stream_main, w.djoin2, 0));
+  }
   ZN_HIP(hipGetLastError());
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if ((rc = ws_release(w, stream, table))) return rc;
@@ -1339,6 +1348,8 @@ int zn_release_workspace(void) {
     zn_host_pipe_release(w.pipe2);
     if (w.cstream) { (void)hipStreamSynchronize(w.cstream); (void)hipStreamDestroy(w.cstream); w.cstream = nullptr; }
     if (w.dstream) { (void)hipStreamSynchronize(w.dstream); (void)hipStreamDestroy(w.dstream); w.dstream = nullptr; }
+    if (w.dstream2) { (void)hipStreamSynchronize(w.dstream2); (void)hipStreamDestroy(w.dstream2); w.dstream2 = nullptr; }
+    if (w.djoin2) { (void)hipEventDestroy(w.djoin2); w.djoin2 = nullptr; }
     if (w.dfork) { (void)hipEventDestroy(w.dfork); w.dfork = nullptr; }
     if (w.djoin) { (void)hipEventDestroy(w.djoin); w.djoin = nullptr; }
     if (w.busy) { (void)hipDeviceSynchronize(); (void)hipEventDestroy(w.busy); w.busy = nullptr; w.have_stream = false; w.multi = false; }
