@@ -269,9 +269,6 @@ __device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g
           for (int p = 0; p < P; p++)
             for (int t = 0; t < 4; t++) {
               const uint32_t b = (pl[p] >> (8 * t)) & 0xFFu;
-#if defined(ZN_OP_PROBE_HALF_HIST)               /* developer timing probe: only the last plane is counted (weights: the same decisions, half the LDS atomics) */
-              if (!NT && p != P - 1) continue;
-#endif
               atomicAdd(hbase + (uint32_t)(p >> 1) * (256u * COLS) + b * COLS, (p & 1) ? 65536u : 1u);
             }
         }
@@ -1019,10 +1016,6 @@ __global__ __launch_bounds__(ZN_E_THREADS, ZN_OP_WGS) void zn_k_encode_onepass(Z
     const uint64_t tag = (uint64_t)gen << (ZN_LB_VBITS + 2u);
     const uint64_t mine = csz_last;
     uint64_t excl = 0;
-#if defined(ZN_OP_FAKE_LB)                          /* developer timing probe (wrong offsets): what the kernel costs without the wait for its predecessors */
-    if (true) { excl = c * 44000ull; }
-    else
-#endif
     if (c == 0) { if (lane == 0) ZN_LB_STORE(lb, tag | (2ull << ZN_LB_VBITS) | mine); }
     else {
       if (lane == 0) ZN_LB_STORE(lb, tag | (1ull << ZN_LB_VBITS) | mine);
