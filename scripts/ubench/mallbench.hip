@@ -51,6 +51,12 @@ __global__ __launch_bounds__(256) void k_reread(const uint8_t* __restrict__ src,
   }
 }
 
+__global__ void k_spin(uint32_t ticks, uint64_t* out) {
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_readcyclecounter();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+  out[0] = __builtin_amdgcn_s_memrealtime() - t0; out[1] = __builtin_readcyclecounter() - c0;
+}
+
 int main(int argc, char** argv) {
   const size_t n = (argc > 1 ? (size_t)atol(argv[1]) : 4096) << 20;        // MiB
   const uint32_t nchunks = (uint32_t)(n / CHUNK), out_bytes = 173u * 1024u;
@@ -63,7 +69,7 @@ int main(int argc, char** argv) {
     for (int r = 0; r < 6; r++) {
       CK(hipMemsetAsync(ticket, 0, 4, 0));
       CK(hipEventRecord(e0, 0));
-#define GO(M, A, B) hipLaunchKernelGGL((k_reread<M, A, B>), dim3(nchunks), dim3(256), lds_bytes, 0, src, other, dst, ticket, delay_us * 10u, out_bytes)
+#define GO(M, A, B) hipLaunchKernelGGL((k_reread<M, A, B>), dim3(nchunks), dim3(256), lds_bytes, 0, src, other, dst, ticket, delay_us * 100u, out_bytes)   /* s_memrealtime: 100 ticks per microsecond (calibrated below) */
       if (mode == 0) { if (nt1 && nt2) GO(0, 1, 1); else if (nt1) GO(0, 1, 0); else if (nt2) GO(0, 0, 1); else GO(0, 0, 0); }
       else if (mode == 1) { if (nt1) GO(1, 1, 0); else GO(1, 0, 0); }
       else { if (nt1 && nt2) GO(2, 1, 1); else if (nt1) GO(2, 1, 0); else if (nt2) GO(2, 0, 1); else GO(2, 0, 0); }
@@ -73,13 +79,21 @@ int main(int argc, char** argv) {
     return best;
   };
   const uint32_t lds_for[] = {0, 0, 80 * 1024, 53 * 1024, 40 * 1024, 32 * 1024, 26 * 1024, 0, 20 * 1024};
+  {   // what is one tick of s_memrealtime?  (one thread spins for 100000 ticks; the launch is timed with events)
+    uint64_t* d; CK(hipMalloc(&d, 16)); uint64_t h[2];
+    for (int r = 0; r < 2; r++) {
+      CK(hipEventRecord(e0, 0)); hipLaunchKernelGGL(k_spin, dim3(1), dim3(1), 0, 0, 100000u, d); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); CK(hipMemcpy(h, d, 16, hipMemcpyDeviceToHost));
+      printf("# calibration: %llu ticks of s_memrealtime (%llu shader cycles) took %.3f ms -> %.1f ticks per us\n", (unsigned long long)h[0], (unsigned long long)h[1], ms, h[0] / (ms * 1e3));
+    }
+  }
   printf("# %zu MiB, %u chunks; time in ms per launch (best of 5): no re-read | re-read SAME chunk | re-read from an untouched buffer (HBM)\n", n >> 20, nchunks);
   for (int nt = 0; nt < 4; nt++)
     for (int occ : {2, 3, 4, 5, 8})
-      for (uint32_t d : {0u, 20u, 40u, 80u}) {
+      for (uint32_t d : {0u, 10u, 20u, 40u, 80u, 120u}) {
         const int nt1 = nt & 1, nt2 = nt >> 1;
         const float a = run(1, nt1, 0, lds_for[occ], d), b = run(0, nt1, nt2, lds_for[occ], d), c = run(2, nt1, nt2, lds_for[occ], d);
-        printf("first read %s, second read %s, %d wg/CU (%3u MiB in flight), delay %2u us:  %7.3f | %7.3f | %7.3f   saved %4.0f %% of the second read\n",
+        printf("first read %s, second read %s, %d wg/CU (%3u MiB in flight), delay %3u us:  %7.3f | %7.3f | %7.3f   saved %4.0f %% of the second read\n",
                nt1 ? "nt   " : "plain", nt2 ? "nt   " : "plain", occ, occ * 256u * 256u >> 10, d, a, b, c, 100.0 * (c - b) / (c - a > 1e-6 ? c - a : 1e-6));
         fflush(stdout);
       }
