@@ -194,9 +194,12 @@ int zn_copy_to_host(void* dst, const void* d_src, size_t n);
  * One host thread per GPU, as the multi-device entry points use the library, is safe with the defaults.
  * ------------------------------------------------------------------------------------------------------------------------- */
 
-/* chunks one workgroup of the fused decoder takes, 1..4; 0 (default) = automatic (4 when the tensor has enough chunks
- * to fill every workgroup slot of the device with groups, fewer for small tensors).  Returns 0 or ZN_E_ARG. */
+/* chunks one workgroup of the fused decoder takes, 1..4; 0 (default) = automatic: the group size whose launch takes the fewest
+ * rounds of workgroups x (one parse of the group's tree descriptions + its chunks), a round being as many workgroups as the device
+ * holds at once (profiles/r05_decode_group_rule.txt).  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_group(int chunks_per_workgroup);
+/* what that rule (or the knob) gives a launch of `chunks` chunks on the current device: 1..4 */
+int zn_decode_group_for(unsigned long long chunks);
 
 /* the small-input form of the decoder (one workgroup per chunk, four or two waves per huff0 stream) — 0 = never,
  * 1 (default) = automatic: calls whose tensors are all split with the sign rotate (bits_mode 1 with 2 or 4 byte planes: bf16, fp32), are whole
@@ -227,11 +230,13 @@ int zn_set_legacy_tree_descriptions(int on);
 /* Frees the per-device workspaces this library caches (scratch planes, size tables). */
 int zn_release_workspace(void);
 
-/* The device-side verdict of the last zn_decompress*_dev call made on the current device with check = 0 (no read-back, asynchronous):
- * waits for `stream` and returns ZN_OK / ZN_E_TYPE / ZN_E_CORRUPT exactly as that call would have with check = 1.  For callers that
- * overlap host work with the decode (a checkpoint loader builds its tensor views while the kernels run) — the reference's
- * combine_dtype (csrc/zipnn_core.c:881) is synchronous and reports through its return value at once.  Valid until the next decode call
- * on this device. */
+/* The device-side verdict of the CALLING THREAD's last zn_decompress*_dev call on the current device with check = 0 (no read-back,
+ * asynchronous): waits for `stream` and returns ZN_OK / ZN_E_TYPE / ZN_E_CORRUPT exactly as that call would have with check = 1.  For
+ * callers that overlap host work with the decode (a checkpoint loader builds its tensor views while the kernels run) — the reference's
+ * combine_dtype (csrc/zipnn_core.c:881) is synchronous and reports through its return value at once.  Every decode call writes its
+ * verdict to a slot of its own (sixteen per device, handed out in turn), so decodes by other threads or on other streams in between
+ * do not disturb it; after sixteen further decode calls on the device the slot is reused and the answer is ZN_E_CORRUPT ("cannot
+ * vouch for it") rather than a guess.  A thread that has made no check = 0 call on this device gets the device's most recent decode. */
 int zn_decode_status(void* stream);
 
 /* Names of the kernels the last *_dev call launched, ';'-separated (for profiles). */

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 from zipnn_amd import _capi, codec   # noqa: E402
 lib = _capi.lib()
 C = 256 * 1024
-for mib in (64, 128, 256, 512, 1024, 2048, 4096):
+for mib in (tuple(int(a) for a in sys.argv[1:]) or (64, 128, 256, 512, 1024, 2048, 4096)):
     n = mib << 20
     x = torch.empty(n // 2, dtype=torch.bfloat16, device="cuda")
     g = torch.Generator(device="cuda"); g.manual_seed(3)

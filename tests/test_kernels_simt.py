@@ -935,3 +935,62 @@ def test_rest_instance_decodes_what_neither_kernel_takes_with_the_generic_code(s
         wide_mode(mode)
         with pytest.raises(RuntimeError):
             simt_lib.decompress(bytes(body), 2, 1, 10, C, len(d))
+
+
+def test_decode_group_rule_counts_rounds(simt_lib):
+    """zn_decode_fused_group: the group size with the fewest rounds x (13 + 85 x size); the emulated device holds 1 CU x 4 workgroups.
+    (On the device, with 1 024 slots, the same arithmetic picks the measured best column of profiles/r05_decode_group_rule.txt.)"""
+    slots = 4
+
+    def rule(K):
+        best, pick = None, 1
+        for m in (1, 2, 3, 4):
+            wgs = -(-K // m); rounds = -(-wgs // slots); cost = rounds * (13 + 85 * m)
+            if best is None or cost <= best:
+                best, pick = cost, m
+        return pick
+    for K in (0, 1, 3, 4, 5, 8, 9, 12, 13, 14, 16, 17, 20, 21, 64, 65, 68, 1 << 20):
+        assert simt_lib.decode_group_for(K) == rule(K), K
+    assert [simt_lib.decode_group_for(K) for K in (4, 5, 8, 9, 12, 16, 20)] == [1, 2, 2, 3, 3, 4, 1]
+    simt_lib.set_decode_group(3)
+    try:
+        assert simt_lib.decode_group_for(1000) == 3
+    finally:
+        simt_lib.set_decode_group(0)
+
+
+def test_decode_status_belongs_to_the_calling_threads_call(simt_lib):
+    """zn_decode_status: a check = 0 call's verdict sits in a slot of its own — a healthy decode by another thread in between does not erase it,
+    and once the slot has been handed to a later call the answer is an error, not a guess."""
+    import threading
+    d = gen_bytes("bf16", 2 * C, 4)
+    good = O.compress_frame(HDR, d, 2, 1, 10, C)
+    bad = bytearray(good)
+    bad[32] = 7                                         # a chunk-type byte that is neither 0 nor 1
+    gb = torch.frombuffer(bytearray(good[32:]), dtype=torch.uint8)
+    bb = torch.frombuffer(bytearray(bad[32:]), dtype=torch.uint8)
+    out = torch.empty(2 * C, dtype=torch.uint8)
+    out2 = torch.empty(2 * C, dtype=torch.uint8)
+
+    def other_thread(n, check):
+        for _ in range(n):
+            simt_lib.decompress_dev(gb.data_ptr(), gb.numel(), 2, 1, 10, C, 2 * C, out2.data_ptr(), check=check)
+
+    simt_lib.decompress_dev(bb.data_ptr(), bb.numel(), 2, 1, 10, C, 2 * C, out.data_ptr(), check=False)
+    for check in (False, True):
+        t = threading.Thread(target=other_thread, args=(3, check)); t.start(); t.join()
+    with pytest.raises(MemoryError):
+        simt_lib.decode_status()                        # ZN_E_TYPE, as the checked call reports it
+    # a healthy call of this thread: ok, whatever other threads' calls found
+    simt_lib.decompress_dev(gb.data_ptr(), gb.numel(), 2, 1, 10, C, 2 * C, out.data_ptr(), check=False)
+    simt_lib.decode_status()
+    assert out.numpy().tobytes() == d
+    # sixteen decode calls later the slot is another call's
+    simt_lib.decompress_dev(gb.data_ptr(), gb.numel(), 2, 1, 10, C, 2 * C, out.data_ptr(), check=False)
+    t = threading.Thread(target=other_thread, args=(16, False)); t.start(); t.join()
+    with pytest.raises(RuntimeError):
+        simt_lib.decode_status()
+    # a thread that made no call of its own is told about the device's last decode
+    res = []
+    t = threading.Thread(target=lambda: res.append(simt_lib.decode_status())); t.start(); t.join()
+    assert res == [None]

@@ -85,6 +85,8 @@ class ZnLib:
         L.zn_set_host_slices.argtypes = [ci]
         L.zn_set_decode_group.restype = ci
         L.zn_set_decode_group.argtypes = [ci]
+        L.zn_decode_group_for.restype = ci
+        L.zn_decode_group_for.argtypes = [ctypes.c_ulonglong]
         L.zn_set_encode_onepass.restype = ci
         L.zn_set_encode_onepass.argtypes = [ci]
         L.zn_set_decode_wide.restype = ci
@@ -284,6 +286,10 @@ class ZnLib:
     def set_decode_group(self, chunks_per_workgroup):
         """Tuning knob (zn_set_decode_group): chunks per workgroup of the fused decoder, 1..4; 0 = automatic."""
         self._check(self._L.zn_set_decode_group(int(chunks_per_workgroup)))
+
+    def decode_group_for(self, chunks):
+        """zn_decode_group_for: chunks per workgroup the fused decoder gives a launch of `chunks` chunks on the current device."""
+        return int(self._L.zn_decode_group_for(int(chunks)))
 
     # -- device pointers (ints), used by zipnn_amd.codec with torch tensors -----------------
     def compress_dev(self, src_ptr, n, num_buf, bits_mode, bytes_mode, chunk, threshold, body_ptr, body_cap, stream=0,

@@ -20,6 +20,10 @@ namespace {
 
 thread_local std::string t_hip_err;
 thread_local std::string t_kernels;
+// which status slot the calling thread's last check = 0 decode used (zn_decode_status): device, slot, the slot's generation at that call
+thread_local int t_status_dev = -1;
+thread_local uint32_t t_status_slot = 0;
+thread_local uint64_t t_status_gen = 0;
 
 #define ZN_HIP(call)                                                            \
   do {                                                                          \
@@ -44,11 +48,19 @@ struct Workspace {
   uint32_t* h_status = nullptr;
   hipEvent_t busy = nullptr;     // orders the workspace between streams (ws_acquire / ws_release)
   hipStream_t only_stream = nullptr; bool have_stream = false, multi = false;   // one stream so far (its handle is only ever COMPARED) / several: an event per call
+  // (a stream created at a destroyed one's address compares equal: the header's contract — destroy a stream only after its asynchronous calls have
+  //  finished — is what covers that; hipStreamGetId, which could tell the two apart, is a hip_7.1 symbol and the runtime PyTorch 2.10 loads is 7.0)
+  // decode status words: ZN_STATUS_SLOTS slots of four words behind the buffer's first 64 bytes, handed out in turn — a decode on another thread or stream
+  // does not zero the word a check = 0 caller has yet to read (zn_decode_status)
+  uint64_t status_gen = 0, slot_gen[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t last_slot = 0;
   ZnHostPipe pipe;               // pinned bounce buffers + copy stream of the host-buffer entry points
   ZnHostPipe pipe2;              // a second one: the pipelined host path downloads slice i - 1 while it uploads slice i + 1
   hipStream_t cstream = nullptr; // … and codes slice i on a stream of its own
   hipStream_t dstream = nullptr, dstream2 = nullptr; hipEvent_t dfork = nullptr, djoin = nullptr, djoin2 = nullptr;   // a mixed batched decode: the one-plane tensors' launches on one of these streams, the others' on the other
 };
+#define ZN_STATUS_SLOTS 16u
+#define ZN_WORDS_BYTES (64u + ZN_STATUS_SLOTS * 4u * sizeof(uint32_t))
 enum { WS_PLANES = 0, WS_ENC, WS_META_A, WS_META_B, WS_META_C, WS_WORDS, WS_DESC, WS_SEGS, WS_HOST_IN, WS_HOST_OUT, WS_TOTALS, WS_HOST_DELTA, WS_LB, WS_COUNT };
 static_assert(WS_COUNT == 13, "Workspace::buf size");
 
@@ -237,7 +249,7 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   if ((rc = ws_reserve(w, WS_META_B, pc_all))) return rc;                      // types
   if ((rc = ws_reserve(w, WS_META_C, pc_all * sizeof(uint64_t)))) return rc;   // payload offsets
   if ((rc = ws_reserve(w, WS_DESC, pc_all * sizeof(ZnEncDesc)))) return rc;
-  if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
+  if ((rc = ws_reserve(w, WS_WORDS, ZN_WORDS_BYTES))) return rc;
   // (one slot more than there are tensors: the call's status word rides behind the body lengths, so that both come back in ONE copy)
   if ((rc = ws_reserve(w, WS_TOTALS, (count + 4) * sizeof(uint64_t)))) return rc;      // (… and the one-pass encoder's three ticket counters behind that)
   if ((rc = ws_host_words(w))) return rc;
@@ -380,8 +392,10 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   uint64_t total_chunks = 0;
   bool any_delta = false;
   uint64_t full_chunks = 0; bool all_rotated = true;
+  uint64_t kq[3] = {0, 0, 0};                    // chunks per launch (one launch per plane count)
   for (size_t i = 0; i < count; i++) {
     total_chunks += zn_num_chunks(items[i].orig_size, items[i].chunk); if (items[i].d_delta) any_delta = true;
+    kq[items[i].num_buf == 1 ? 0 : items[i].num_buf == 2 ? 1 : 2] += zn_num_chunks(items[i].orig_size, items[i].chunk);
     if (items[i].chunk) full_chunks += items[i].orig_size / items[i].chunk;
     // (tensors without the sign rotate — fp16, fp8, integers: their Huffman planes are dense codes, which the wide kernel parses and declines)
     if (!(items[i].bits_mode == 1 && items[i].num_buf > 1)) all_rotated = false;
@@ -390,7 +404,8 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (items[i].chunk && items[i].orig_size % items[i].chunk) all_rotated = false;
   }
   const int wide = zn_decode_use_wide(full_chunks, any_delta, all_rotated);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
-  const uint32_t ncg = wide ? 1u : zn_decode_fused_group(total_chunks);
+  uint32_t ncg_of[3];
+  for (int q = 0; q < 3; q++) ncg_of[q] = wide ? 1u : zn_decode_fused_group(kq[q]);
   for (size_t i = 0; i < count; i++) {
     const zn_batch_item& it = items[i];
     ZnSeg sg;
@@ -400,6 +415,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (it.orig_size == 0) continue;
     if (!it.d_body || !it.d_dst) return ZN_E_ARG;
     const int q = sg.g.P == 1 ? 0 : sg.g.P == 2 ? 1 : 2;
+    const uint32_t ncg = ncg_of[q];
     sg.body = (const uint8_t*)it.d_body; sg.body_len = it.body_len; sg.dst = (uint8_t*)it.d_dst;
     sg.xr = (const uint8_t*)it.d_delta;
     if (sg.xr) delta_of[q] = true;
@@ -432,7 +448,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if ((rc = ws_reserve(w, WS_PLANES, all_tail * ZN_TAIL_SLOT))) return rc;   // decoded Huffman planes of partial last chunks
   const size_t sync_off = (all_tail + 15u) & ~(size_t)15u;                   // … and whether the tail kernel produced them; behind that two flag words per tensor with a partial chunk
   if ((rc = ws_reserve(w, WS_META_A, sync_off + 2u * sizeof(uint32_t) * all_tail))) return rc;
-  if ((rc = ws_reserve(w, WS_WORDS, 64))) return rc;
+  if ((rc = ws_reserve(w, WS_WORDS, ZN_WORDS_BYTES))) return rc;
   if ((rc = ws_host_words(w))) return rc;
   if (table) {
     if ((rc = ws_reserve(w, WS_SEGS, nseg_all * sizeof(ZnSeg)))) return rc;
@@ -443,7 +459,11 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     }
   }
   if ((rc = ws_acquire(w, stream))) return rc;
-  uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 8;
+  // this call's status slot (status word + the three "left to the generic kernels" counters)
+  const uint32_t slot = (uint32_t)(w.status_gen % ZN_STATUS_SLOTS);
+  w.slot_gen[slot] = ++w.status_gen; w.last_slot = slot;
+  if (!check) { t_status_dev = dev; t_status_slot = slot; t_status_gen = w.status_gen; }
+  uint32_t* d_status = (uint32_t*)w.buf[WS_WORDS] + 16 + 4u * slot;
   w.last_K = all_k; w.last_tails = all_tail;
   // status + the three "left to the generic kernels" counters (a wide call: its first kernel zeroes them)
   bool status_zeroed = false;
@@ -1252,12 +1272,19 @@ int zn_decode_status(void* stream_) {
     if (dev < 0 || dev >= 64) return ZN_E_ARG;
     std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
-    if (!w.buf[WS_WORDS]) return ZN_OK;              // nothing has run on this device yet
+    if (!w.buf[WS_WORDS] || w.cap[WS_WORDS] < ZN_WORDS_BYTES || w.status_gen == 0) return ZN_OK;              // no decode has run on this device yet
     int rc;
     if ((rc = ws_host_words(w))) return rc;
     hipStream_t stream = (hipStream_t)stream_;
+    // the calling thread's last check = 0 decode on this device — or, for a thread that made none (a loader that launches on one thread and asks on another),
+    // the device's last decode.  Sixteen decodes later the slot belongs to another call: its answer is gone, and saying "ok" would be a guess
+    uint32_t slot = w.last_slot;
+    if (t_status_dev == dev) {
+      if (w.slot_gen[t_status_slot] != t_status_gen) return ZN_E_CORRUPT;
+      slot = t_status_slot;
+    }
     if (w.multi && w.busy) ZN_HIP(hipStreamWaitEvent(stream, w.busy, 0));      // (several streams on this device: behind the last call's kernels, whichever stream they ran on — ADVICE r4)
-    ZN_HIP(hipMemcpyAsync(w.h_status, (uint32_t*)w.buf[WS_WORDS] + 8, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    ZN_HIP(hipMemcpyAsync(w.h_status, (uint32_t*)w.buf[WS_WORDS] + 16 + 4u * slot, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     ZN_HIP(hipStreamSynchronize(stream));
     const uint32_t st = *w.h_status;
     if (st & ZN_DEV_BAD_TYPE) return ZN_E_TYPE;
@@ -1352,7 +1379,9 @@ int zn_release_workspace(void) {
     if (w.djoin2) { (void)hipEventDestroy(w.djoin2); w.djoin2 = nullptr; }
     if (w.dfork) { (void)hipEventDestroy(w.dfork); w.dfork = nullptr; }
     if (w.djoin) { (void)hipEventDestroy(w.djoin); w.djoin = nullptr; }
-    if (w.busy) { (void)hipDeviceSynchronize(); (void)hipEventDestroy(w.busy); w.busy = nullptr; w.have_stream = false; w.multi = false; }
+    if (w.busy) { (void)hipDeviceSynchronize(); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
+    w.have_stream = false; w.multi = false;
+    for (uint32_t i = 0; i < ZN_STATUS_SLOTS; i++) w.slot_gen[i] = 0;      // (the status slots went with the buffers: a thread's old token matches nothing)
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   return ZN_OK;

@@ -1112,8 +1112,11 @@ extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
 }
 #endif
 
-// chunks per workgroup: 4 amortises the serial tree description best, but only when the groups still
-// outnumber the workgroup slots of the device (CUs x ZN_F_WAVES_PER_SIMD)
+// chunks per workgroup.  The device runs `slots` workgroups at once (CUs x ZN_F_WAVES_PER_SIMD); a launch of W workgroups takes ceil(W / slots) rounds,
+// and a round takes one parse of the group's tree descriptions (side by side on the four waves: ≈ 13 µs) plus its chunks one after the other (≈ 85 µs each
+// with the chip full).  Until round 5 the rule was K / slots clamped to 1..4, which put 1 088 chunks into two rounds of one (185 µs; 173 as 544 groups of two),
+// 2 304 into two rounds of two (334 µs; 263 as 768 groups of three) and 5 120 into two rounds of four (623 µs; 540 as five rounds of one): the size sweep of
+// profiles/r05_decode_group_rule.txt — the cheapest (rounds x (parse + chunks)) of the four group sizes is the measured best one in every row of it.
 static std::atomic<int> g_zn_decode_group{0};
 uint32_t zn_decode_fused_group(uint64_t K) {
   static std::atomic<int> slots_of[64];          // per device (a node may mix parts); 0 = not asked yet
@@ -1126,8 +1129,12 @@ uint32_t zn_decode_fused_group(uint64_t K) {
     slots = cus * ZN_F_WAVES_PER_SIMD;
     slots_of[dev].store(slots, std::memory_order_relaxed);     // (racing first calls store the same value)
   }
-  uint32_t ncg = (uint32_t)(K / (uint64_t)slots);
-  ncg = ncg > 4u ? 4u : (ncg < 1u ? 1u : ncg);
+  uint32_t ncg = 1; uint64_t best = ~0ull;
+  for (uint32_t m = 1; m <= 4u; m++) {
+    const uint64_t wgs = (K + m - 1u) / m, rounds = (wgs + (uint64_t)slots - 1u) / (uint64_t)slots;
+    const uint64_t cost = rounds * (13u + 85u * m);
+    if (cost <= best) { best = cost; ncg = m; }     // (a tie: the larger group — fewer parses)
+  }
   const int forced = g_zn_decode_group.load(std::memory_order_relaxed);      // zn_set_decode_group (include/zipnn_hip.h): 0 = automatic
   if (forced >= 1 && forced <= 4) ncg = (uint32_t)forced;
   return ncg;
@@ -1153,6 +1160,7 @@ extern "C" int zn_set_decode_wide(int mode) {
   g_zn_decode_wide.store(mode, std::memory_order_relaxed);
   return 0;
 }
+extern "C" int zn_decode_group_for(unsigned long long chunks) { return (int)zn_decode_fused_group((uint64_t)chunks); }
 extern "C" int zn_set_decode_group(int chunks_per_workgroup) {
   if (chunks_per_workgroup < 0 || chunks_per_workgroup > 4) return -1;     // ZN_E_ARG
   g_zn_decode_group.store(chunks_per_workgroup, std::memory_order_relaxed);

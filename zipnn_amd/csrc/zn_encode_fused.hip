@@ -896,7 +896,8 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
 //     then runs the four-kernel encoder, which overwrites everything.
 //   * the second read of the chunk, 40-100 us after the first, is served by the 256 MB Infinity Cache IF the first read allocates there (plain loads)
 //     and the second does not (non-temporal loads): measured with the access pattern alone, scripts/ubench/mallbench.hip, profiles/r05_mall_reread.txt —
-//     N read + N re-read + 0.66 N written in 1.51 ms at 4 workgroups per CU and 40 us between the reads, against 2.07 ms when the second read comes from HBM.
+//     N read + N re-read + 0.66 N written in 1.58 ms at 4 workgroups per CU and 40 us between the reads, against 2.12 ms when the second read comes from HBM
+//     (with twice the cache's size in flight — 8 workgroups per CU — the saving falls from 3/4 to 1/4 as the gap grows to 120 us).
 // One workgroup = the stats kernel's histogram pass (zn_stats_count), the table kernel's job on wave 0 (zn_table_job), the look-back on wave 0, the emit
 // kernel's pass (zn_emit_pass).  Types and stored sizes go to the same arrays; zn_k_scan_sizes writes the wire-format tables from them as before.
 // Replaces compression_worker + prepare_python_return_buffer for full chunks (reference csrc/zipnn_core.c:294-390, :105-244).
