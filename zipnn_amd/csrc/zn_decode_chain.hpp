@@ -77,6 +77,19 @@ __device__ __forceinline__ uint2 zn_trim_group(uint2 e, int32_t rem) {
   return r;
 }
 
+// … of a DENSE code's group (shortest code ≥ 4 bits: a TL ≤ 11-bit window holds at most TWO symbols, the second one E1 bits in; E1 = nb when there is none):
+// 14 vector instructions where the general form above needs 25 — a dense sub-block closes with two boundary steps in nearly every tile
+// (some lane of the 64 has a third symbol starting in its last 10 bits), and its streams are bound by instruction issue (profiles/r05y_pmc_fp8.txt: 85 % VALU-active)
+__device__ __forceinline__ uint2 zn_trim_group_dense(uint2 e, int32_t rem) {
+  const uint32_t meta = e.y;
+  const uint32_t nb = ZN_M_NB(meta), e1 = (meta >> 16) & 15u;
+  const bool t0 = rem > 0, t1 = (int32_t)e1 < rem && ZN_M_CNT(meta) >= 2u;
+  uint2 r;
+  r.x = t1 ? e.x : (t0 ? (e.x & 0xFFu) : 0u);
+  r.y = t1 ? (nb | (2u << 8)) : (t0 ? (e1 | (1u << 8)) : 0u);
+  return r;
+}
+
 // ---- the looping form of the chain (sync run-in; the rare tiles the register-resident form below does not take) ----
 // MODE 0: advance only; 1: count symbols; 2: OR the symbols into the staging buffer.
 struct ZnChain {
@@ -101,7 +114,8 @@ __device__ __forceinline__ void zn_chain_apply(ZnChain& c, uint2 e, uint32_t* st
 // without the per-step boundary test and its two selects: 4 instead of 9 vector instructions per step.  Lanes whose result the caller
 // discards (fix-up iterations re-run the pass for a few lanes only) may run past their boundary there; MODE 2 callers pass U > 0
 // only when every lane of the wave is writing.
-template <int MODE>
+// DENSE: the caller guarantees a code without lengths below 4 bits (the boundary steps then use zn_trim_group_dense).
+template <int MODE, bool DENSE = false>
 __device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* in, int32_t base_bit, uint32_t TL, ZnChain& c, uint32_t* stage, int U = 0) {
   const uint32_t sh = 32u - TL;
   const int32_t mb = c.stop + (int32_t)TL - 1;
@@ -125,8 +139,8 @@ __device__ __forceinline__ void zn_fused_run(const uint2* lut, const uint32_t* i
   while (__any(c.pos > c.stop)) {            // the boundary step(s): one iteration unless > 4 symbols start in the last TL - 1 bits
     const uint64_t w = zn_window(in, c.pos - 1 - base_bit);
     uint2 e = lut[(uint32_t)(w >> 32) >> sh];
-    if (!(c.pos > c.stop)) { e.x = 0; e.y = 0; }
-    zn_chain_apply<MODE>(c, zn_trim_group(e, c.pos - c.stop), stage);
+    if (!DENSE && !(c.pos > c.stop)) { e.x = 0; e.y = 0; }
+    zn_chain_apply<MODE>(c, DENSE ? zn_trim_group_dense(e, c.pos - c.stop) : zn_trim_group(e, c.pos - c.stop), stage);
   }
 }
 
@@ -232,8 +246,8 @@ __device__ __forceinline__ bool zn_pass1(const uint2* lut, const uint32_t* in, i
       if (live) {
         w = zn_window(in, qb - (int32_t)(acc & 0xFFu));
         uint2 e = lut[(uint32_t)(w >> 32) >> sh];
-        if (!(rem > 0)) { e.x = 0; e.y = 0; }
-        e = zn_trim_group(e, rem);
+        if (!DENSE && !(rem > 0)) { e.x = 0; e.y = 0; }           // (the dense trim takes nothing from a lane with rem <= 0 by itself)
+        e = DENSE ? zn_trim_group_dense(e, rem) : zn_trim_group(e, rem);
         acc += e.y;
         zn_rec_put<TF + b, DENSE>(rec, e.x, e.y);
         ZN_STEP_FENCE();

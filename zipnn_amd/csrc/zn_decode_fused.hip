@@ -528,7 +528,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         c.pos -= (int32_t)ZN_M_NB(zn_trim_group(e, c.pos - c.stop).y);
       }
     } else {
-      zn_fused_run<0>(lut, in, base_bit, TL, c, nullptr, regular_tile ? (delta - 21) / 11 : 0);
+      zn_fused_run<0, DENSE>(lut, in, base_bit, TL, c, nullptr, regular_tile ? (delta - 21) / 11 : 0);
     }
     return (lane > 0) ? c.pos : carry;
   };
