@@ -79,7 +79,7 @@ __device__ __forceinline__ uint2 zn_trim_group(uint2 e, int32_t rem) {
 
 // … of a DENSE code's group (shortest code ≥ 4 bits: a TL ≤ 11-bit window holds at most TWO symbols, the second one E1 bits in; E1 = nb when there is none):
 // 14 vector instructions where the general form above needs 25 — a dense sub-block closes with two boundary steps in nearly every tile
-// (some lane of the 64 has a third symbol starting in its last 10 bits), and its streams are bound by instruction issue (profiles/r05y_pmc_fp8.txt: 85 % VALU-active)
+// (some lane of the 64 has a third symbol starting in its last 10 bits), and its streams are bound by vector-instruction issue (~75 % of the SIMDs' issue cycles: profiles/r05_dense_valu.txt)
 __device__ __forceinline__ uint2 zn_trim_group_dense(uint2 e, int32_t rem) {
   const uint32_t meta = e.y;
   const uint32_t nb = ZN_M_NB(meta), e1 = (meta >> 16) & 15u;
