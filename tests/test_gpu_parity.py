@@ -337,6 +337,29 @@ def test_batched_decode_many_tensors(lib):
     assert "zn_k_decode_fused" in lib.last_kernels()
 
 
+def test_mixed_batch_of_two_full_kinds_runs_on_two_streams(lib):
+    """A batch whose one-plane tensors and whose multi-plane tensors each fill the chip (>= 512 chunks per kind: what a checkpoint with an fp8 copy of its
+    linears looks like) forks the two kinds' launches onto two streams of the library's own and joins them: same bytes as the sources,
+    with ragged tensors of both kinds in it, through the unchecked (check = 0 + zn_decode_status) entry as well."""
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    specs = [("fp8", 330 * 128 * KB + 7001, 1, 0, 10, 128 * KB), ("bf16", 300 * C, 2, 1, 10, C), ("fp8", 200 * 128 * KB, 1, 0, 10, 128 * KB),
+             ("fp32", 100 * C + 12, 4, 1, 220, C), ("bf16", 130 * C + 100000, 2, 1, 10, C), ("fp16", 9 * C, 2, 0, 10, C)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = gen_bytes(kind, nb, 80 + i)
+        frame = O.compress_frame(HDR, d, P, rot, bm, chunk, threads=8)
+        datas.append(d)
+        items.append((torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8).to(dev), P, rot, bm, chunk, nb))
+    for check in (True, False):
+        outs = codec.decompress_device_batch(lib, items, check=check)
+        if not check:
+            lib.decode_status()
+        assert "(two streams)" in lib.last_kernels()
+        for d, o in zip(datas, outs):
+            assert o.cpu().numpy().tobytes() == d
+
+
 @pytest.mark.parametrize("case", [("bf16", 5 * C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 10, C, 1),
                                   ("fp32", 2 * C + C // 2 + 4, 4, 1, 220, C, 1), ("fp8", 128 * KB + 70001, 1, 1, 10, 128 * KB, 1),
                                   ("fp16", 3 * C - 2, 2, 0, 10, C, 1), ("skew", C + 130000, 2, 0, 10, C, 2),

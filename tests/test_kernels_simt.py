@@ -994,3 +994,28 @@ def test_decode_status_belongs_to_the_calling_threads_call(simt_lib):
     res = []
     t = threading.Thread(target=lambda: res.append(simt_lib.decode_status())); t.start(); t.join()
     assert res == [None]
+
+
+def test_mixed_batch_of_two_full_kinds_takes_the_two_stream_path(simt_lib):
+    """zn_decompress_batch_dev: a batch whose one-plane tensors AND whose multi-plane tensors each have at least 512 chunks forks the two kinds' launches onto two
+    streams of the library's own and joins them again — per-kind bases in the launch-wide arrays, ragged tensors, a tensor of each kind.  Small
+    chunks keep the emulated run short; the same bytes as the sources, and the kernel log says that the path was taken."""
+    from zipnn_amd import codec
+    c1, c2, c4 = 4096, 4096, 8192
+    specs = [("fp8", 300 * c1 + 77, 1, 0, 10, c1), ("bf16", 400 * c2, 2, 1, 10, c2), ("fp8", 230 * c1, 1, 0, 10, c1),
+             ("fp32", 40 * c4 + 12, 4, 1, 220, c4), ("bf16", 120 * c2 + 1000, 2, 1, 10, c2), ("fp16", 3 * c2, 2, 0, 10, c2)]
+    datas, items = [], []
+    for i, (kind, nb, P, rot, bm, chunk) in enumerate(specs):
+        d = gen_bytes(kind, nb, 60 + i)
+        frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
+        datas.append(d)
+        items.append((torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8), P, rot, bm, chunk, nb))
+    outs = codec.decompress_device_batch(simt_lib, items)
+    for d, o in zip(datas, outs):
+        assert o.numpy().tobytes() == d
+    assert "(two streams)" in simt_lib.last_kernels()
+    # … and a batch below the bar stays on the caller's stream
+    outs = codec.decompress_device_batch(simt_lib, items[1:])
+    for d, o in zip(datas[1:], outs):
+        assert o.numpy().tobytes() == d
+    assert "(two streams)" not in simt_lib.last_kernels()

@@ -491,6 +491,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     ZN_HIP(hipEventRecord(w.dfork, stream_main));          // behind the memsets and the segment table
     ZN_HIP(hipStreamWaitEvent(w.dstream, w.dfork, 0));
     ZN_HIP(hipStreamWaitEvent(w.dstream2, w.dfork, 0));
+    zn_note_kernel("(two streams)");                        // (zn_last_kernels: the launches that follow are split over the two)
   }
   const bool fp8_last = overlap && zn_decode_overlap_on() == 2;
   size_t seg_b[3]; uint64_t k_b[3], pk_b[3], tail_b[3];          // where plane count q starts in the launch-wide arrays
