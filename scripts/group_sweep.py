@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from zipnn_amd import _capi, codec   # noqa: E402
-lib = _capi.lib()
+lib = _capi.ZnLib(os.environ["ZN_LIB"]) if os.environ.get("ZN_LIB") else _capi.lib()      # (ZN_LIB: a library variant built for an A/B)
 C = 256 * 1024
 for mib in (tuple(int(a) for a in sys.argv[1:]) or (64, 128, 256, 512, 1024, 2048, 4096)):
     n = mib << 20

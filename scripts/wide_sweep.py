@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from zipnn_amd import _capi, codec   # noqa: E402
-lib = _capi.lib()
+lib = _capi.ZnLib(os.environ["ZN_LIB"]) if os.environ.get("ZN_LIB") else _capi.lib()      # (ZN_LIB: a library variant built for an A/B)
 C = 256 * 1024
 for mib in (64, 96, 128, 192, 256, 384, 512, 1024):
     n = mib << 20
