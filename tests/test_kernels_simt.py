@@ -173,7 +173,9 @@ def test_fused_detects_corrupt_stream(simt_lib):
 ENC = [("bf16", 3 * C + 100, 2, 1, 10, C), ("fp16", 2 * C, 2, 0, 10, C), ("fp32", 2 * C, 4, 1, 220, C), ("fp8", 2 * C, 1, 1, 10, C),
        ("u11", 2 * C, 2, 1, 10, C), ("skew", 2 * C, 1, 1, 10, C), ("skew", 2 * C, 2, 0, 10, C), ("rand", 2 * C, 4, 1, 220, C),
        ("const", 2 * C + 2, 2, 1, 10, C), ("bf16", 256 * 1024, 2, 1, 10, 256 * 1024), ("bf16", 3 * 16384, 2, 1, 10, 16384),
-       ("bf16", 3 * 8192, 2, 1, 10, 8192)]
+       ("bf16", 3 * 8192, 2, 1, 10, 8192),
+       # every byte of a plane in ONE bin, in the largest chunks the fused encoders take: the 16-bit halves of the histogram's shared counters at their bound (4 096 / 8 192 counts a column)
+       ("const", 2 * 256 * 1024, 2, 1, 10, 256 * 1024), ("const", 512 * 1024, 4, 1, 220, 512 * 1024), ("skew", 256 * 1024, 2, 0, 10, 256 * 1024)]
 
 
 @pytest.mark.parametrize("onepass", [True, False], ids=["onepass", "four-kernel"])

@@ -225,9 +225,11 @@ __device__ __forceinline__ void zn_encode_tail_stats(uint32_t* hist /* LDS: [256
 // The histogram pass over one full chunk: thread = bin afterwards (tot[p] = count of byte value `tid` in plane p, qc[p][q] = … in quarter q).
 // NT: non-temporal loads (the stats kernel: one pure streaming read, -3 % on compress) — or plain ones (the one-pass encoder, whose second read of the
 // chunk is to be served by the Infinity Cache: a non-temporal first read leaves nothing there, profiles/r05_mall_reread.txt).
-template <int P, bool X, bool NT>
-__device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g, const uint8_t* cs0, const uint8_t* xcs0, uint32_t tid, uint32_t lane,
-                                               uint32_t (&tot)[P], uint32_t (&qc)[P][4]) {
+// WHOLE: a quarter is a whole number of workgroup steps (4 x 256 vectors: every chunk size that is a multiple of 64 KiB, the default 256 KiB among them) — no vector of a
+// step is out of range, and the loop body loses its per-vector range tests (an exec-mask region around every half vector: a tenth of its instructions)
+template <int P, bool X, bool NT, bool WHOLE>
+__device__ __forceinline__ void zn_stats_count_impl(ZnStatsLds<P>& L, const ZnGeom& g, const uint8_t* cs0, const uint8_t* xcs0, uint32_t tid, uint32_t lane,
+                                                    uint32_t (&tot)[P], uint32_t (&qc)[P][4]) {
   constexpr uint32_t COLS = ZnStatsLds<P>::COLS;
   constexpr uint32_t PAIRS = ZnStatsLds<P>::PAIRS;
   for (int p = 0; p < P; p++) tot[p] = 0;
@@ -239,10 +241,10 @@ __device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g
   auto ld = [&](const uint8_t* a) -> uint4 { return NT ? ZN_LD_STATS(a) : *(const uint4*)a; };
   auto fetch = [&](uint4 (&xs)[4], uint32_t q, uint32_t v0) {
     const uint8_t* qs = cs0 + (uint64_t)q * qbytes;
-    for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (v < nvec) ? ld(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
+    for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; xs[u] = (WHOLE || v < nvec) ? ld(qs + 16ull * v) : make_uint4(0, 0, 0, 0); }
     if (X && xcs0) {
       const uint8_t* xqs = xcs0 + (uint64_t)q * qbytes;
-      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (v < nvec) { const uint4 t = ld(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
+      for (int u = 0; u < 4; u++) { const uint32_t v = v0 + ZN_E_THREADS * (uint32_t)u; if (WHOLE || v < nvec) { const uint4 t = ld(xqs + 16ull * v); xs[u].x ^= t.x; xs[u].y ^= t.y; xs[u].z ^= t.z; xs[u].w ^= t.w; } }
     }
   };
   uint4 nx[4];
@@ -260,7 +262,7 @@ __device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g
         if (v1 < nvec) fetch(nx, (uint32_t)q, v1);
         else if (q < 3) fetch(nx, (uint32_t)q + 1u, tid);
       }
-      for (int u = 0; u < 4; u++) if (v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
+      for (int u = 0; u < 4; u++) if (WHOLE || v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
         // (the vector's 16 / P elements plane by plane: zn_split4 per four elements, then one counter per byte)
         const uint32_t d[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
         for (int k0 = 0; k0 < 4; k0 += P) {
@@ -300,6 +302,13 @@ __device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g
     for (int p = 0; p < P; p++) { qc[p][q] = cum[p] - tot[p]; tot[p] = cum[p]; }
     __syncthreads();
   }
+}
+template <int P, bool X, bool NT>
+__device__ __forceinline__ void zn_stats_count(ZnStatsLds<P>& L, const ZnGeom& g, const uint8_t* cs0, const uint8_t* xcs0, uint32_t tid, uint32_t lane,
+                                               uint32_t (&tot)[P], uint32_t (&qc)[P][4]) {
+  // (the one-pass kernel only: 4 GiB bf16 2.179 -> 2.141 ms; the stats kernel's own loop got slower with it — fp32 1 GiB 0.650 -> 0.674 ms, fp8 0.689 -> 0.705)
+  if (!NT && (g.chunk % (64ull * 4u * ZN_E_THREADS)) == 0) zn_stats_count_impl<P, X, NT, true>(L, g, cs0, xcs0, tid, lane, tot, qc);      // (wave-uniform: the geometry is a kernel argument)
+  else zn_stats_count_impl<P, X, NT, false>(L, g, cs0, xcs0, tid, lane, tot, qc);
 }
 
 template <int P, bool X>
