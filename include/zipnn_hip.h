@@ -236,7 +236,8 @@ int zn_release_workspace(void);
  * combine_dtype (csrc/zipnn_core.c:881) is synchronous and reports through its return value at once.  Every decode call writes its
  * verdict to a slot of its own (sixteen per device, handed out in turn), so decodes by other threads or on other streams in between
  * do not disturb it; after sixteen further decode calls on the device the slot is reused and the answer is ZN_E_CORRUPT ("cannot
- * vouch for it") rather than a guess.  A thread that has made no check = 0 call on this device gets the device's most recent decode. */
+ * vouch for it") rather than a guess.  A thread whose most recent check = 0 call was not on this device (it made none, or its last one
+ * went to another device) gets the device's most recent decode: ask on the device you launched on, before you launch on another. */
 int zn_decode_status(void* stream);
 
 /* Names of the kernels the last *_dev call launched, ';'-separated (for profiles). */
