@@ -947,7 +947,7 @@ def test_decode_group_rule_counts_rounds(simt_lib):
     def rule(K):
         best, pick = None, 1
         for m in (1, 2, 3, 4):
-            wgs = -(-K // m); rounds = -(-wgs // slots); cost = rounds * (13 + 85 * m)
+            wgs = max(1, -(-K // m)); rounds = -(-wgs // slots); cost = rounds * (13 + 85 * m)
             if best is None or cost <= best:
                 best, pick = cost, m
         return pick

@@ -1131,7 +1131,7 @@ uint32_t zn_decode_fused_group(uint64_t K) {
   }
   uint32_t ncg = 1; uint64_t best = ~0ull;
   for (uint32_t m = 1; m <= 4u; m++) {
-    const uint64_t wgs = (K + m - 1u) / m, rounds = (wgs + (uint64_t)slots - 1u) / (uint64_t)slots;
+    const uint64_t wgs = K ? (K + m - 1u) / m : 1u, rounds = (wgs + (uint64_t)slots - 1u) / (uint64_t)slots;
     const uint64_t cost = rounds * (13u + 85u * m);
     if (cost <= best) { best = cost; ncg = m; }     // (a tie: the larger group — fewer parses)
   }
