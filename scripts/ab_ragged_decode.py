@@ -11,7 +11,7 @@ from zipnn_amd import codec
 def main():
     libs = [(os.path.basename(p), ZnLib(p)) for p in sys.argv[1:]]
     dev = torch.device("cuda:0")
-    for n in ((1 << 30), (1 << 30) + 200 * 1024, (100 << 20), (100 << 20) + 250 * 1024 + 2, (65 << 20) + 250 * 1024, (8 << 20), (8 << 20) + 3000, (8 << 20) + 200 * 1024):
+    for n in ((4 << 30), (4 << 30) + 200 * 1024, (3 << 29), (3 << 29) + 200 * 1024, (1 << 30), (1 << 30) + 200 * 1024, (100 << 20), (100 << 20) + 250 * 1024 + 2, (65 << 20) + 250 * 1024, (8 << 20), (8 << 20) + 3000, (8 << 20) + 200 * 1024):
         g = torch.Generator(device=dev); g.manual_seed(1)
         x = (torch.randn(n // 2, generator=g, device=dev) * 0.02).to(torch.bfloat16)
         flat = codec.flat_bytes(x)
