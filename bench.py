@@ -138,7 +138,8 @@ def size_sweep(lib, codec, device, steps):
     """Decode GB/s by tensor size (bf16, device-resident, event-timed): small tensors are bound by the ~100 us a workgroup needs per chunk
     group and by the launch, not by HBM."""
     out = {}
-    for mib in (64, 128, 256, 1024):          # (64: the 16-wave small-input kernel, 128: its 8-wave form, from 256 on the fused kernel)
+    for mib in (64, 128, 256, 576, 1024):     # (64: the 16-wave small-input kernel, 128: its 8-wave form, from 256 on the fused kernel; 576 MiB = 2 304 chunks lies BETWEEN two
+                                              #  rounds of workgroups: the size class the round-counting group rule of zn_decode_fused_group is for, DESIGN.md §3.1)
         n = mib << 20
         x = make_tensor(n, device, 99 + mib)
         flat = codec.flat_bytes(x)
