@@ -268,6 +268,32 @@ def cpu_baseline(raw, want_body):
     return out
 
 
+def cpu_frame_compare(flat, body, nb, rot, bm, chunk):
+    """The GPU's body of a tensor against the CPU reference's frame of the same bytes (whole buffers, sha256 of each)."""
+    import hashlib
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    try:
+        raw = flat.cpu().numpy()
+        got = body.cpu().numpy()
+        threads = min(os.cpu_count() or 1, 16)
+        if O.ref_core() is not None:
+            kind = "reference"
+            frame = O.ref_core().zipnn_core(bytearray(32), bytearray(raw.tobytes()), nb, rot, bm, 0, chunk, THR, 10, threads)     # (a copy: the core rotates its input in place)
+            back = O.ref_core().combine_dtype(memoryview(got), nb, rot, bm, chunk, raw.size, threads)                             # … and the reference decodes the GPU's body
+        else:
+            kind = "port"
+            frame = O.compress_frame(bytes(32), raw, nb, rot, bm, chunk, THR, threads)
+            back = O.decompress_body(got, nb, rot, bm, chunk, raw.size, threads)
+        want = np.frombuffer(memoryview(frame)[32:], dtype=np.uint8)
+        return {"kind": kind, "bytes": int(raw.size), "equal": bool(want.size == got.size and np.array_equal(want, got)),
+                "cpu_decodes_gpu_body": bool(np.array_equal(np.frombuffer(back, dtype=np.uint8), raw)),
+                "gpu_body_sha256": hashlib.sha256(memoryview(got)).hexdigest(), "cpu_body_sha256": hashlib.sha256(memoryview(want)).hexdigest()}
+    except Exception as e:                                 # noqa: BLE001 — a missing checker is reported, not fatal
+        return {"error": repr(e)[:200]}
+
+
 def csrc_digest():
     """sha256 over the kernel sources (zipnn_amd/csrc/*, sorted by name): what profiles/traffic_pmc.json was measured on must be what runs."""
     import glob
@@ -298,8 +324,10 @@ def traffic_of(kind, n_bytes):
         return None, None
 
 
-def other_dtypes(lib, codec, device, steps):
-    """BASELINE.json configs[2] (+ fp8): 1 GiB each, event-timed; the bytes of record for these dtypes on the driver's run."""
+def other_dtypes(lib, codec, device, steps, cpu_compare=True):
+    """BASELINE.json configs[2] (+ fp8): 1 GiB each, event-timed; the bytes of record for these dtypes on the driver's run.
+    cpu_compare: after the timed regions the WHOLE 1 GiB body is compared with the frame the CPU reference writes for the same tensor
+    (oracle/_ref = the reference's C core, or the C restatement where that build is absent) — sha256 of both on the line."""
     out = {}
     cases = [("fp16", torch.float16, 2, 0, 10, CHUNK), ("fp32", torch.float32, 4, 1, 220, CHUNK)]
     f8 = getattr(torch, "float8_e4m3fn", None)
@@ -324,7 +352,8 @@ def other_dtypes(lib, codec, device, steps):
         exact = exact and bool(torch.equal(dst, flat))
         cpl = used - 9 * nb * ((n + chunk - 1) // chunk)
         tr, _ = traffic_of({"fp8_e4m3": "fp8"}.get(name, name), n)
-        out[name] = {"GiB": 1.0, "ratio": round((used + 32) / n, 5), "exact": exact, "decompress_traffic": tr, "algorithmic_bytes": int(n + cpl),
+        cmp_ = cpu_frame_compare(flat, body[:used], nb, rot, bm, chunk) if cpu_compare else None      # (outside every timed region; the checker, never the thing measured)
+        out[name] = {"GiB": 1.0, "ratio": round((used + 32) / n, 5), "exact": exact, "body_vs_cpu_reference": cmp_, "decompress_traffic": tr, "algorithmic_bytes": int(n + cpl),
                      "decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "decompress_ms_min": round(d["min"], 4),
                      "decompress_roofline_frac": round((n + cpl) / (d["avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                      "compress_GBps": round(n / c["avg"] / 1e6, 1), "compress_ms": round(c["avg"], 4), "compress_ms_min": round(c["min"], 4),
@@ -745,7 +774,7 @@ def main():
             line["llama8b"] = llama
     if rank == 0:
         if world == 1 and not args.no_other_dtypes:
-            line["other_dtypes"] = other_dtypes(lib, codec, device, max(4, min(args.steps, 20)))
+            line["other_dtypes"] = other_dtypes(lib, codec, device, max(4, min(args.steps, 20)), cpu_compare=not args.no_cpu_baseline)
         if world == 1 and not args.no_other_dtypes:
             line["sizes"] = size_sweep(lib, codec, device, max(4, min(args.steps, 20)))
         if world == 1 and not args.no_plugin:

@@ -67,5 +67,31 @@ def parse_frame(frame):
                 body=frame[32 + ext_len:])
 
 
+# ---- delta (XOR) frames written by the reference: tests/golden/make_golden_delta.py ----
+_DELTA_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_delta_v1.npz")
+_DELTA = None
+
+
+def delta_load():
+    """[(meta, frame bytes, base bytes)] — `base` is the delta_second_data the reference was given."""
+    global _DELTA
+    if _DELTA is None:
+        z = np.load(_DELTA_PATH)
+        meta = json.loads(bytes(z["meta.json"]).decode())
+        _DELTA = [(m, bytes(z[m["name"] + ".frame"]), bytes(z[m["name"] + ".base"])) for m in meta]
+    return _DELTA
+
+
+def delta_names():
+    return [m["name"] for m, _, _ in delta_load()]
+
+
+def delta_get(name):
+    for m, f, b in delta_load():
+        if m["name"] == name:
+            return m, f, b
+    raise KeyError(name)
+
+
 def sha(b):
     return hashlib.sha256(bytes(b)).hexdigest()

@@ -220,6 +220,19 @@ def test_golden_frames_through_zipnn_api(lib, name):
         assert dev.is_cuda and dev.cpu().view(torch.uint8).numpy().tobytes() == raw
 
 
+@pytest.mark.parametrize("name", G.delta_names())
+def test_reference_written_delta_frames_through_zipnn_api(lib, name):
+    """Frames the REFERENCE wrote in its delta mode (tests/golden/make_golden_delta.py; reference zipnn/zipnn.py:625-640, 983-1004,
+    its tests/simple_stress_tests.py:85-150,180-203) decode on the GPU — XOR fused into the decode kernels — to the reference's input,
+    and the GPU encoder (XOR fused into stats / emit) writes the reference's frame back, byte for byte."""
+    from zipnn_amd import ZipNN
+    meta, blob, base = G.delta_get(name)
+    ctor = dict(meta["ctor"])
+    back = bytes(ZipNN(**ctor).decompress(blob, delta_second_data=base))
+    assert len(back) == meta["in_len"] and G.sha(back) == meta["in_sha256"]
+    assert G.sha(bytes(ZipNN(**ctor).compress(back, delta_second_data=base))) == meta["frame_sha256"]
+
+
 def test_reference_stress_sizes_roundtrip(lib):
     """Sizes of the reference's tests/simple_stress_tests.py:19-70 (chunk boundary ±1 KiB)."""
     from zipnn_amd import ZipNN
@@ -1118,3 +1131,71 @@ def test_onepass_encoder_on_hardware(lib, dtype):
             assert zb.cpu().numpy().tobytes() == O.compress_frame(bytes(32), z.numpy(), P, rot, bm, chunk, threads=8)[32:]
     finally:
         lib.set_encode_onepass(1)
+
+
+def _binding_cases():
+    """The sixteen cases of tests/run_reference_cases.py (= the reference's tests/simple_stress_tests.py:19-264 with sizes trimmed), as the
+    core calls the reference's Python package makes for them: (name, [data pieces], numBuf, bits_mode, bytes_mode, origChunkSize) — a streaming
+    case is one core call per streaming chunk (zipnn/zipnn.py:612-635), a delta case codes data ^ base (:625-640)."""
+    rng = np.random.default_rng(123)
+    rb = lambda n: rng.integers(0, 256, n, dtype=np.uint8).tobytes()      # noqa: E731
+    g = torch.Generator().manual_seed(9)
+    tb = lambda t: t.contiguous().view(torch.uint8).reshape(-1).numpy().tobytes()      # noqa: E731
+    xor = lambda a, b: bytes(np.frombuffer(a, np.uint8) ^ np.frombuffer(b, np.uint8))    # noqa: E731
+    cut = lambda d, sc: [d[o:o + sc] for o in range(0, len(d), sc)]                         # noqa: E731
+    cs = []
+    for kb in (255, 256, 257):
+        cs.append((f"torch_bf16_{kb}k", [tb((torch.rand(kb * KB, generator=g) * 2 - 1).to(torch.bfloat16))], 2, 1, 10, C))
+    cs.append(("bytes_255k", [rb(255 * KB)], 2, 1, 10, C))
+    cs.append(("torch_bf16_weights", [tb((torch.randn(300 * KB, generator=g) * 0.02).to(torch.bfloat16))], 2, 1, 10, C))
+    cs.append(("torch_fp32", [tb(torch.randn(70 * KB, generator=g) * 0.02)], 4, 1, 220, C))
+    hc = torch.ones(100, 100); hc[50:] = torch.rand(50, 100, generator=g) * 2 - 1
+    cs.append(("torch_fp16_half_const", [tb(hc.to(torch.float16))], 2, 0, 10, C))
+    for sc in (2 ** 19, 2 ** 20):
+        cs.append((f"streaming_{sc}", cut(rb(10 * KB), sc), 2, 1, 10, C))
+    cs.append(("streaming_multi_frame", cut(tb((torch.randn(400 * KB, generator=g) * 0.02).to(torch.bfloat16)), 2 ** 18), 2, 1, 10, C))
+    a, b, c = rb(10 * KB), rb(10 * KB), rb(10 * KB)
+    cs.append(("delta_byte", [xor(a + b, a + c)], 2, 1, 10, C))
+    cs.append(("delta_byte_streaming", cut(xor(a + b, a + c), 2 ** 20), 2, 1, 10, C))
+    cs.append(("delta_file", [xor(a + b, a + c)], 2, 1, 10, C))
+    fa, fb, fc = (rng.random(8 * KB).astype(np.float32) for _ in range(3))
+    cs.append(("bytes_float32", [fa.tobytes()], 4, 1, 220, C))
+    cs.append(("bytes_float32_streaming", cut(fa.tobytes(), 2 ** 20), 4, 1, 220, C))
+    cs.append(("bytes_float32_streaming_delta", cut(xor(np.concatenate([fa, fb]).tobytes(), np.concatenate([fa, fc]).tobytes()), 2 ** 20), 4, 1, 220, C))
+    return cs
+
+
+@pytest.fixture(scope="module")
+def ref_binding():
+    """tests/ref_binding/zipnn_core.py — the module INTEGRATION.md §1 tells a zipnn maintainer to drop in for the compiled extension
+    (reference csrc/zipnn_core_module.c:9-23) — loaded over the REAL library (no $ZIPNN_HIP_LIB: its default, zipnn_amd/libzipnn_hip.so)."""
+    import importlib.util
+    import os
+    assert not os.environ.get("ZIPNN_HIP_LIB"), "this test is about the in-tree library"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_binding", "zipnn_core.py")
+    spec = importlib.util.spec_from_file_location("zn_ref_binding_on_hardware", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod._L._name.endswith(os.path.join("zipnn_amd", "libzipnn_hip.so"))
+    return mod
+
+
+@pytest.mark.parametrize("case", _binding_cases(), ids=lambda c: c[0])
+def test_integration_stub_on_hardware_equals_the_reference_extension(lib, ref_binding, case):
+    """The two functions of the reference's extension module — zipnn_core.zipnn_core(...) and zipnn_core.combine_dtype(...)
+    (csrc/zipnn_core_module.c:9-23; called at zipnn/zipnn.py:714-725, 1143-1151) — called with the SAME positional arguments on
+    oracle/_ref (the reference's C compiled where it lies) and on the INTEGRATION stub over the GPU: same frame bytes, same
+    header length field written back into the caller's header, same decoded bytes, each core decoding the other's frame."""
+    ref = O.ref_core()
+    if ref is None:
+        pytest.skip("oracle/_ref was not built (no /root/reference at build time)")
+    name, pieces, P, rot, bm, chunk = case
+    for piece in pieces:
+        h_ref, h_gpu = bytearray(range(32)), bytearray(range(32))
+        f_ref = bytes(ref.zipnn_core(h_ref, bytearray(piece), P, rot, bm, 0, chunk, 0.95, 10, 4))       # (a copy: the reference rotates its input in place)
+        f_gpu = bytes(ref_binding.zipnn_core(h_gpu, bytearray(piece), P, rot, bm, 0, chunk, 0.95, 10, 4))
+        assert f_gpu == f_ref, name
+        assert h_gpu == h_ref                                                                               # zipnn_core.c:121
+        n = len(piece)
+        assert bytes(ref_binding.combine_dtype(f_ref[32:], P, rot, bm, chunk, n, 4)) == piece              # the reference's frame through the stub
+        assert bytes(ref.combine_dtype(f_gpu[32:], P, rot, bm, chunk, n, 4)) == piece                       # the stub's frame through the reference

@@ -84,6 +84,19 @@ def test_zipnn_api_reproduces_golden(use_simt, name):
     assert G.sha(again) == meta["frame_sha256"]
 
 
+@pytest.mark.parametrize("name", G.delta_names())
+def test_zipnn_api_reproduces_reference_written_delta_frames(use_simt, name):
+    """ZipNN(delta_compressed_type="byte") on frames the REFERENCE wrote in its delta mode (tests/golden/make_golden_delta.py;
+    reference zipnn/zipnn.py:625-640, 983-1004): decompress(frame, base) == data and compress(data, base) == frame, byte for byte —
+    with the XOR fused into the kernels here instead of a host pass."""
+    from zipnn_amd import ZipNN
+    meta, blob, base = G.delta_get(name)
+    ctor = dict(meta["ctor"])
+    back = bytes(ZipNN(**ctor).decompress(blob, delta_second_data=base))
+    assert len(back) == meta["in_len"] and G.sha(back) == meta["in_sha256"]
+    assert G.sha(bytes(ZipNN(**ctor).compress(back, delta_second_data=base))) == meta["frame_sha256"]
+
+
 FUSED = [("bf16", 3 * C, 2, 1, 10, C, 3), ("bf16", 2 * C + 100, 2, 1, 10, C, 2), ("fp16", 2 * C, 2, 0, 10, C, 2),
          ("fp32", 2 * C, 4, 1, 220, C, 2), ("fp8", 2 * C, 1, 1, 10, C, 2), ("const", 2 * C, 2, 1, 10, C, 2),
          ("rand", 2 * C, 2, 1, 10, C, 2), ("u11", 2 * C, 2, 1, 10, C, 2), ("skew", 2 * C, 1, 1, 10, C, 2),

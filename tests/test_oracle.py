@@ -36,6 +36,24 @@ def test_oracle_reproduces_golden_frames_bit_exact(name):
     assert rebuilt == blob
 
 
+@pytest.mark.parametrize("name", G.delta_names())
+def test_oracle_on_reference_written_delta_frames(name):
+    """Delta frames written by the reference's own package (tests/golden/make_golden_delta.py; reference zipnn/zipnn.py:625-640,
+    983-1004: XOR with the second buffer on the host around the core call): the oracle decodes them to data ^ base and re-encodes
+    data ^ base to the same bytes."""
+    meta, blob, base = G.delta_get(name)
+    out, rebuilt = b"", b""
+    for fr in G.split_frames(blob):
+        p = G.parse_frame(fr)
+        x = O.decompress_body(p["body"], p["num_buf"], p["bits_mode"], p["bytes_mode"], p["chunk"], p["orig_len"], threads=2)
+        rebuilt += O.compress_frame(p["header"], x, p["num_buf"], p["bits_mode"], p["bytes_mode"], p["chunk"], threshold=0.95, threads=2)
+        out += x
+    data = bytes(np.frombuffer(out, np.uint8) ^ np.frombuffer(base, np.uint8))
+    assert len(data) == meta["in_len"] and G.sha(data) == meta["in_sha256"]
+    assert rebuilt == blob and G.sha(rebuilt) == meta["frame_sha256"]
+    assert meta["frame_len"] < meta["plain_frame_len"]          # the delta is what made it small
+
+
 def _planes(rng):
     """byte planes with the shapes the path meets: skewed exponents, flat mantissas, tiny, RLE."""
     out = []
