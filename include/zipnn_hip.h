@@ -49,7 +49,8 @@ typedef enum zn_status {
   ZN_E_CORRUPT = -4,  /* compressed body is malformed (sizes, huff0 header, streams) */
   ZN_E_TYPE = -5,     /* a chunk-type byte is not 0/1 (reference: MemoryError "Compress Type is not correct", zipnn_core.c:993-996) */
   ZN_E_NODEV = -6,    /* no usable GPU */
-  ZN_E_ALLOC = -7     /* device/host allocation failed */
+  ZN_E_ALLOC = -7,    /* device/host allocation failed */
+  ZN_E_TIMEOUT = -8   /* a bounded device-side wait between workgroups of one launch ran out (a preempted or faulted device): the data was not judged */
 } zn_status;
 
 /* ABI version of this header (bumped on incompatible change). */

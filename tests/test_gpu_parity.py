@@ -1199,3 +1199,52 @@ def test_integration_stub_on_hardware_equals_the_reference_extension(lib, ref_bi
         n = len(piece)
         assert bytes(ref_binding.combine_dtype(f_ref[32:], P, rot, bm, chunk, n, 4)) == piece              # the reference's frame through the stub
         assert bytes(ref.combine_dtype(f_gpu[32:], P, rot, bm, chunk, n, 4)) == piece                       # the stub's frame through the reference
+
+
+def test_onepass_automatic_mode_backs_off_and_never_takes_delta_calls(lib):
+    """the one-pass encoder's layout speculation (every plane but the last raw) fails on sparse / delta tensors, and a failed call runs twice.
+    Automatic mode therefore (a) never takes a call with a delta base and (b) sits out the next automatic calls of the device after a misspeculation.
+    6 144+ full chunks of 16 KiB (the automatic threshold counts chunks), bodies compared with the oracle's every time."""
+    from zipnn_amd import codec
+    chunk, K = 16384, 6400
+    n = chunk * K
+    g = torch.Generator().manual_seed(77)
+    sparse = torch.zeros(n, dtype=torch.uint8)
+    sparse[::5] = torch.randint(0, 6, (sparse[::5].numel(),), generator=g, dtype=torch.uint8)        # both planes Huffman-coded: the speculation fails
+    w = (torch.randn(n // 2, generator=g) * 0.02).to(torch.bfloat16).view(torch.uint8)
+    want_sparse = O.compress_frame(bytes(32), sparse.numpy(), 2, 1, 10, chunk, threads=8)[32:]
+    want_w = O.compress_frame(bytes(32), w.numpy(), 2, 1, 10, chunk, threads=8)[32:]
+    sd, wd = sparse.cuda(), w.cuda()
+    lib.release_workspace()                                    # a device without history
+    lib.set_encode_onepass(1)
+    assert codec.compress_device(lib, wd, 2, 1, 10, chunk, 0.95).cpu().numpy().tobytes() == want_w
+    assert "zn_k_encode_onepass" in lib.last_kernels() and "failed" not in lib.last_kernels()            # plain weights: taken, and right
+    assert codec.compress_device(lib, sd, 2, 1, 10, chunk, 0.95).cpu().numpy().tobytes() == want_sparse
+    assert "speculation failed" in lib.last_kernels()                                                     # the cliff, once
+    for _ in range(3):                                                                                    # … then the device sits out (8 calls)
+        assert codec.compress_device(lib, sd, 2, 1, 10, chunk, 0.95).cpu().numpy().tobytes() == want_sparse
+        assert "zn_k_encode_onepass" not in lib.last_kernels() and "zn_k_encode_emit" in lib.last_kernels()
+    lib.release_workspace()                                    # (forgets the back-off)
+    base = (w.clone().view(torch.bfloat16).float() * 1.001).to(torch.bfloat16).view(torch.uint8)
+    want_delta = O.compress_frame(bytes(32), (w ^ base).numpy(), 2, 1, 10, chunk, threads=8)[32:]
+    got = codec.compress_device(lib, wd, 2, 1, 10, chunk, 0.95, delta=base.cuda())
+    assert "zn_k_encode_onepass" not in lib.last_kernels()                                                # a delta call: never speculated
+    assert got.cpu().numpy().tobytes() == want_delta
+    lib.release_workspace()
+
+
+def test_decode_status_after_the_workspace_is_released(lib):
+    """a thread that holds the token of an unverified check = 0 decode must not be told "ok" once the status words are gone."""
+    from zipnn_amd import codec
+    from zipnn_amd._capi import ZnError
+    d = gen_bytes("bf16", 3 * C + 100, 8)
+    body = torch.from_numpy(np.frombuffer(O.compress_frame(HDR, d, 2, 1, 10, C)[32:], dtype=np.uint8).copy()).cuda()
+    out = codec.decompress_device(lib, body, 2, 1, 10, C, len(d), check=False)
+    lib.decode_status()                                        # the verdict of that call: ok
+    assert out.cpu().numpy().tobytes() == d
+    codec.decompress_device(lib, body, 2, 1, 10, C, len(d), check=False)
+    torch.cuda.synchronize()
+    lib.release_workspace()
+    with pytest.raises(ZnError):
+        lib.decode_status()                                    # "cannot vouch for it", not a guess
+    lib.decode_status()                                        # (asked and answered: the token is spent)

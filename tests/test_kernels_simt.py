@@ -1011,6 +1011,21 @@ def test_decode_status_belongs_to_the_calling_threads_call(simt_lib):
     assert res == [None]
 
 
+def test_decode_status_after_the_workspace_is_released(simt_lib):
+    """the token of an unverified check = 0 decode outlives zn_release_workspace; the answer is then an error, once, not "ok"."""
+    d = gen_bytes("bf16", 2 * C, 4)
+    gb = torch.frombuffer(bytearray(O.compress_frame(HDR, d, 2, 1, 10, C)[32:]), dtype=torch.uint8)
+    out = torch.empty(2 * C, dtype=torch.uint8)
+    simt_lib.decompress_dev(gb.data_ptr(), gb.numel(), 2, 1, 10, C, 2 * C, out.data_ptr(), check=False)
+    simt_lib.release_workspace()
+    with pytest.raises(RuntimeError):
+        simt_lib.decode_status()
+    simt_lib.decode_status()                            # the token is spent: nothing has run since
+    simt_lib.decompress_dev(gb.data_ptr(), gb.numel(), 2, 1, 10, C, 2 * C, out.data_ptr(), check=False)
+    simt_lib.decode_status()
+    assert out.numpy().tobytes() == d
+
+
 def test_mixed_batch_of_two_full_kinds_takes_the_two_stream_path(simt_lib):
     """zn_decompress_batch_dev: a batch whose one-plane tensors AND whose multi-plane tensors each have at least 512 chunks forks the two kinds' launches onto two
     streams of the library's own and joins them again — per-kind bases in the launch-wide arrays, ragged tensors, a tensor of each kind.  Small

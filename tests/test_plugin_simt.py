@@ -416,6 +416,30 @@ def test_get_slice_of_a_compressed_tensor_decodes_only_the_covering_chunks(use_s
         del os.environ["ZIPNN_AMD_REFERENCE_GET_SLICE"]
 
 
+def test_get_slice_of_a_zero_dim_compressed_tensor(use_simt, tmp_path):
+    """a 0-dim tensor LEFT COMPRESSED in a file (neither writer does that — the frame is larger than the value — but a third party's file
+    may): CompressedSlice used to take its 'empty' branch and hand back uninitialised memory.  A hand-built file: the frame of a scalar, listed in
+    znn_compressed_vectors with shape []."""
+    import json
+    from safetensors.torch import save_file
+    from zipnn_amd import ZipNN
+    from zipnn_amd import zipnn as Z
+    for val, dt in ((torch.tensor(3.25, dtype=torch.bfloat16), "BF16"), (torch.tensor(-7.5, dtype=torch.float32), "F32")):
+        frame = bytes(ZipNN(input_format="torch").compress(val.clone()))
+        stored = torch.frombuffer(bytearray(frame), dtype=torch.uint8)
+        path = os.path.join(tmp_path, f"scalar_{dt}.znn.safetensors")
+        save_file({"s": stored, "plain": torch.arange(4)}, path,
+                  {"format": "pt", Z.METADATA_KEY: json.dumps({"s": Z.build_compressed_tensor_info(val)})})
+        with Z.SafeOpen(path, framework="pt", device="cpu") as f:
+            assert torch.equal(f.get_tensor("s"), val)
+            sl = f.get_slice("s")
+            assert sl.get_shape() == [] and sl.get_dtype() == dt
+            for idx in ((), Ellipsis):
+                got = sl[idx]
+                assert got.shape == () and got.dtype == val.dtype and got.item() == val.item(), (dt, idx)
+            assert sl.last_chunk_range == (0, 1)
+
+
 def test_read_ahead_failures_fall_back_to_the_per_tensor_path(use_simt, tmp_path, monkeypatch):
     """whatever goes wrong inside the plugin's read-ahead (one corrupt frame in the file, an allocation that does not fit)
     only switches the read-ahead off — every healthy tensor still loads, and the error surfaces for the tensor that has it, as with the

@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_NAME = "libzipnn_hip.so"
 
-ZN_OK, ZN_E_ARG, ZN_E_HIP, ZN_E_CAP, ZN_E_CORRUPT, ZN_E_TYPE, ZN_E_NODEV, ZN_E_ALLOC = 0, -1, -2, -3, -4, -5, -6, -7
+ZN_OK, ZN_E_ARG, ZN_E_HIP, ZN_E_CAP, ZN_E_CORRUPT, ZN_E_TYPE, ZN_E_NODEV, ZN_E_ALLOC, ZN_E_TIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7, -8
 
 
 class ZnError(RuntimeError):

@@ -46,8 +46,16 @@ def build_extension(force=False, verbose=False, defines=(), out=None):
     os.makedirs(objdir, exist_ok=True)
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"] + [f"-D{d}" for d in defines]
 
+    headers = [f for f in glob.glob(os.path.join(CSRC, "*")) if not f.endswith(".hip")] + [os.path.join(os.path.dirname(HERE), "include", "zipnn_hip.h")]
+    stamp = os.path.join(objdir, "flags.txt")
+    same_flags = os.path.exists(stamp) and open(stamp).read() == " ".join(flags)
+    newest_header = max(os.path.getmtime(h) for h in headers)
+
     def one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        # (an object is kept when it is newer than its unit and than every header, and was built with the same flags)
+        if same_flags and not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), newest_header):
+            return obj, subprocess.CompletedProcess([], 0, "", "")
         cmd = [hipcc] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
@@ -59,6 +67,8 @@ def build_extension(force=False, verbose=False, defines=(), out=None):
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)
             raise RuntimeError("hipcc failed building " + os.path.basename(out))
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out] + [o for o, _ in res]
     if verbose:
         print(" ".join(cmd))

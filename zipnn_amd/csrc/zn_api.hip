@@ -41,6 +41,7 @@ struct Workspace {
   size_t last_tails = 0;         // tail planes of the last decompress call (for zn_last_tail_planes)
   void* buf[13] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t cap[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  uint32_t op_backoff = 0, op_penalty = 0;   // automatic one-pass encoding sits out `op_backoff` calls after a misspeculated one (compress_items)
   uint32_t lb_gen = 0;           // generation tag of the one-pass encoder's look-back words (WS_LB): a launch only believes words of its own generation, so the array is never zeroed between calls
   ZnSeg* h_segs = nullptr; size_t h_segs_cap = 0;   // pinned staging for the segment table of a batched call (capacity in ZnSeg units)
   uint64_t* h_totals = nullptr; size_t h_totals_cap = 0;   // pinned: body lengths of a batched compress
@@ -148,6 +149,7 @@ const char* zn_strerror(int s) {
     case ZN_E_TYPE: return "Compress Type is not correct in Decompression function";
     case ZN_E_NODEV: return "no HIP device";
     case ZN_E_ALLOC: return "allocation failed";
+    case ZN_E_TIMEOUT: return "a device-side wait between workgroups timed out";
     default: return "unknown status";
   }
 }
@@ -274,7 +276,12 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
     if (op_mode == 0 || chunks_of[q] == 0) continue;
     bool ok = true, rot = true;
     for (const ZnESeg& sg : segs[q]) { if (sg.g.n >= (1ull << 38)) ok = false; if (sg.nfull && !sg.g.rot) rot = false; }
-    op_of[q] = ok && (op_mode == 2 || (q == 1 && rot && chunks_of[q] >= ZN_ONEPASS_MIN_CHUNKS));
+    // automatic mode: plain weights only.  A call with a delta base (XOR of a fine-tuned checkpoint: both planes compress) breaks the layout speculation almost
+    // always, and a misspeculation costs the whole call twice — so delta calls never take it, and after a misspeculated call the device sits out
+    // `op_backoff` automatic calls (8, doubling up to 1 024 while misspeculations keep coming; a call that speculated right halves the penalty)
+    const bool auto_ok = q == 1 && rot && !delta_of[q] && chunks_of[q] >= ZN_ONEPASS_MIN_CHUNKS;
+    if (op_mode == 1 && auto_ok && w.op_backoff > 0) { w.op_backoff--; continue; }
+    op_of[q] = ok && (op_mode == 2 || auto_ok);
   }
   const bool onepass = op_of[0] || op_of[1] || op_of[2];
   const uint64_t chunks_all = chunks_of[0] + chunks_of[1] + chunks_of[2];
@@ -339,10 +346,13 @@ static int compress_items(zn_cbatch_item* items, size_t count, hipStream_t strea
   if ((rc = launch_all(onepass))) return rc;
   if (onepass) {
     ZN_HIP(hipStreamSynchronize(stream));
-    if ((uint32_t)w.h_totals[count] & ZN_DEV_MISSPEC) {           // a tensor that does not look like weights: its bytes are where a decoder would not look for them
+    if ((uint32_t)w.h_totals[count] & (ZN_DEV_MISSPEC | ZN_DEV_SYNC_TIMEOUT)) {    // a tensor that does not look like weights: its bytes are where a decoder would not look for them
+      const bool timed_out = ((uint32_t)w.h_totals[count] & ZN_DEV_SYNC_TIMEOUT) != 0;      // (… or a look-back that gave up waiting: the four-kernel encoder waits for nobody)
+      w.op_penalty = w.op_penalty ? (w.op_penalty < 1024u ? 2u * w.op_penalty : 1024u) : 8u;
+      w.op_backoff = w.op_penalty;
       if ((rc = launch_all(false))) return rc;
-      zn_note_kernel("(one-pass speculation failed: four-kernel encoder)");
-    }
+      zn_note_kernel(timed_out ? "(one-pass look-back timed out: four-kernel encoder)" : "(one-pass speculation failed: four-kernel encoder)");
+    } else if (w.op_penalty) w.op_penalty >>= 1;
   }
   if ((rc = ws_release(w, stream, table))) return rc;
   ZN_HIP(hipStreamSynchronize(stream));
@@ -491,8 +501,10 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (!w.dfork) ZN_HIP(hipEventCreateWithFlags(&w.dfork, hipEventDisableTiming));
     if (!w.djoin) ZN_HIP(hipEventCreateWithFlags(&w.djoin, hipEventDisableTiming));
     ZN_HIP(hipEventRecord(w.dfork, stream_main));          // behind the memsets and the segment table
-    ZN_HIP(hipStreamWaitEvent(w.dstream, w.dfork, 0));
-    ZN_HIP(hipStreamWaitEvent(w.dstream2, w.dfork, 0));
+    // (from here to the join nothing returns: a failure is remembered, the side streams are joined — or, if even that fails, drained — and THEN the call fails;
+    //  kernels already queued on them must not outlive the call's claim on d_dst and the workspace)
+    hipError_t e1 = hipStreamWaitEvent(w.dstream, w.dfork, 0), e2 = hipStreamWaitEvent(w.dstream2, w.dfork, 0);
+    if (e1 != hipSuccess || e2 != hipSuccess) { t_hip_err = std::string("hipStreamWaitEvent(fork): ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2); (void)hipGetLastError(); return ZN_E_HIP; }     // (nothing queued on the side streams yet)
     zn_note_kernel("(two streams)");                        // (zn_last_kernels: the launches that follow are split over the two)
   }
   const bool fp8_last = overlap && zn_decode_overlap_on() == 2;
@@ -524,10 +536,19 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   }
   stream = stream_main;
   if (overlap) {
-    ZN_HIP(hipEventRecord(w.djoin, w.dstream)); ZN_HIP(hipStreamWaitEvent(stream_main, w.djoin, 0));
-    ZN_HIP(hipEventRecord(w.djoin2, w.dstream2)); ZN_HIP(hipStreamWaitEvent(stream_main, w.djoin2, 0));
+    hipError_t ej = hipEventRecord(w.djoin, w.dstream);
+    if (ej == hipSuccess) ej = hipStreamWaitEvent(stream_main, w.djoin, 0);
+    hipError_t ej2 = hipEventRecord(w.djoin2, w.dstream2);
+    if (ej2 == hipSuccess) ej2 = hipStreamWaitEvent(stream_main, w.djoin2, 0);
+    if (ej != hipSuccess || ej2 != hipSuccess) {           // the join itself failed: drain the side streams on the host, so that nothing of this call is still running when it returns
+      (void)hipStreamSynchronize(w.dstream); (void)hipStreamSynchronize(w.dstream2);
+      t_hip_err = std::string("two-stream join: ") + hipGetErrorString(ej != hipSuccess ? ej : ej2); (void)hipGetLastError();
+      (void)ws_release(w, stream_main, table);
+      return ZN_E_HIP;
+    }
   }
-  ZN_HIP(hipGetLastError());
+  { const hipError_t el = hipGetLastError();               // a launch that failed: the workspace is still handed back in stream order (the side streams are joined above)
+    if (el != hipSuccess) { t_hip_err = std::string("kernel launch: ") + hipGetErrorString(el); (void)ws_release(w, stream_main, table); return ZN_E_HIP; } }
   if (check) ZN_HIP(hipMemcpyAsync(w.h_status, d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
   if ((rc = ws_release(w, stream, table))) return rc;
   if (check) {
@@ -535,6 +556,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     const uint32_t st = *w.h_status;
     if (st & ZN_DEV_BAD_TYPE) return ZN_E_TYPE;
     if (st & ZN_DEV_CORRUPT) return ZN_E_CORRUPT;
+    if (st & ZN_DEV_SYNC_TIMEOUT) { t_hip_err = "a workgroup gave up waiting for another one of the same launch (device preempted or faulted?)"; return ZN_E_TIMEOUT; }
   }
   return ZN_OK;
 }
@@ -1275,7 +1297,12 @@ int zn_decode_status(void* stream_) {
     if (dev < 0 || dev >= 64) return ZN_E_ARG;
     std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
-    if (!w.buf[WS_WORDS] || w.cap[WS_WORDS] < ZN_WORDS_BYTES || w.status_gen == 0) return ZN_OK;              // no decode has run on this device yet
+    if (!w.buf[WS_WORDS] || w.cap[WS_WORDS] < ZN_WORDS_BYTES || w.status_gen == 0) {
+      // no decode has run on this device — or its status words are gone (zn_release_workspace).  A thread that still holds the token of an unverified
+      // check = 0 decode here gets "cannot vouch for it", not "ok" (ADVICE r5): the verdict went with the buffer
+      if (t_status_dev == dev && t_status_gen != 0) { t_status_gen = 0; t_status_dev = -1; return ZN_E_CORRUPT; }
+      return ZN_OK;
+    }
     int rc;
     if ((rc = ws_host_words(w))) return rc;
     hipStream_t stream = (hipStream_t)stream_;
@@ -1292,6 +1319,7 @@ int zn_decode_status(void* stream_) {
     const uint32_t st = *w.h_status;
     if (st & ZN_DEV_BAD_TYPE) return ZN_E_TYPE;
     if (st & ZN_DEV_CORRUPT) return ZN_E_CORRUPT;
+    if (st & ZN_DEV_SYNC_TIMEOUT) return ZN_E_TIMEOUT;
     return ZN_OK;
   } catch (...) { return ZN_E_ALLOC; }
 }
@@ -1384,7 +1412,9 @@ int zn_release_workspace(void) {
     if (w.djoin) { (void)hipEventDestroy(w.djoin); w.djoin = nullptr; }
     if (w.busy) { (void)hipDeviceSynchronize(); (void)hipEventDestroy(w.busy); w.busy = nullptr; }
     w.have_stream = false; w.multi = false;
-    for (uint32_t i = 0; i < ZN_STATUS_SLOTS; i++) w.slot_gen[i] = 0;      // (the status slots went with the buffers: a thread's old token matches nothing)
+    for (uint32_t i = 0; i < ZN_STATUS_SLOTS; i++) w.slot_gen[i] = 0;      // (the status slots went with the buffers: a thread's old token matches nothing;
+    w.last_slot = 0; w.last_K = 0; w.last_tails = 0;                       //  status_gen keeps counting, so that no later call can be handed an old token's generation)
+    w.op_backoff = 0; w.op_penalty = 0;
   }
   if (prev >= 0) (void)hipSetDevice(prev);
   return ZN_OK;

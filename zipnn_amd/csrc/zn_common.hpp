@@ -22,6 +22,7 @@
 // device-side status bits OR-ed into the per-call status word
 #define ZN_DEV_BAD_TYPE 1u
 #define ZN_DEV_CORRUPT 2u
+#define ZN_DEV_SYNC_TIMEOUT 8u   // a workgroup gave up waiting for another workgroup of the same launch (the merge workgroups of a partial chunk, the one-pass encoder's look-back): not a verdict on the data
 #define ZN_DEV_MISSPEC 4u  // the one-pass encoder's layout speculation (every plane but the last stored raw) did not hold: the caller runs the four-kernel encoder
 
 // plane-chunk kinds resolved by the decoder from (type, stored size, plane length)

@@ -895,7 +895,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     __shared__ uint32_t ok_s, serial_s;
     if (tid == 0) { ok_s = zn_flag_wait(tailsync + 2u * tt, (uint32_t)P) ? 1u : 0u; serial_s = 0; ZN_FLAG_ACQUIRE(); }      // (one lane's acquire drops this CU's L1 lines: the tail workgroups' bytes come from L2)
     __syncthreads();
-    if (!ok_s) { if (tid == 0) atomicOr(status, ZN_DEV_CORRUPT); return; }
+    if (!ok_s) { if (tid == 0) atomicOr(status, ZN_DEV_SYNC_TIMEOUT); return; }     // (a slow or preempted device is not a corrupt frame: ZN_E_TIMEOUT)
     static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS");
     // every merge workgroup classifies the chunk's planes for itself (the same descriptors from all of them: raw / RLE / decoded by the tail workgroups) …
     if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane, true, &serial_s);

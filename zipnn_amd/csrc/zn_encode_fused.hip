@@ -940,7 +940,7 @@ struct ZnOnePassLds {
     struct { ZnEncDesc D; uint32_t pad_; uint16_t qc[P][4][256];       // then: the last plane's descriptor, the planes' per-quarter counts,
              union { ZnTablesLds tab; ZnEmitLds<P> em; } u;             //       the table job's scratch / the emit pass's buffers,
              uint32_t kind[4], csz[4], rle[4], need[4];                 //       per plane: 0 raw / 1 RLE / 2 huff0, stored size, the RLE byte, "wants a code table"
-             uint64_t excl; } b;
+             uint64_t excl; uint32_t excl_bad; } b;
   };
 };
 
@@ -1026,10 +1026,15 @@ __global__ __launch_bounds__(ZN_E_THREADS, ZN_OP_WGS) void zn_k_encode_onepass(Z
     const uint64_t tag = (uint64_t)gen << (ZN_LB_VBITS + 2u);
     const uint64_t mine = csz_last;
     uint64_t excl = 0;
+    bool timed_out = false;
     if (c == 0) { if (lane == 0) ZN_LB_STORE(lb, tag | (2ull << ZN_LB_VBITS) | mine); }
     else {
       if (lane == 0) ZN_LB_STORE(lb, tag | (1ull << ZN_LB_VBITS) | mine);
       int64_t j0 = (int64_t)c - 1;               // lane l looks at chunk j0 - l (of this tensor)
+      // (bounded like zn_flag_wait: a predecessor that never publishes — a device fault, a kernel stopped by a debugger — must not hang the launch and the
+      //  host behind it.  After two seconds the workgroup reports ZN_DEV_SYNC_TIMEOUT, publishes an inclusive word all the same — its successors stop
+      //  waiting at once — and leaves; the host then runs the four-kernel encoder, which waits for nobody.  ADVICE r5)
+      const unsigned long long t0 = ZN_FLAG_CLOCK();
       for (;;) {
         const int64_t j = j0 - (int64_t)lane;
         uint32_t fi;
@@ -1042,19 +1047,22 @@ __global__ __launch_bounds__(ZN_E_THREADS, ZN_OP_WGS) void zn_k_encode_onepass(Z
           fi = im ? (uint32_t)__builtin_ctzll(im) : 64u;                    // the nearest predecessor with an inclusive prefix
           const uint64_t upto = fi >= 63u ? ~0ull : ((2ull << fi) - 1ull);     // lanes 0 .. fi
           if (!(nm & upto)) break;               // everything up to it is published
+          if (ZN_FLAG_CLOCK() - t0 > 200000000ull) { timed_out = true; break; }      // (wave-uniform: one scalar clock)
           ZN_LB_SLEEP();
         }
+        if (timed_out) break;
         excl += zn_wave_sum64_e((lane <= fi) ? (v & ZN_LB_VMASK) : 0ull);
         if (fi < 64u) break;
         j0 -= 64;
       }
       if (lane == 0) ZN_LB_STORE(lb, tag | (2ull << ZN_LB_VBITS) | ((excl + mine) & ZN_LB_VMASK));
+      if (timed_out && lane == 0) atomicOr(status, ZN_DEV_SYNC_TIMEOUT);
     }
-    if (lane == 0) L.b.excl = excl;
+    if (lane == 0) { L.b.excl = excl; L.b.excl_bad = timed_out ? 1u : 0u; }
   }
   __syncthreads();
   ZN_PT(14);  // look-back
-  if (!spec_ok) return;
+  if (!spec_ok || L.b.excl_bad) return;
 
   // ---- 4. emit: the chunk again (Infinity Cache), raw planes to their speculated places, the last plane behind its predecessors ----
   uint64_t off[P];

@@ -676,6 +676,9 @@ class CompressedSlice:
                 rest = idx                      # (negative steps: the whole tensor, torch reports what it does not index)
         row_bytes = n // rows if rows else 0
         byte_lo, byte_hi = a * row_bytes, b * row_bytes
+        scalar = not shape and n > 0             # a 0-dim tensor left compressed (no writer of ours or the reference's does that — the frame is larger than the
+        if scalar:                               #  value — but a third party's file may): its one element is all the bytes, decoded and viewed as the scalar
+            byte_lo, byte_hi = 0, n
         if byte_hi <= byte_lo:
             self.last_chunk_range = (0, 0)
             t = torch.empty((max(b - a, 0),) + shape[1:], dtype=tdt, device=want) if shape else torch.empty((), dtype=tdt, device=want)
@@ -688,7 +691,7 @@ class CompressedSlice:
             if work.type == "cuda":
                 torch.cuda.current_stream(work).synchronize()      # (`buf` may be a block that kernels queued earlier still use)
             _capi.lib().decompress_range_dev(self._frame[body_off:], P, bits, byts, chunk, n, c_lo, c_hi, dev_index, buf.data_ptr())
-            t = buf[byte_lo - base: byte_hi - base].view(tdt).reshape((b - a,) + shape[1:])
+            t = buf[byte_lo - base: byte_hi - base].view(tdt).reshape(() if scalar else (b - a,) + shape[1:])
             if want != work:
                 t = t.to(want)
         sel = (() if lead is None else (lead,)) + tuple(rest)
