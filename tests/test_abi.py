@@ -75,3 +75,21 @@ def test_cited_profiles_exist():
     missing = {name: src for name, src in cited.items() if not os.path.exists(os.path.join(ROOT, "profiles", name))}
     assert not missing, missing
     assert len(cited) > 20
+
+
+def test_design_quotes_the_binary_s_register_and_spill_counts(hip_lib):
+    """DESIGN.md's register / spill / LDS figures are a generated table (scripts/codeobj_stats.py --write), and this test reads the same
+    fields (.vgpr_count, .vgpr_spill_count, .sgpr_spill_count, .private_segment_fixed_size, .group_segment_fixed_size) out of the code objects the library was
+    just linked from: a kernel change that moves them fails here until the document is regenerated."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("no llvm-readelf on this machine")
+    spec = importlib.util.spec_from_file_location("codeobj_stats", os.path.join(ROOT, "scripts", "codeobj_stats.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    if not os.path.isdir(m.OBJDIR) or not any(f.endswith(".hip.o") for f in os.listdir(m.OBJDIR)):
+        pytest.skip("the library was not built on this machine (prebuilt .so only)")
+    stated = m.design_block()
+    assert stated is not None, "DESIGN.md lost its codeobj block"
+    assert stated == m.table().strip(), "DESIGN.md's register/spill table differs from the built code objects: python scripts/codeobj_stats.py --write"
+    assert "(not in this build)" not in stated
