@@ -210,8 +210,17 @@ int zn_set_decode_wide(int mode);
 
 /* slices of the three-stage pipeline upload | code | download that large pageable buffers can go through in the host-buffer entry points
  * (zn_compress / zn_decompress).  0 (default) = automatic (compress: 4-8 slices from 192 MiB up; decompress: one shot — measured: no gain
- * there), 1 = never, 2..64 = that many, both directions.  Returns 0 or ZN_E_ARG. */
+ * there — unless the direct transfers of zn_set_host_direct are on), 1 = never, 2..64 = that many, both directions.  Returns 0 or ZN_E_ARG. */
 int zn_set_host_slices(int slices);
+
+/* how the host-buffer entry points (zn_compress / zn_decompress, the *_multi forms, zn_copy_to_host / _to_device) move a caller's pageable buffer:
+ * bit 2 (default, = 4): result buffers get madvise(MADV_HUGEPAGE) before they are first written — a page-size hint, nothing else;
+ * bit 0 / bit 1 (opt-in; 7 = everything): device-to-host / host-to-device transfers of 128 MiB and more may go DIRECT — the caller's pages pinned piece
+ * by piece (hipHostRegister), DMA straight between them and HBM, the two directions of a call pipelined in 4-8 slices; only for calls whose result buffer
+ * is already backed by pages (recycled buffers), anything else takes the staged copy through the library's own pinned buffers.  1 GiB bf16 each way:
+ * 23 ms direct with recycled buffers against 31-36 ms staged; why it is not the default: profiles/r06_host_path.txt (calls that fault a fresh result
+ * buffer in get slower in a long-lived process that has pinned user memory).  Also ZIPNN_AMD_HOST_DIRECT=0..7 in the environment.  Returns 0 or ZN_E_ARG. */
+int zn_set_host_direct(int mode);
 
 /* the one-pass encoder (full chunks histogrammed, coded and placed by one workgroup each, the chunk's second read aimed at the Infinity Cache) —
  * 0 = never (the four-kernel encoder only), 1 (default; ZIPNN_AMD_ONEPASS=0/1/2 in the environment changes the default) = automatic: calls whose

@@ -282,6 +282,9 @@ static inline hipError_t hipMalloc(void** p, size_t n) { return posix_memalign(p
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned) { return hipMalloc(p, n); }
 static inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0 };
+static inline hipError_t hipHostRegister(void*, size_t, unsigned) { return hipSuccess; }      // (host memory IS "device" memory here: nothing to pin)
+static inline hipError_t hipHostUnregister(void*) { return hipSuccess; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

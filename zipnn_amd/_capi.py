@@ -83,6 +83,8 @@ class ZnLib:
         L.zn_merge_range_bodies.argtypes = [vpp, ctypes.POINTER(sz), ctypes.POINTER(sz), ci, ci, vp, sz, ctypes.POINTER(sz)]
         L.zn_set_host_slices.restype = ci
         L.zn_set_host_slices.argtypes = [ci]
+        L.zn_set_host_direct.restype = ci
+        L.zn_set_host_direct.argtypes = [ci]
         L.zn_set_decode_group.restype = ci
         L.zn_set_decode_group.argtypes = [ci]
         L.zn_decode_group_for.restype = ci
@@ -269,6 +271,10 @@ class ZnLib:
     def set_host_slices(self, slices):
         """Tuning knob (zn_set_host_slices): slices of the pipelined host path; 0 = automatic, 1 = one shot."""
         self._check(self._L.zn_set_host_slices(int(slices)))
+
+    def set_host_direct(self, mode):
+        """zn_set_host_direct: 4 (default) = huge-page hint only, 7 = pinned, direct DMA for recycled buffers as well, 0 = neither."""
+        self._check(self._L.zn_set_host_direct(int(mode)))
 
     def set_legacy_tree_descriptions(self, on):
         """zn_set_legacy_tree_descriptions: True = write tree descriptions the way the reference's PyPI wheels do (-1 markers)."""

@@ -584,11 +584,11 @@ int zn_decompress_batch_dev(const zn_batch_item* items, size_t count, void* stre
 
 // Large host buffers take a three-stage pipeline over slices of the chunks — upload slice i + 1 | code slice i | download slice i - 1 —
 // so that both directions of the PCIe link work at once (defined below, behind the range helpers).  0 = not applicable: the one-shot path.
-static int zn_host_slices(size_t n, size_t chunk, bool decompress);
+static int zn_host_slices(size_t n, size_t chunk, bool decompress, bool direct);
 static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
-                                      size_t chunk, float threshold, int dev, int S, void* dst, size_t dst_cap, size_t* dst_len);
+                                      size_t chunk, float threshold, int dev, int S, bool direct, void* dst, size_t dst_cap, size_t* dst_len);
 static int zn_decompress_host_pipelined(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                                        size_t orig_size, int dev, int S, void* dst);
+                                        size_t orig_size, int dev, int S, bool direct, void* dst);
 
 int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const void* delta, size_t n, int num_buf, int bits_mode,
                       int bytes_mode, size_t chunk, float threshold, int device, void* dst, size_t dst_cap, size_t* dst_len) {
@@ -597,13 +597,18 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
   DeviceScope scope(device);              // (restored on every return path)
   if (!scope.ok) { t_hip_err = "hipSetDevice"; return ZN_E_HIP; }
   const size_t bound = zn_compress_bound(n, num_buf, chunk, 0);
+  zn_host_thp_hint(dst, dst_cap);         // (a fresh result buffer faults in 2 MiB at a time, and is freed as fast: zn_host_pipe.hpp)
+  // The DIRECT transfers (the caller's buffers pinned, DMA straight between them and HBM: zn_host_pipe.hpp) are for calls whose RESULT buffer is already
+  // backed by pages — a recycled buffer, or one its owner has written before.  A call that has to fault its result in goes the staged way of rounds 1-5 in
+  // BOTH directions: page faults in a process with pinned user memory were measured slow and disruptive to every DMA in flight (profiles/r06_host_path.txt).
+  const bool direct = zn_host_pipe_detail::direct_enabled() && zn_host_resident(dst, hdr_len + 9u * (size_t)num_buf * zn_num_chunks(n, chunk) + n / 2);
   if (!delta && (num_buf == 1 || num_buf == 2 || num_buf == 4) && chunk) {
-    const int S = zn_host_slices(n, chunk, false);
+    const int S = zn_host_slices(n, chunk, false, direct);
     if (S >= 2) {
       int dev_ = 0;
       ZN_HIP(hipGetDevice(&dev_));
       if (dev_ < 0 || dev_ >= 64) return ZN_E_ARG;
-      try { return zn_compress_host_pipelined(hdr, hdr_len, src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, dev_, S, dst, dst_cap, dst_len); }
+      try { return zn_compress_host_pipelined(hdr, hdr_len, src, n, num_buf, bits_mode, bytes_mode, chunk, threshold, dev_, S, direct, dst, dst_cap, dst_len); }
       catch (...) { return ZN_E_ALLOC; }
     }
   }
@@ -626,13 +631,13 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
   do {
     // (pageable host memory through the pinned, multi-threaded pipe of zn_host_pipe.hpp; g_host_mu serialises its use)
     ZnHostPipe& pipe = g_ws[dev].pipe;
-    if (n && zn_host_pipe_copy(pipe, d_src, const_cast<void*>(src), n, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
-    if (d_delta && zn_host_pipe_copy(pipe, d_delta, const_cast<void*>(delta), n, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
+    if (n && zn_host_pipe_copy(pipe, d_src, const_cast<void*>(src), n, true, nullptr, !direct) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
+    if (d_delta && zn_host_pipe_copy(pipe, d_delta, const_cast<void*>(delta), n, true, nullptr, !direct) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
     rc = zn_compress_delta_dev(d_src, d_delta, n, num_buf, bits_mode, bytes_mode, chunk, threshold, d_body, bound ? bound : 16, &body_len, nullptr);
     if (rc) break;
     if (hdr_len + body_len > dst_cap) { rc = ZN_E_CAP; break; }
     if (hdr_len) memcpy(dst, hdr, hdr_len);
-    if (body_len && zn_host_pipe_copy(pipe, d_body, (uint8_t*)dst + hdr_len, body_len, false) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe D2H"; break; }
+    if (body_len && zn_host_pipe_copy(pipe, d_body, (uint8_t*)dst + hdr_len, body_len, false, nullptr, !direct) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe D2H"; break; }
     *dst_len = hdr_len + body_len;
     if (hdr_len >= 32) { const uint64_t total = *dst_len; memcpy((uint8_t*)dst + 24, &total, 8); }   // zipnn_core.c:121
   } while (0);
@@ -653,10 +658,12 @@ int zn_decompress_delta(const void* body, size_t body_len, const void* delta, in
   int dev = 0;
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
+  zn_host_thp_hint(dst, orig_size);
+  const bool direct = zn_host_pipe_detail::direct_enabled() && zn_host_resident(dst, orig_size);      // (see zn_compress_delta)
   if (!delta && (num_buf == 1 || num_buf == 2 || num_buf == 4) && chunk) {
-    const int S = zn_host_slices(orig_size, chunk, true);
+    const int S = zn_host_slices(orig_size, chunk, true, direct);
     if (S >= 2) {
-      try { return zn_decompress_host_pipelined(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dev, S, dst); }
+      try { return zn_decompress_host_pipelined(body, body_len, num_buf, bits_mode, bytes_mode, chunk, orig_size, dev, S, direct, dst); }
       catch (...) { return ZN_E_ALLOC; }
     }
   }
@@ -674,11 +681,11 @@ int zn_decompress_delta(const void* body, size_t body_len, const void* delta, in
   int rc = ZN_OK;
   do {
     ZnHostPipe& pipe = g_ws[dev].pipe;
-    if (body_len && zn_host_pipe_copy(pipe, d_body, const_cast<void*>(body), body_len, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
-    if (d_delta && zn_host_pipe_copy(pipe, d_delta, const_cast<void*>(delta), orig_size, true) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
+    if (body_len && zn_host_pipe_copy(pipe, d_body, const_cast<void*>(body), body_len, true, nullptr, !direct) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
+    if (d_delta && zn_host_pipe_copy(pipe, d_delta, const_cast<void*>(delta), orig_size, true, nullptr, !direct) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe H2D"; break; }
     rc = zn_decompress_delta_dev(d_body, body_len, d_delta, num_buf, bits_mode, bytes_mode, chunk, orig_size, d_dst, nullptr, 1);
     if (rc) break;
-    if (orig_size && zn_host_pipe_copy(pipe, d_dst, dst, orig_size, false) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe D2H"; break; }
+    if (orig_size && zn_host_pipe_copy(pipe, d_dst, dst, orig_size, false, nullptr, !direct) != hipSuccess) { rc = ZN_E_HIP; t_hip_err = "host pipe D2H"; break; }
   } while (0);
   return rc;
 }
@@ -962,16 +969,23 @@ int zn_pipeline_streams(Workspace& w) {
 // (pageable <-> pinned: 48-54 GB/s per direction with 8 threads, more threads do not help), and the two directions disturb each
 // other when they run at once: compress 36.9 -> 32.1 ms pipelined (4 slices), decompress 35.2 -> 35.5-38.7 ms.  So the automatic
 // choice pipelines compress only; zn_set_host_slices forces either.
-static int zn_host_slices(size_t n, size_t chunk, bool decompress) {
+static int zn_host_slices(size_t n, size_t chunk, bool decompress, bool direct) {
   const size_t K = chunk ? (n + chunk - 1) / chunk : 0;
   const int forced = g_host_slices.load(std::memory_order_relaxed);
   size_t S;
   if (forced == 1) return 0;
   if (forced >= 2) S = (size_t)forced;
-  else if (decompress) return 0;
-  else { if (n < ((size_t)192 << 20)) return 0; S = n / ((size_t)256 << 20); if (S < 4) S = 4; if (S > 8) S = 8; }   // four to eight slices
+  // (round 6: with the caller's buffers pinned ahead of the transfers — ZnHostMap — the two directions no longer share the host's copy threads, and the
+  //  decompress pipeline pays as well: 1 GiB 33 -> 23 ms, profiles/r06_host_path.txt; without the direct path it stays what rounds 3-5 measured: compress only)
+  else if (decompress && !direct) return 0;
+  else { if (n < ((size_t)192 << 20)) return 0; S = n / ((size_t)(direct ? 128 : 256) << 20); if (S < 4) S = 4; if (S > 8) S = 8; }   // four to eight slices
   if (S > K) S = K;
   return S >= 2 ? (int)S : 0;
+}
+int zn_set_host_direct(int mode) {
+  if (mode < 0 || mode > 7) return ZN_E_ARG;
+  zn_host_pipe_detail::direct_mode_ref().store(mode, std::memory_order_relaxed);
+  return ZN_OK;
 }
 int zn_set_host_slices(int slices) {
   if (slices < 0 || slices > 64) return ZN_E_ARG;
@@ -980,7 +994,7 @@ int zn_set_host_slices(int slices) {
 }
 
 static int zn_decompress_host_pipelined(const void* body, size_t body_len, int num_buf, int bits_mode, int bytes_mode, size_t chunk,
-                                        size_t orig_size, int dev, int S, void* dst) {
+                                        size_t orig_size, int dev, int S, bool direct, void* dst) {
   ZnBodyView v;
   int rc = zn_body_view(body, body_len, num_buf, chunk, orig_size, &v);
   if (rc) return rc;
@@ -1000,6 +1014,11 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
   }
   ZnGate up, dec;
   int rc_up = ZN_OK, rc_down = ZN_OK, rc_dec = ZN_OK;
+  // the caller's two buffers made DMA-able ahead of the transfers (zn_host_pipe.hpp: ZnHostMap): the payload for reading, the result — hinted to
+  // huge pages, touched, pinned, piece by piece on helper threads — for writing.  Declared ahead of the workers: unpinned after they are joined.
+  ZnHostMap src_map, dst_map;
+  if (direct) { src_map.start(const_cast<uint8_t*>(v.pay), v.pay_len, false, ~(size_t)0, dev); dst_map.start(dst, orig_size, true, ~(size_t)0, dev); }
+  else { src_map.gave_up = true; dst_map.gave_up = true; }
   try {
     ZnWorkers wk;
     ZnGateGuard guard(&up, &dec);
@@ -1017,11 +1036,11 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
             for (size_t j = 0; j < k; j++) { const uint64_t c = zn_rd64(v.cums + 8 * (p * K + r.lo + j)) - s0[p]; memcpy(meta.data() + P * k + 8 * (p * k + j), &c, 8); }
           }
           uint8_t* d = d_in + in_off[(size_t)i];
-          bool ok = zn_host_pipe_copy(pipe, d, meta.data(), meta.size(), true) == hipSuccess;
+          bool ok = zn_host_pipe_copy(pipe, d, meta.data(), meta.size(), true) == hipSuccess;      // (small: never pinned)
           size_t at = meta.size();
           for (size_t p = 0; ok && p < P; p++) {
             const size_t m = (size_t)(zn_cum_before(v, p, r.hi) - s0[p]);
-            if (m) ok = zn_host_pipe_copy(pipe, d + at, const_cast<uint8_t*>(v.pay + v.base[p] + s0[p]), m, true) == hipSuccess;
+            if (m) ok = zn_host_copy_mapped(src_map, pipe, d + at, const_cast<uint8_t*>(v.pay + v.base[p] + s0[p]), m, true) == hipSuccess;
             at += m;
           }
           if (!ok || dec.fail) { if (!ok) { (void)hipGetLastError(); rc_up = ZN_E_HIP; } up.abort(); return; }
@@ -1037,7 +1056,7 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
           if (!dec.wait_for((size_t)i + 1)) return;
           const ZnRange r = rg[(size_t)i];
           const size_t off = r.lo * chunk, len = (r.hi * chunk < orig_size ? r.hi * chunk : orig_size) - off;
-          if (len && zn_host_pipe_copy(pipe, d_out + off, (uint8_t*)dst + off, len, false) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
+          if (len && zn_host_copy_mapped(dst_map, pipe, d_out + off, (uint8_t*)dst + off, len, false) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
         }
       } catch (...) { rc_down = ZN_E_ALLOC; }
     });
@@ -1058,7 +1077,7 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
 }
 
 static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const void* src, size_t n, int num_buf, int bits_mode, int bytes_mode,
-                                      size_t chunk, float threshold, int dev, int S, void* dst, size_t dst_cap, size_t* dst_len) {
+                                      size_t chunk, float threshold, int dev, int S, bool direct, void* dst, size_t dst_cap, size_t* dst_len) {
   const size_t P = (size_t)num_buf, K = (n + chunk - 1) / chunk;
   if (hdr_len + 9 * P * K > dst_cap) return ZN_E_CAP;
   std::lock_guard<std::mutex> hk(g_host_mu[dev]);
@@ -1087,6 +1106,9 @@ static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const voi
   ZnGate up, queued; bool all_queued = false;
   int rc_up = ZN_OK, rc_down = ZN_OK, rc_enc = ZN_OK;
   std::vector<std::vector<uint8_t>> metas((size_t)S);
+  ZnHostMap src_map, dst_map;                       // (as in the decompress pipeline; the result is prepared as far as a weights-like tensor will need it, further on demand)
+  if (direct) { src_map.start(const_cast<void*>(src), n, false, ~(size_t)0, dev); dst_map.start(dst, dst_cap, true, hdr_len + 9 * P * K + n / 2 + n / 4, dev); }
+  else { src_map.gave_up = true; dst_map.gave_up = true; }
   try {
     ZnWorkers wk;
     ZnGateGuard guard(&up, &queued);
@@ -1095,7 +1117,7 @@ static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const voi
         if (hipSetDevice(dev) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
         for (int i = 0; i < S; i++) {
           const size_t off = rg[(size_t)i].lo * chunk, len = (rg[(size_t)i].hi * chunk < n ? rg[(size_t)i].hi * chunk : n) - off;
-          if (len && zn_host_pipe_copy(g_ws[dev].pipe, d_src + off, const_cast<uint8_t*>((const uint8_t*)src + off), len, true) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
+          if (len && zn_host_copy_mapped(src_map, g_ws[dev].pipe, d_src + off, const_cast<uint8_t*>((const uint8_t*)src + off), len, true) != hipSuccess) { (void)hipGetLastError(); rc_up = ZN_E_HIP; up.abort(); return; }
           if (queued.fail) { up.abort(); return; }
           up.publish((size_t)i + 1);
         }
@@ -1110,7 +1132,7 @@ static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const voi
           { std::unique_lock<std::mutex> lk(queued.m); queued.cv.wait(lk, [&] { return queued.done > next || queued.fail || all_queued; }); have = queued.done; fin = all_queued; if (queued.fail) return; }
           for (; next < have; next++) {
             const Job j = jobs[next];
-            if (j.len && zn_host_pipe_copy(g_ws[dev].pipe2, const_cast<uint8_t*>(j.d), j.h, j.len, false) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
+            if (j.len && zn_host_copy_mapped(dst_map, g_ws[dev].pipe2, const_cast<uint8_t*>(j.d), j.h, j.len, false) != hipSuccess) { (void)hipGetLastError(); rc_down = ZN_E_HIP; return; }
           }
           if (fin && next >= have) { std::lock_guard<std::mutex> lk(queued.m); if (queued.done == next) return; }
         }
