@@ -26,7 +26,7 @@ struct ZnHostPipe {
 };
 
 // ---- the DIRECT path (round 6): DMA straight between the caller's buffer and HBM ------------------------------
-// Measured on the MI355X boxes (scripts/ubench/hostreg.hip, profiles/r06_host_register.txt), 1 GiB: the DMA itself takes 18.8 ms either way
+// Measured on the MI355X boxes (scripts/ubench/hostreg.hip, profiles/r06_host_path.txt), 1 GiB: the DMA itself takes 18.8 ms either way
 // (57 GB/s); what a caller's pageable buffer costs on top depends on its PAGES.  4 KiB pages: first touch 36-90 ms (8 threads), hipHostRegister
 // 20-47 ms, free() 70-110 ms — the staged copy above (≈ 20 ms + the faults) is the better deal.  2 MiB pages (transparent huge pages; this kernel
 // runs THP in `madvise` mode): first touch 5.7 ms, register 2.7 ms, unregister ≈ 0.  So:
