@@ -27,6 +27,8 @@ Also on the JSON line:
                      restatement if that build is absent) timed on the host cores at T = min(nproc, 16) (the reference's
                      default) and at T = nproc, with nproc / CPU model / NUMA nodes / malloc environment on the line, and
                      the WHOLE GPU frame compared with the CPU frame of the same tensor (gpu_frame_equals_cpu_frame)
+  host_path          zn_compress / zn_decompress with HOST buffers (what the INTEGRATION stub binds), 1 GiB, PCIe inside the time: GB/s with fresh and with
+                     recycled result buffers, in the library's default mode and with zn_set_host_direct(7)
   plugin_gpt2        BASELINE.json configs[3] (N = 1): a real-size GPT-2 checkpoint (148 fp32 tensors, 498 MB, synthesised),
                      compressed once, then loaded onto cuda:0 through zipnn_safetensors() + safe_open and through
                      safetensors_io.load_file — seconds split into file read / H2D / decode — beside the reference's
@@ -138,9 +140,11 @@ def size_sweep(lib, codec, device, steps):
     """Decode GB/s by tensor size (bf16, device-resident, event-timed): small tensors are bound by the ~100 us a workgroup needs per chunk
     group and by the launch, not by HBM."""
     out = {}
-    for mib in (64, 128, 256, 576, 1024):     # (64: the 16-wave small-input kernel, 128: its 8-wave form, from 256 on the fused kernel; 576 MiB = 2 304 chunks lies BETWEEN two
-                                              #  rounds of workgroups: the size class the round-counting group rule of zn_decode_fused_group is for, DESIGN.md §3.1)
-        n = mib << 20
+    # (64: the 16-wave small-input kernel, 128: its 8-wave form, from 256 on the fused kernel; 576 MiB = 2 304 chunks lies BETWEEN two rounds of workgroups: the
+    #  size class the round-counting group rule of zn_decode_fused_group is for, DESIGN.md §3.1; "100MiB+250000" is a RAGGED tensor — 400 chunks and a partial one,
+    #  what every real tensor whose size is not a multiple of 256 KiB looks like — next to the same tensor without its tail)
+    for mib, extra in ((64, 0), (100, 0), (100, 250000), (128, 0), (256, 0), (576, 0), (1024, 0)):
+        n = (mib << 20) + extra
         x = make_tensor(n, device, 99 + mib)
         flat = codec.flat_bytes(x)
         body = codec.compress_device(lib, flat, P, ROT, BMODE, CHUNK, THR).clone()
@@ -150,12 +154,68 @@ def size_sweep(lib, codec, device, steps):
         d = stats(time_events(lambda: codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n, out=dst, check=False), steps))
         c = stats(time_events(lambda: codec.compress_device(lib, flat, P, ROT, BMODE, CHUNK, THR), max(2, steps // 2)))
         torch.cuda.synchronize()
-        out[f"{mib}MiB"] = {"decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "decompress_ms_median": round(d["median"], 4),
+        out[f"{mib}MiB" + (f"+{extra}" if extra else "")] = {"decompress_GBps": round(n / d["avg"] / 1e6, 1), "decompress_ms": round(d["avg"], 4), "decompress_ms_median": round(d["median"], 4),
                             "compress_GBps": round(n / c["avg"] / 1e6, 1), "compress_ms": round(c["avg"], 4), "compress_ms_median": round(c["median"], 4),
                             "compress_ms_max": round(c["max"], 4), "exact": bool(torch.equal(dst, flat))}
         del x, flat, body, dst
     torch.cuda.empty_cache()
     return out
+
+
+def host_path(lib, device, n_bytes=1 << 30):
+    """The host-buffer entry points — zn_compress / zn_decompress through raw ctypes: what the INTEGRATION stub (tests/ref_binding/zipnn_core.py) and
+    ZipNN().compress(bytes) call; reference zipnn/zipnn.py:714-725, 1143-1151 — on 1 GiB of bf16, PCIe both ways inside the time: GB/s = uncompressed
+    bytes / wall seconds, best of 3.  `fresh` = the result buffer is allocated (np.empty) inside the timed region, what a caller that does not recycle
+    buffers pays; `warm` = result buffers recycled.  Two modes of the library: the default (staged through its own pinned buffers, result buffers hinted to
+    huge pages) and zn_set_host_direct(7) (the caller's buffers pinned, DMA straight between them and HBM — for callers that recycle buffers:
+    profiles/r06_host_path.txt says why it is opt-in).  Never part of `value`."""
+    import ctypes
+    import numpy as np
+    L = lib._L
+    try:
+        n = n_bytes // CHUNK * CHUNK
+        x = make_tensor(n, device, 31337).view(torch.uint8).cpu().numpy()
+        hdr = np.zeros(32, dtype=np.uint8)
+        cap = L.zn_compress_bound(n, P, CHUNK, 32)
+        sz = ctypes.c_size_t(0)
+        dev = device.index or 0
+
+        def comp(o):
+            rc = L.zn_compress(hdr.ctypes.data, 32, x.ctypes.data, n, P, ROT, BMODE, CHUNK, ctypes.c_float(THR), dev, o.ctypes.data, cap, ctypes.byref(sz))
+            assert rc == 0, rc
+            return sz.value
+
+        def dec(fr, flen, o):
+            rc = L.zn_decompress(fr.ctypes.data + 32, flen - 32, P, ROT, BMODE, CHUNK, n, dev, o.ctypes.data)
+            assert rc == 0, rc
+        frame = np.empty(cap, dtype=np.uint8); flen = comp(frame)
+        back = np.empty(n, dtype=np.uint8); dec(frame, flen, back)
+        out = {"GiB": n / (1 << 30), "exact": bool(np.array_equal(back, x)), "unit": "GB/s, uncompressed bytes / wall seconds, PCIe inside; best of 3"}
+        for mode, tag in ((4, "default"), (7, "direct")):
+            lib.set_host_direct(mode)
+            r = {}
+            for name in ("compress", "decompress"):
+                warm = fresh = 1e9
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    comp(frame) if name == "compress" else dec(frame, flen, back)
+                    warm = min(warm, time.perf_counter() - t0)
+                    t0 = time.perf_counter()
+                    o = np.empty(cap if name == "compress" else n, dtype=np.uint8)
+                    comp(o) if name == "compress" else dec(frame, flen, o)
+                    fresh = min(fresh, time.perf_counter() - t0)
+                    del o
+                r[name] = {"warm_GBps": round(n / warm / 1e9, 1), "warm_ms": round(warm * 1e3, 1), "fresh_GBps": round(n / fresh / 1e9, 1), "fresh_ms": round(fresh * 1e3, 1)}
+            out[tag] = r
+        lib.set_host_direct(4)
+        out["exact"] = out["exact"] and bool(np.array_equal(back, x))
+        return out
+    except Exception as e:                                 # (never let the optional leg take the bench line down)
+        try:
+            lib.set_host_direct(4)
+        except Exception:
+            pass
+        return {"error": repr(e)[:300]}
 
 
 def multi_dev_inprocess(lib, codec, n_bytes=1 << 30):
@@ -496,6 +556,59 @@ def llama8b_shapes(layers=32, hidden=4096, inter=14336, vocab=128256, kv_heads=8
     return t
 
 
+def llama8b_partition(world, layers=32):
+    """What every rank of a `world`-rank llama8b run gets, computed on paper (no device): chunks and bytes per rank, max / min — the load balance of
+    zipnn_amd.sharding.chunk_ranges over the 291 + 224 tensors (known before the first 8-GPU run, and on its line)."""
+    from zipnn_amd import sharding
+    f8 = getattr(torch, "float8_e4m3fn", None)
+    chunks, nbytes_r = [0] * world, [0] * world
+    for name, shape, linear in llama8b_shapes(layers=layers):
+        numel = 1
+        for d in shape:
+            numel *= d
+        for es, chunk in [(2, CHUNK)] + ([(1, CHUNK // 2)] if (linear and f8 is not None) else []):
+            nb = numel * es
+            K = (nb + chunk - 1) // chunk
+            for r, (lo, hi) in enumerate(sharding.chunk_ranges(K, world)):
+                if hi > lo:
+                    chunks[r] += hi - lo
+                    nbytes_r[r] += min(hi * chunk, nb) - lo * chunk
+    return {"ranks": world, "chunks_per_rank_min": min(chunks), "chunks_per_rank_max": max(chunks), "bytes_per_rank_min": min(nbytes_r), "bytes_per_rank_max": max(nbytes_r),
+            "imbalance": round(max(nbytes_r) / max(1, sum(nbytes_r) / world), 5)}
+
+
+def pin_rank_to_its_gpus_numa_node(dev_index):
+    """N > 1: this rank's host threads onto the CPUs of the NUMA node its GPU hangs off (/sys/bus/pci/devices/<bdf>/local_cpulist) — the pinned staging buffers,
+    the launch thread and the RCCL proxy then sit next to the device instead of wherever the launcher left them.  Best effort: returns what it did, never raises."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        dom, bus, dv = getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", None), getattr(pr, "pci_device_id", 0)
+        if bus is None:
+            return {"pinned": False, "why": "no pci_bus_id on this torch"}
+        bdf = f"{dom:04x}:{bus:02x}:{dv:02x}.0"
+        base = f"/sys/bus/pci/devices/{bdf}"
+        with open(base + "/local_cpulist") as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-"); cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        node = None
+        try:
+            node = int(open(base + "/numa_node").read().strip())
+        except (OSError, ValueError):
+            pass
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            return {"pinned": False, "pci": bdf, "numa_node": node, "why": "no local CPU in this process's affinity mask"}
+        os.sched_setaffinity(0, allowed)
+        return {"pinned": True, "pci": bdf, "numa_node": node, "cpus": len(allowed)}
+    except Exception as e:       # noqa: BLE001
+        return {"pinned": False, "why": repr(e)[:120]}
+
+
 def run_llama8b(args, lib, codec, device, world, rank, dist, td, sample_oracle=False):
     from zipnn_amd import sharding
     shapes = llama8b_shapes(layers=args.layers)
@@ -579,6 +692,7 @@ def run_llama8b(args, lib, codec, device, world, rank, dist, td, sample_oracle=F
                 "compress_GBps": round(total_bytes * csteps / c_elapsed / 1e9, 2), "compress_ms_per_step": round(c_elapsed / csteps * 1e3, 3),
                 "ratio": round(c_bytes / total_bytes, 5), "bit_exact_roundtrip": exact,
                 "rank0_decode_ms": {k: round(v, 4) for k, v in d.items()}, "rank_ms_per_step": rank_ms,
+                "partition": llama8b_partition(world, args.layers), "partition_at_8_ranks": llama8b_partition(8, args.layers),
                 "kernels": {"decompress": decode_kernels, "compress": encode_kernels}}
         if c_payload is not None:                     # (N + C) / t on rank 0's event-timed launches, as a fraction of 8 TB/s
             line["decompress_roofline_frac"] = round((total_bytes + c_payload) / (d["avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
@@ -638,6 +752,7 @@ def main():
     dev_index = local_rank % max(1, torch.cuda.device_count()) if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    affinity = pin_rank_to_its_gpus_numa_node(dev_index) if (world > 1 and not share) else None      # (N = 1: the launcher's mask stays — the CPU baseline wants every core)
     td = None
     if dist:
         import torch.distributed as td
@@ -761,6 +876,7 @@ def main():
             line["dry_run_shared_gpu"] = True
         line["device_under_load"] = device_state_under_load(lambda: [codec.decompress_device(lib, body, P, ROT, BMODE, CHUNK, n_bytes, out=out, check=False) for _ in range(120)])
         line["rccl_ranks"] = rccl_ranks
+        line["rank0_cpu_affinity"] = affinity
         line["rank_ms_per_step"] = rank_ms          # every rank's own wall time per step (a straggler shows as max >> min); null without torch.distributed
     # ---- BASELINE.json configs[4] on the same line, at every N (every rank takes part; strong scaling) ----
     del x, flat, body_buf, out
@@ -779,6 +895,8 @@ def main():
             line["sizes"] = size_sweep(lib, codec, device, max(4, min(args.steps, 20)))
         if world == 1 and not args.no_plugin:
             line["plugin_gpt2"] = plugin_gpt2(lib, device)
+        if world == 1 and not args.no_plugin:
+            line["host_path"] = host_path(lib, device)
         if world == 1:
             line["multi_dev_inprocess"] = multi_dev_inprocess(lib, codec)
         if world == 1 and not args.no_cpu_baseline:

@@ -26,95 +26,19 @@ PKG = os.path.join(ROOT, "zipnn_amd")
 
 # name -> (commit or None, [flags])
 VARIANTS = {
-    "r01": ("fb215d2", []),                         # the kernels of the round-1 final state
+    "new": (None, []),                              # the sources in the tree
     "c1": ("HEAD", []),                             # the last commit
-    "new": (None, []),
-    "late": (None, ["-DZN_F_EARLY_STAGE=0"]),
-    "prio0": (None, ["-DZN_F_PRIO_SYNC=0", "-DZN_F_PRIO_COUNT=0", "-DZN_F_PRIO_WRITE=0"]),
-    "plainld": (None, ["-DZN_F_NT_LOADS=0"]),
-    "p2m0": (None, ["-DZN_F_P2_MASK=0"]),
-    "nosplit": (None, ["-DZN_F_FETCH_SPLIT=0"]),
-    "rb8": (None, ["-DZN_F_RB2=8"]),
-    "rb2": (None, ["-DZN_F_RB2=2"]),
-    "rb3": (None, ["-DZN_F_RB2=3"]),
-    "dcap4": (None, ["-DZN_F_DCAP=4"]),
-    "dcap3": (None, ["-DZN_F_DCAP=3", "-DZN_F_DCONST2=3"]),
-    "dcap5": (None, ["-DZN_F_DCAP=5", "-DZN_F_DCONST2=5"]),
-    "e_abl1": ("3c0f9d7", ["-DZN_E_ABL=1"]),
-    "e_abl2": ("3c0f9d7", ["-DZN_E_ABL=2"]),
-    "e_abl2na": ("3c0f9d7", ["-DZN_E_ABL=2", "-DZN_E_STATS_AHEAD=0"]),
-    "e_noahead": (None, ["-DZN_E_STATS_AHEAD=0"]),
-    "e_fwd": (None, ["-DZN_E_EMIT_REVERSE=0"]),
-    "e_old": (None, ["-DZN_E_STATS_AHEAD=0", "-DZN_E_EMIT_REVERSE=0"]),
-    "rb5": (None, ["-DZN_F_RB2=5"]),
-    "nod6": (None, ["-DZN_F_DCONST2=0"]),
-    "rb6": (None, ["-DZN_F_RB2=6"]),
-    "nopass2": ("3c0f9d7", ["-DZN_F_ABL=1"]),
-    "noraw": ("3c0f9d7", ["-DZN_F_ABL=2"]),
-    "nostore": ("3c0f9d7", ["-DZN_F_ABL=4"]),
-    "nomem": ("3c0f9d7", ["-DZN_F_ABL=6"]),
-    "nofix": ("3c0f9d7", ["-DZN_F_ABL=8"]),
-    "nolut": ("3c0f9d7", ["-DZN_F_ABL=16"]),
-    "nop2mem": ("3c0f9d7", ["-DZN_F_ABL=7"]),
-    "noall": ("3c0f9d7", ["-DZN_F_ABL=31"]),
-    "nofence": (None, ["-DZN_F_NO_SCHED_FENCE"]),
-    "w3": (None, ["-DZN_F_WAVES_PER_SIMD=3"]),      # 3 waves per SIMD: 168 VGPRs
-    "w2": (None, ["-DZN_F_WAVES_PER_SIMD=2"]),
-    "tf15": (None, ["-DZN_F_TF(D)=((D)*4-1)"]),     # record slots for whole-group steps (default 4 D + 1)
-    "tf19": (None, ["-DZN_F_TF(D)=((D)*4+3)"]),
-    "d16": (None, ["-DZN_F_DELTA0=16"]),
-    "d21": (None, ["-DZN_F_DELTA0=21"]),
-    "d32": (None, ["-DZN_F_DELTA0=32"]),
-    "p2m1": (None, ["-DZN_F_P2_MASK=1"]),
-    "p2m2": (None, ["-DZN_F_P2_MASK=2"]),
-    # round 3
-    "r02": ("8959d1d", []),                         # the kernels of the round-2 final state
-    "d33": (None, ["-DZN_F_DELTA0=33"]),
-    "nmis1": (None, ["-DZN_F_NMIS=1"]),
-    "d44": (None, ["-DZN_F_DELTA0=44"]),
+    # the kernels of earlier rounds (their -D switches are gone from the tree: round 6 made the settled ones constants; a variant of an old switch is built from
+    # the commit that still had it, e.g. ("741f196", ["-DZN_F_RB2=4"]))
+    "r01": ("fb215d2", []), "r02": ("8959d1d", []), "r03": ("3c0f9d7", []), "r04a": ("5b359c5", []), "r05": ("741f196", []),
     # compiler scheduling options (same sources)
     "ilp": (None, ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     "iter": (None, ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
     "maxocc": (None, ["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
     "nopost": (None, ["-mllvm", "-enable-post-misched=0"]),
-    "bias100": (None, ["-mllvm", "-amdgpu-schedule-metric-bias=100"]),
-    "bias0": (None, ["-mllvm", "-amdgpu-schedule-metric-bias=0"]),
     "o2": (None, ["-O2"]),
-    "d44c": (None, ["-DZN_F_DELTA0=44", "-DZN_F_DELTA_MAX=44"]),
-    "dmax88": (None, ["-DZN_F_DELTA_MAX=88"]),
-    "pp3": (None, ["-DZN_F_PRIO_PARSE=3"]),
-    "pp2": (None, ["-DZN_F_PRIO_PARSE=2"]),
-    "pf3": (None, ["-DZN_F_PRIO_FILL=3"]),
-    "pp3f3": (None, ["-DZN_F_PRIO_PARSE=3", "-DZN_F_PRIO_FILL=3"]),
-    "pp3f1": (None, ["-DZN_F_PRIO_PARSE=3", "-DZN_F_PRIO_FILL=1"]),
-    "ps2": (None, ["-DZN_F_PRIO_SYNC=2"]),
-    "ps3": (None, ["-DZN_F_PRIO_SYNC=3"]),
-    "ps0": (None, ["-DZN_F_PRIO_SYNC=0"]),
-    "rb4_3": (None, ["-DZN_F_RB4=3"]),
-    "rb4_4": (None, ["-DZN_F_RB4=4"]),
-    "rb4_1": (None, ["-DZN_F_RB4=1"]),
-    "dd44": (None, ["-DZN_F_DELTA0_DENSE=44"]),
-    "dd66": (None, ["-DZN_F_DELTA0_DENSE=66"]),
-    "dd132": (None, ["-DZN_F_DELTA0_DENSE=132"]),
-    "dd192": (None, ["-DZN_F_DELTA0_DENSE=192"]),
-    "dmax66": (None, ["-DZN_F_DELTA_MAX=66"]),
-    "d88": (None, ["-DZN_F_DELTA0=88"]),
-    "tf23": (None, ["-DZN_F_TF(D)=((D)==6?23:(D)*4+1)"]),
-    "tf21": (None, ["-DZN_F_TF(D)=((D)==6?21:(D)*4+1)"]),
-    "d33c": (None, ["-DZN_F_DELTA0=33", "-DZN_F_DELTA_MAX=44"]),
-    "d22c": (None, ["-DZN_F_DELTA_MAX=44"]),
-    "nmis2": (None, ["-DZN_F_NMIS=2"]),
-    # round 4: wave specialisation (four decode waves + mover waves per workgroup) — the code lives in commit b49b217 only (profiles/r04_decode_experiments.txt)
-    "r03": ("3c0f9d7", []),                         # the kernels of the round-3 final state
-    "nopipe": (None, ["-DZN_F_PIPE=0"]),
-    "p12cond": (None, ["-DZN_F_P12_UNCOND=0"]),     # zn_pass12 with masked atomics (the compiler then waits lgkmcnt(0) at every look-up)            # the tiles' passes one after the other (no zn_pass12)
-    "spec8": ("b49b217", []),                       # 8-wave workgroups (4 decode + 4 movers), 80 VGPRs
-    "spec8w5": ("b49b217", ["-DZN_F_SPEC_WAVES=5"]),   # … 96 VGPRs: two workgroups per CU
-    "spec8free": ("b49b217", ["-DZN_F_ABL=96"]),    # … timing only: neither side of the hand-over waits
-    "spec8pers": ("b49b217", ["-DZN_F_PERSIST=1"]), # … persistent workgroups
-    # (an unrolled run-in for up to 88 / 110 / 132 bits — the dense instance's 88 bits go through the looping form — was built and measured
-    #  in round 4: no effect on any dtype, profiles/r04_decode_experiments.txt; not in the sources)
-    "r04a": ("5b359c5", []),
+    # round 6: profiles/r06_glds_stream_tile.patch (the next stream tile by LDS-DMA) is applied to a scratch copy of the tree by hand; the two libraries it was
+    # measured with were "new" with and without it
 }
 
 
@@ -152,7 +76,7 @@ def load(path):
     return L
 
 
-ALLD = ("r04a", "r01", "r02", "r03", "pipe", "pipecond", "pipeoff", "spec8", "spec8w5", "spec8free", "spec8pers", "c1", "prev", "new", "d33", "d44", "d44c", "d33c", "d22c", "nmis1", "nmis2", "dcap5", "dcap3", "fp8reg", "ilp", "iter", "maxocc", "nopost", "bias100", "bias0", "o2", "dmax88", "dmax66", "d88", "tf23", "tf21", "dd44", "dd66", "dd132", "dd192", "rb4_3", "rb4_4", "rb4_1", "ps2", "ps3", "ps0", "pp3", "pp2", "pf3", "pp3f3", "pp3f1")
+ALLD = None
 
 
 def run(names):
@@ -170,7 +94,7 @@ def run(names):
     st = torch.cuda.current_stream().cuda_stream
     results = {}
     for name, n, P, rot, bm, dt, only in cases:
-        use = [(k, L) for k, L in libs if only is None or k in only]
+        use = list(libs)
         if not use:
             continue
         es = torch.empty(0, dtype=dt).element_size()

@@ -129,22 +129,13 @@ __device__ __forceinline__ uint32_t zn_plane_len(uint32_t chunk_len, uint32_t P,
   return chunk_len / P + (p < chunk_len % P ? 1u : 0u);
 }
 
-// Developer-only switches.  ZN_F_ONLY_HOT compiles one instance, ZN_PHASE_TIMERS(_SUB) adds shader-clock timers, ZN_F_P2_MASK=0 issues
-// LDS atomics below the staging buffer.  None of them may reach a product build: zipnn_amd/build.py never defines ZN_DEV_BUILD, and
-// without it any of these is an error (scripts/ab_variants.py and scripts/phase_profile.py define it for their throw-away libraries).
-// (Round 5's two timing probes of the one-pass encoder — a made-up look-back offset, only the last plane counted — left the sources with their numbers in
-//  profiles/r05_encoder_onepass.txt; ZN_F_NO_REST — the plain decode instance for every call, same bytes — stays as the A/B tool of profiles/r05_rest_instance_ab.txt.)
-// (The phase-ablation switches of rounds 1-3 — ZN_F_ABL / ZN_E_ABL: a phase dropped to price it on the device, wrong output — are not in
-//  the sources any more; their numbers are in profiles/r0[123]_decode_experiments.txt, scripts/ab_variants.py builds them from commit 3c0f9d7.)
+// The one developer-only switch left: ZN_PHASE_TIMERS(_SUB) adds shader-clock timers to the kernels (scripts/phase_profile.py).  It may not reach a product
+// build: zipnn_amd/build.py never defines ZN_DEV_BUILD, and without it the macro is an error.  Round 6 removed the A/B switches of rounds 1-5 whose experiments are
+// settled (about forty `#ifndef ZN_F_* / ZN_E_* / ZN_OP_*` defaults: they are plain constants now, the losing branches are gone; what each one measured is in
+// profiles/r0[1-5]_*.txt and profiles/DESIGN_history_r1_r4.md, and scripts/ab_variants.py rebuilds any of them from the commit that still had it).
 #if !defined(ZN_DEV_BUILD) && !defined(ZN_SIMT_EMULATOR)
-#if defined(ZN_F_ABL) || defined(ZN_E_ABL)
-#error "ZN_F_ABL / ZN_E_ABL: the ablation code left the sources after round 3 (build commit 3c0f9d7 for it)"
-#endif
-#if defined(ZN_F_ONLY_HOT) || defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB) || defined(ZN_F_NO_REST)
-#error "developer-only macro (ZN_F_ONLY_HOT / ZN_PHASE_TIMERS) without ZN_DEV_BUILD: not a product configuration"
-#endif
-#if defined(ZN_F_P2_MASK) && (ZN_F_P2_MASK == 0)
-#error "ZN_F_P2_MASK=0 without ZN_DEV_BUILD: not a product configuration"
+#if defined(ZN_PHASE_TIMERS) || defined(ZN_PHASE_TIMERS_SUB)
+#error "developer-only macro (ZN_PHASE_TIMERS) without ZN_DEV_BUILD: not a product configuration"
 #endif
 #endif
 

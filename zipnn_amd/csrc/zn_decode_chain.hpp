@@ -7,7 +7,7 @@
 
 #include "zn_common.hpp"
 
-#ifndef ZN_F_TLMAX
+#ifndef ZN_F_TLMAX        /* (the including file may have said it already) */
 #define ZN_F_TLMAX 11u
 #endif
 #ifndef ZN_IN_IDX
@@ -16,7 +16,7 @@
 // a scheduling fence between the unrolled steps of the register-resident decode: a step is one dependent chain, nothing
 // is gained by interleaving two of them, and left alone the scheduler postpones the packing of the count bytes, which
 // keeps every step's meta word alive (one more register per step)
-#if !defined(ZN_SIMT_EMULATOR) && !defined(ZN_F_NO_SCHED_FENCE)
+#if !defined(ZN_SIMT_EMULATOR)
 #define ZN_STEP_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
 #define ZN_STEP_FENCE() do { } while (0)
@@ -279,22 +279,16 @@ __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& 
   auto put = [&](uint32_t cnt, uint32_t sv) {
     const uint32_t g = ~wm1;                               // low two bits = (-wpos) & 3
     uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & AMASK));
-#ifndef ZN_F_P2_MASK
-#define ZN_F_P2_MASK 2        // 1: lanes with nothing to add stay out of the atomics (exec mask) — 2: per dword.  (0, every lane every dword, is a
-                              // developer measurement only, refused outside ZN_DEV_BUILD: with wpos == 0 the pair starts one dword BELOW the staging
-                              // buffer — the neighbouring wave's last dword, or the LUT's — and only the masks keep that zero-valued atomic from being issued)
-#endif
+    // (per DWORD: a lane stays out of an atomic whose operand is zero — with wpos == 0 the pair starts one dword BELOW the staging buffer, the neighbouring
+    //  wave's last dword or the LUT's, and only this test keeps that zero-valued atomic from being issued; masks per lane or none at all measured slower /
+    //  are wrong: profiles/r02_decode_experiments.txt)
     const uint32_t lo = zn_alignbyte(sv, 0u, g), hi = zn_alignbyte(0u, sv, g);
-    if (ZN_F_P2_MASK == 0) { atomicOr(d, lo); atomicOr(d + 1, hi); }
-    else if (ZN_F_P2_MASK == 1) { if (cnt) { atomicOr(d, lo); atomicOr(d + 1, hi); } }
-    else { if (lo) atomicOr(d, lo); if (hi) atomicOr(d + 1, hi); }
+    if (lo) atomicOr(d, lo);
+    if (hi) atomicOr(d + 1, hi);
     wm1 += cnt;
     ZN_STEP_FENCE();
   };
-#ifndef ZN_F_P2_PAIRS
-#define ZN_F_P2_PAIRS 1       // dense records: the two steps of a register leave together
-#endif
-  if constexpr (DENSE && ZN_F_P2_PAIRS) {
+  if constexpr (DENSE) {      // dense records: the two steps of a register leave together
     // The two steps that share a record register (≤ 2 + 2 bytes) are written as ONE group: the second step's bytes are moved down
     // next to the first's (one v_perm_b32, selector by the first step's count), one pair of dwords instead of two — half the
     // ds_or_b32 of a dense stream's compaction, whose LDS time they are.  A slot that did not run in this pass (beyond nfull /

@@ -51,79 +51,43 @@
 #include "zn_decode_rest.hpp"
 
 #define ZN_F_THREADS 256
-#ifndef ZN_F_RING_BYTES
 #define ZN_F_RING_BYTES 4096u            // per wave; multiple of every row size (512 / 1024 symbols)
-#endif
-#ifndef ZN_F_WAVES_PER_SIMD
 #define ZN_F_WAVES_PER_SIMD 4            // workgroups per CU the LDS budget allows (drives the VGPR budget)
-#endif
 #define ZN_F_RING_DW (ZN_F_RING_BYTES / 4u)
-#ifndef ZN_F_DMAX
 #define ZN_F_DMAX 6                      // largest sub-block (dwords); sizes the stream-tile buffer and its prefetch registers (LDS: 40.8 KB, still 4 workgroups/CU; dense codes — fp8, fp16 — want long sub-blocks: +22 % on fp8)
-#endif
 // Dense codes (fp16's top byte, fp8: 5-6 bits a symbol) would get sub-blocks of 6 dwords from the density rule, which only
 // the looping form decodes.  Capped at the compile-time size they run the register-resident form: fp16 +14 %.  The
 // exception is a code that does not re-synchronise — most of its code space at ONE length (fp8 e4m3 weights: 72 % of the
 // symbols are 5 bits long, a mis-aligned decoder stays mis-aligned for a median of 35 bits, 12 % beyond 128): nearly every
 // tile then needs fix-up passes whatever the run-in, and the looping form with long sub-blocks is the faster one (−13 %
 // with the cap).  `dom` = the share of the code space held by the most populated code length (ZnWaveStats).
-#ifndef ZN_F_DCAP
 #define ZN_F_DCAP 4
-#endif
-#ifndef ZN_F_DOM_MAX
 #define ZN_F_DOM_MAX 154                 // (0.6 · 256)
-#endif
-#ifndef ZN_F_DCONST
 #define ZN_F_DCONST 4                    // the sub-block size that gets a compile-time instance
-#endif
 // The second compile-time size: the DENSE-code instance (fp8, fp16's top byte: 5-6 bits a symbol want 6-dword sub-blocks).  Round 2
 // had it off — 25 + 3 record slots spilled in every instance.  Round 3: a code whose shortest length is ≥ 4 bits puts at most two
 // symbols into an 11-bit window, so two steps share a record register (zn_rec_put<I, DENSE>): 14 + 7 registers for 28 steps, fewer
 // than the 4-dword instance's 20 + 5, and the tiles of such streams take the register-resident form (no second decode for the
 // write pass).  Instantiated for one- and two-plane tensors; 0 = off.
-#ifndef ZN_F_DCONST2
 #define ZN_F_DCONST2 6
-#endif
-#ifndef ZN_F_DENSE_LMIN
 #define ZN_F_DENSE_LMIN 4                // shortest code length (bits) from which a stream counts as dense
-#endif
 // dwords 0 (look-ahead below the tile) .. 64 D (its top) of a stream tile, + spare
 #define ZN_F_IN_DW (64 * ZN_F_DMAX + 4)
-#ifndef ZN_F_TF
 #define ZN_F_TF(D) ((D) * 4 + 1)         // whole-group step slots of the register-resident decode for a sub-block of D dwords
-#endif
 #define ZN_F_TLMAX 11u
 // the 16-bit single-symbol table (scratch of the LUT build, aliased into the idle staging buffers 0 and 1): one
 // dword of padding per 32 — the build reads it at (u << pos) & mask, power-of-two strides across the lanes that
 // would otherwise pile 16 or 32 lanes onto one bank
-#ifndef ZN_F_L16_PAD
-#define ZN_F_L16_PAD 1
-#endif
-#if ZN_F_L16_PAD
 #define ZN_L16(i) ((i) + (((i) >> 6) << 1))
-#else
-#define ZN_L16(i) (i)
-#endif
 // wave priority (s_setprio) by phase: it rises with the progress through a tile — sync run-in 1, count pass 2, write
 // pass 3, everything else (flush, staging, table build) 0.  The passes are chains of dependent LDS look-ups: their next
 // instruction issues ahead of the other waves' flush / table-build code, and a wave that is further along goes first.
 // Measured: all three passes at 3: +1.6 % over no priorities; graded like this: another +1 % (bf16; fp16 +3 %).
-#ifndef ZN_F_PRIO_SYNC
 #define ZN_F_PRIO_SYNC 1
-#endif
-#ifndef ZN_F_PRIO_COUNT
 #define ZN_F_PRIO_COUNT 2
-#endif
-#ifndef ZN_F_PRIO_WRITE
 #define ZN_F_PRIO_WRITE 3
-#endif
-#ifndef ZN_F_PRIO_PARSE          // the tree descriptions at the head of a workgroup (every wave parses one; the workgroup waits for the slowest)
-#define ZN_F_PRIO_PARSE 0
-#endif
-#ifndef ZN_F_PRIO_FILL           // the LUT fill of a chunk
-#define ZN_F_PRIO_FILL 0
-#endif
-#if (ZN_F_PRIO_SYNC || ZN_F_PRIO_COUNT || ZN_F_PRIO_WRITE) && !defined(ZN_SIMT_EMULATOR)
+// (the tree-description parse and the LUT fill run at priority 0: raising them measured nothing, profiles/r03_decode_experiments.txt)
+#if !defined(ZN_SIMT_EMULATOR)
 #define ZN_PRIO(v) __builtin_amdgcn_s_setprio(v)
 #else
 #define ZN_PRIO(v) do { } while (0)
@@ -146,26 +110,14 @@ __device__ __forceinline__ uint32_t zn_bfi_(uint32_t mask, uint32_t a, uint32_t 
 #define ZN_KEEP32(x) ((void)(x))
 #define ZN_BFI(mask, a, b) ((((uint32_t)(a)) & (uint32_t)(mask)) | (((uint32_t)(b)) & ~(uint32_t)(mask)))
 #endif
-#ifndef ZN_F_EARLY_STAGE
-#define ZN_F_EARLY_STAGE 1               // stage the next stream tile inside the flush, ahead of its stores (0: at the top of the tile loop)
-#endif
-#ifndef ZN_F_DELTA0
+// (the next stream tile is staged inside the flush, ahead of its stores — at the top of the tile loop the wait for its registers was a wait for those stores: 19 % of a wave's time)
 #define ZN_F_DELTA0 44                   // initial sync run-in (bits): 22 / 33 / 44 = two / three / four whole groups ahead of the boundary step.  Measured
                                          // (profiles/r03_decode_experiments.txt): 44 from the start is neutral on bf16 / fp32 (fewer fix-ups pay for the two
                                          // extra look-ups) and 2 % faster on the dense codes (fp16, fp8), whose streams end up there anyway
-#endif
-#ifndef ZN_F_DELTA0_DENSE
 #define ZN_F_DELTA0_DENSE 88             // … of the dense-code instance (fp8 +2 %, fp16 +1.3 % over 44; bf16 would lose 4 % to it)
-#endif
-#ifndef ZN_F_DELTA_FAST
 #define ZN_F_DELTA_FAST 44               // longest run-in the unrolled sync handles (beyond it: the looping form)
-#endif
-#ifndef ZN_F_DELTA_MAX
 #define ZN_F_DELTA_MAX 1024              // the run-in never grows beyond this (and never beyond a sub-block)
-#endif
-#ifndef ZN_F_NMIS
 #define ZN_F_NMIS 3                      // tiles of a stream that needed a fix-up before its run-in is lengthened
-#endif
 
 // path counters of the emulated build (tests/simt): which form decoded how many tiles — [0] tiles, [1] looping form,
 // [2] fix-up iterations, [3] tiles written in several lane groups.  The device build has none of this.
@@ -202,10 +154,7 @@ template <typename T> __device__ __forceinline__ T* zn_uniform_ptr(T* p) { retur
 typedef uint64_t __attribute__((aligned(1))) zn_u64u;
 typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 // the payload is read once: streaming (non-temporal) loads for the raw planes and the stream tiles
-#ifndef ZN_F_NT_LOADS
-#define ZN_F_NT_LOADS 1
-#endif
-#if ZN_F_NT_LOADS && !defined(ZN_SIMT_EMULATOR)
+#if !defined(ZN_SIMT_EMULATOR)
 #define ZN_LD_RAW32(p) __builtin_nontemporal_load((const zn_u32u*)(p))
 #define ZN_LD_RAW64(p) __builtin_nontemporal_load((const zn_u64u*)(p))
 #define ZN_LD_STREAM32(p) __builtin_nontemporal_load((const uint32_t*)(p))
@@ -214,8 +163,8 @@ typedef uint32_t __attribute__((aligned(1))) zn_u32u;
 #define ZN_LD_RAW64(p) (*(const zn_u64u*)(p))
 #define ZN_LD_STREAM32(p) (*(const uint32_t*)(p))
 #endif
-// the four-plane rows' stores (ZN_F_SPLIT4): non-temporal unless ZN_F_SPLIT4_PLAIN
-#if defined(ZN_F_SPLIT4_PLAIN) || defined(ZN_SIMT_EMULATOR)
+// the four-plane rows' stores: non-temporal (each store instruction writes whole 32-byte sectors: ZN_F_SPLIT4)
+#if defined(ZN_SIMT_EMULATOR)
 #define ZN_ST128_4(p, a, b, c, d) (*(uint4*)(p) = make_uint4((a), (b), (c), (d)))
 #else
 #define ZN_ST128_4(p, a, b, c, d) ZN_ST128(p, a, b, c, d)
@@ -306,24 +255,18 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   constexpr uint32_t UNIT = 64u * EPL;        // symbols per flushed row (lane row = EPL*P output bytes)
   // rows kept in registers at once (fetched before the write pass, emitted after it).  A 4-plane row holds three
   // raw planes in registers: two rows at a time, or the kernel spills (ZN_F_RB4).
-#ifndef ZN_F_RB4
 #define ZN_F_RB4 2
-#endif
   // Four planes: a lane's 8 symbols of a row are 32 output bytes = two 16-byte stores; as ONE run of 8 symbols each store instruction writes 16 bytes at a stride
   // of 32 (half of every 32-byte sector).  ZN_F_SPLIT4: the lane owns two runs of 4 symbols, [4 lane, +4) and [256 + 4 lane, +4) of the row's 512, so that each
   // store instruction writes 1 KB contiguous (whole sectors, whole lines) and can be non-temporal.
-#ifndef ZN_F_SPLIT4
 #define ZN_F_SPLIT4 1
-#endif
   constexpr bool SPLIT = (P == 4) && (ZN_F_SPLIT4 != 0);
   // (two planes: 4 rows per batch, a tile's ~6 rows in two batches.  8 rows — one batch — keeps 16 more registers in flight
   //  through the compaction; every build of that variant spilled somewhere in the tile loop and ran between 1.61 and 2.2 ms
   //  on the 4 GiB config depending on where, 4 rows ran 1.60 ms three builds in a row; with the tile loop spill-free 3 rows
   //  — two even batches for the ~6 rows of a tile — run 1.545 against 1.568 (4), 1.588 (2), 1.581 (5), 1.82 (8):
   //  profiles/r02_decode_experiments.txt)
-#ifndef ZN_F_RB2
 #define ZN_F_RB2 3
-#endif
   constexpr int RB = (P == 2) ? (int)ZN_F_RB2 : (P == 4) ? ZN_F_RB4 : (int)(ZN_F_RING_BYTES / 1024u);
   // register-resident decode (zn_pass1 / zn_pass2): slots for whole-group steps / boundary steps, unchecked head.
   // A sub-block of D dwords needs about 32 D / 9.6 steps (a step consumes 9-10 of its ≤ 11 window bits on every
@@ -500,9 +443,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     __builtin_amdgcn_wave_barrier();
   };
   fetch_tile(hi_dw - TD, hi_dw);
-#if ZN_F_EARLY_STAGE
   stage_tile();
-#endif
 
   // sync: every sub-block except the tile's first guesses a start `delta` bits above itself and runs into it; returns the
   // position the lane's own decode starts from (lane 0: the true position carried over from the previous tile)
@@ -559,9 +500,6 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
     J = zn_uniform(J); JF = zn_uniform(JF);
     // ---- tile: dwords [lo_dw, hi_dw) of the stream, plus one below for look-ahead ----
     const int32_t lo_dw = hi_dw - TD;
-#if !ZN_F_EARLY_STAGE
-    stage_tile();
-#endif
     if (32 * lo_dw > b0) fetch_tile(lo_dw - TD, lo_dw);      // prefetch the next tile while this one is decoded
     // (tried, r02: requesting the rows this tile will PROBABLY complete — predicted from the previous tile's count — at the top of
     //  the tile, a whole decode pass ahead: no gain; a second flush batch's rows requested behind the first batch's wait: slower)
@@ -625,10 +563,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           int rows = (int)zn_uniform((base + N) / UNIT);
           const uint32_t total_rows = (uint32_t)rows;
           const int first = rows < RB ? rows : RB;
-#ifndef ZN_F_FETCH_SPLIT
-#define ZN_F_FETCH_SPLIT 1                // 1: request the second half of the flush's raw rows in the middle of the compaction, when half of the record registers are free again
-#endif
-          constexpr int RH = (ZN_F_FETCH_SPLIT && RB >= 4) ? RB / 2 : RB;         // rows requested before the compaction
+          constexpr int RH = (RB >= 4) ? RB / 2 : RB;         // rows requested before the compaction; the second half of a batch of four or more in the middle of it, when half of the record registers are free again
           for (int r = 0; r < RH; r++) if (r < first) fetch_row(JF, r);
           ZN_PT(8);   // scans / shuffles / issue loads
           ZN_PRIO(ZN_F_PRIO_WRITE);
@@ -650,9 +585,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
           J += N;
           // (the compaction is over: the stream-tile buffer is free for the next tile, staged behind the flush's wait)
           emit_rows(JF, first, 0, [&] {
-#if ZN_F_EARLY_STAGE
             if (32 * hi_dw > b0) stage_tile();
-#endif
           });
           uint32_t srow = (uint32_t)first;
           JF += (uint32_t)first * UNIT; rows -= first;
@@ -718,9 +651,7 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
         const uint32_t total_rows = (uint32_t)rows;
         uint32_t srow = 0;
         emit_rows(JF, first, srow, [&] {
-#if ZN_F_EARLY_STAGE
           if (lane_hi >= 64u && 32 * hi_dw > b0) stage_tile();
-#endif
         });
         JF += (uint32_t)first * UNIT; srow += (uint32_t)first; rows -= first;
         while (rows > 0) { const int nr = rows < RB ? rows : RB; fetch_rows(JF, nr); emit_rows(JF, nr, srow, [] {}); JF += (uint32_t)nr * UNIT; srow += (uint32_t)nr; rows -= nr; }
@@ -862,16 +793,13 @@ __device__ __forceinline__ int zn_fused_more_passes(ZnFusedLds& L, const ZnGeom&
 // (LUT fill by 256 threads, then wave w = stream w).  ncg = chunks per group (1..4, chosen by the host so
 // that small inputs still spread over every CU).
 // (the delta instance at 3 waves per SIMD — 168 VGPRs, fewer spills — was 50 % slower than at 4: occupancy matters
-// more than the spills, measured in profiles/r01z_delta_path.txt; ZN_F_XWAVES is that knob)
-#ifndef ZN_F_XWAVES
-#define ZN_F_XWAVES ZN_F_WAVES_PER_SIMD
-#endif
+// more than the spills, measured in profiles/r01z_delta_path.txt; every instance runs at ZN_F_WAVES_PER_SIMD)
 static_assert(sizeof(ZnFusedLds) * ZN_F_WAVES_PER_SIMD <= 160u * 1024u, "ZnFusedLds: the LDS budget of ZN_F_WAVES_PER_SIMD workgroups per CU");
 // REST (launches without partial chunks and delta bases): a chunk this kernel does not take is decoded right here by the generic
 // path's own device functions (zn_decode_rest.hpp: one wave per plane, then the merge) instead of being left to two more launches that would
 // return at once in nearly every call; `descs_rest` = the launch's plane descriptors (the generic kernels' workspace).
 template <int P, bool X, bool REST = false>
-__global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAVES) ? ZN_F_XWAVES : ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
+__global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode_fused(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                   uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                   uint32_t* __restrict__ status, uint32_t ntail,
                                                                   uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done, uint32_t only_pending,
@@ -982,7 +910,6 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
   ZN_PT(0);   // metadata
 
   // ---- wave j: is chunk j ours, and if it has a Huffman plane, its tree description ----
-  if (ZN_F_PRIO_PARSE) ZN_PRIO(ZN_F_PRIO_PARSE);
   if (wave < nc) {
     int h = -1; uint32_t nhuf = 0;
     bool elig = (g.chunk % (4u * P * UNIT)) == 0 && ((((uint64_t)dst) & 15u) == 0);
@@ -1003,7 +930,6 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
     }
     if (lane == 0) { L.st[wave] = st; L.what[wave] = elig ? (uint32_t)(h + 2) : 0u; }   // 0: not ours, 1: no Huffman plane, 2+h
   }
-  if (ZN_F_PRIO_PARSE) ZN_PRIO(0);
   __syncthreads();
   ZN_PT(1);   // tree descriptions (one per wave)
 
@@ -1035,9 +961,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
       const uint8_t* src = body + h_off;
       const ZnWaveStats st = L.st[j];
       const int hs = (int)zn_uniform((uint32_t)st.hs); TL = zn_uniform(st.tl);
-      if (ZN_F_PRIO_FILL) ZN_PRIO(ZN_F_PRIO_FILL);
       zn_fused_fill_luts(L, tid, TL, j, zn_uniform(st.lmin));
-      if (ZN_F_PRIO_FILL) ZN_PRIO(0);
       // jump table → this wave's stream
       const uint8_t* js = src + hs; const uint32_t rem = csize - (uint32_t)hs;
       const uint32_t l1 = zn_uniform(zn_ld16(js)), l2 = zn_uniform(zn_ld16(js + 2)), l3 = zn_uniform(zn_ld16(js + 4));
@@ -1072,9 +996,6 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
                             : (dense) ? zn_fused_wave<P, H_, ((X || P > 2 || !ZN_F_DCONST2) ? 0 : ZN_F_DCONST2), X>(ZN_WAVE_ARGS) \
                             : zn_fused_wave<P, H_, 0, X>(ZN_WAVE_ARGS)
     // (one instance per Huffman plane index that exists for this P — nothing is instantiated twice)
-#ifdef ZN_F_ONLY_HOT      // (developer probe: the common instance alone, to read its register use off the compiler's remarks)
-    if (P == 2) ok = zn_fused_wave<P, (P >= 2 ? 1 : 0), ZN_F_DCONST, X>(ZN_WAVE_ARGS); else
-#endif
     if (h < 0) ok = zn_fused_wave<P, -1, 0, X>(ZN_WAVE_ARGS);
     else if (P == 1 || h == 0) ZN_WAVE_CASE(0);
     else if (P == 2 || h == 1) ZN_WAVE_CASE((P >= 2 ? 1 : 0));
@@ -1083,13 +1004,11 @@ __global__ __launch_bounds__(ZN_F_THREADS, (X && ZN_F_WAVES_PER_SIMD > ZN_F_XWAV
 #undef ZN_WAVE_CASE
 #undef ZN_WAVE_ARGS
     // ---- further Huffman planes (deltas, sparse tensors: every plane compresses): one more pass per plane
-#ifndef ZN_F_ONLY_HOT
     if (P >= 2 && __builtin_expect(more != 0u, 0)) {
       const int r2 = zn_fused_more_passes<P>(L, g, body, body_end, outq, j, more, seg ZN_PT_PASS);
       if (r2 < 0) { ZN_REST_CHUNK(c); ZN_SET_DONE(c, 0); continue; }   // a later plane this kernel does not take: the generic path redoes the chunk
       ok = ok && r2 > 0;
     }
-#endif
     if (!ok) atomicOr(status, ZN_DEV_CORRUPT);
     ZN_SET_DONE(c, 1);
     ZN_PT_COUNT(19, 1);                        // chunks
@@ -1174,9 +1093,6 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   // launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9); partial last chunks (ntail > 0) are finished by merge workgroups at the
   // end of the same launch (d_tailsync: two zeroed words per tensor with a partial chunk) — except behind the wide kernel, which keeps the generic launches
   if (delta || (ntail != 0 && (wide || !d_tailsync))) d_descs_rest = nullptr;
-#if defined(ZN_F_NO_REST)                        /* developer A/B (scripts/ab_libs.py): the plain instance + the generic launches, as before round 4 */
-  d_descs_rest = nullptr;
-#endif
   const uint32_t ntt = ntail / (uint32_t)P;      // tensors with a partial last chunk
   uint32_t merge_per = 0;
   if (d_descs_rest && ntail) { merge_per = 32u; while (merge_per > 1u && (uint64_t)merge_per * ntt > 4096u) merge_per >>= 1; }

@@ -47,14 +47,8 @@ __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { const zn_ev4u v = _
 __device__ __forceinline__ uint4 zn_ldnt128(const void* p) { return *(const uint4*)p; }
 #endif
 #define ZN_LD_STATS(p) zn_ldnt128(p)
-#ifndef ZN_E_EMIT_REVERSE
-#define ZN_E_EMIT_REVERSE 0               // 1: emit walks the chunks from the last one down (what the stats pass read last is what the 256 MB Infinity Cache still holds); measured ±0 at 4 GiB
-#endif
-#ifndef ZN_E_STATS_AHEAD
-#define ZN_E_STATS_AHEAD 0                 // 1: the stats kernel requests step i + 1 before it counts step i.  Measured ±0 (806 vs 815 µs; without any
-                                           // atomics the kernel reads at 6.7 TB/s — 637 µs — and is SLOWER one step ahead: 796 µs): the 170 µs above the
-                                           // pure read are LDS atomics (one per byte) that the five workgroups per CU do not fully overlap with their loads
-#endif
+// (measured and gone, profiles/r02_decode_experiments.txt: the emit pass in reverse chunk order — ±0 at 4 GiB: a non-temporal first read leaves nothing in the
+//  Infinity Cache —; the stats pass requesting step i + 1 before it counts step i — ±0: what it adds to a pure read are LDS atomics, not exposed latency)
 #define ZN_LD_EMIT(p) (*(const uint4*)(p))
 
 typedef uint64_t __attribute__((aligned(1))) zn_eu64u;
@@ -235,8 +229,6 @@ __device__ __forceinline__ void zn_stats_count_impl(ZnStatsLds<P>& L, const ZnGe
   for (int p = 0; p < P; p++) tot[p] = 0;
   const uint32_t nvec = (uint32_t)(g.chunk / 4u) / 16u;       // 16-byte vectors per quarter (a multiple of 256)
   uint32_t* hbase = &L.hist[0][lane & (COLS - 1u)];
-  // The loads of step i + 1 are issued before the bytes of step i are counted, across quarter ends too (the column
-  // sums and their barriers would otherwise run with nothing in flight): ZN_E_STATS_AHEAD.
   const uint32_t qbytes = (uint32_t)(g.chunk / 4u);
   auto ld = [&](const uint8_t* a) -> uint4 { return NT ? ZN_LD_STATS(a) : *(const uint4*)a; };
   auto fetch = [&](uint4 (&xs)[4], uint32_t q, uint32_t v0) {
@@ -248,20 +240,14 @@ __device__ __forceinline__ void zn_stats_count_impl(ZnStatsLds<P>& L, const ZnGe
     }
   };
   uint4 nx[4];
-  if (ZN_E_STATS_AHEAD) fetch(nx, 0u, tid);
   for (uint32_t i = tid; i < PAIRS * 256u * COLS; i += ZN_E_THREADS) (&L.hist[0][0])[i] = 0;
   __syncthreads();
   for (int q = 0; q < 4; q++) {
-    // 4 independent 16-byte loads in flight per thread per step, one step ahead
+    // 4 independent 16-byte loads in flight per thread per step
     for (uint32_t v0 = tid; v0 < nvec; v0 += 4u * ZN_E_THREADS) {
       uint4 xs[4];
-      if (!ZN_E_STATS_AHEAD) fetch(nx, (uint32_t)q, v0);
+      fetch(nx, (uint32_t)q, v0);
       for (int u = 0; u < 4; u++) xs[u] = nx[u];
-      const uint32_t v1 = v0 + 4u * ZN_E_THREADS;
-      if (ZN_E_STATS_AHEAD) {
-        if (v1 < nvec) fetch(nx, (uint32_t)q, v1);
-        else if (q < 3) fetch(nx, (uint32_t)q + 1u, tid);
-      }
       for (int u = 0; u < 4; u++) if (WHOLE || v0 + ZN_E_THREADS * (uint32_t)u < nvec) {
         // (the vector's 16 / P elements plane by plane: zn_split4 per four elements, then one counter per byte)
         const uint32_t d[4] = {xs[u].x, xs[u].y, xs[u].z, xs[u].w};
@@ -599,17 +585,11 @@ __device__ __forceinline__ bool zn_emit_pass(const ZnGeom& g, const uint8_t* __r
   // this lane's 32 elements of a tile = 32·P source bytes.  ZN_E_SPLIT: TWO runs of 16 — elements [16 l, +16) of the tile's lower half (d[0 .. 4P)) and of its upper half
   // (d[4P .. 8P)) — instead of one run of 32: a raw plane's 32 bytes per lane then leave as two 16-byte stores that each write 1 KB contiguous across the wave
   // (whole 32-byte sectors); as one run, each non-temporal store wrote half of every sector (the emit kernel's 8 % write surplus: profiles/r04_decode_experiments.txt)
-#ifndef ZN_E_SPLIT
 #define ZN_E_SPLIT 1
-#endif
-#ifndef ZN_E_PREFETCH
 #define ZN_E_PREFETCH 1                   // the NEXT tile's source vectors are requested before this tile is packed (the emit kernel; the one-pass kernel has no registers for them)
-#endif
   constexpr uint32_t RUN = ZN_E_SPLIT ? ZN_E_SPL / 2u : ZN_E_SPL;          // consecutive elements of a run
   constexpr uint32_t HALF = ZN_E_SPLIT ? ZN_E_TILE / 2u : 0u;              // element distance between the lane's two runs
-#ifndef ZN_E_PREFETCH_NT
 #define ZN_E_PREFETCH_NT 1                // … in the one-pass kernel as well (its four-workgroups-per-CU build: 128 registers; 4 GiB bf16 2.223 -> 2.185 ms against five workgroups without)
-#endif
   constexpr bool AHEAD = (ZN_E_PREFETCH != 0) && !X && (!NT || ZN_E_PREFETCH_NT != 0);
   auto load_tile = [&](uint32_t (&d)[8 * P], int32_t base) {
     const uint8_t* a = qsrc + (uint64_t)P * ((uint32_t)base + RUN * lane);
@@ -847,9 +827,7 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
     zn_encode_tail_emit(L.code, L.buf, S, tb - S.ptail0, planes_all, slot, csize_all, type_all, offs_all, descs_all, status);
     return;
   }
-  // ZN_E_EMIT_REVERSE: the emit pass walks the chunks from the last one down — what the stats pass read last is what the
-  // Infinity Cache (256 MB, memory side) still holds
-  const uint32_t bid = ZN_E_EMIT_REVERSE ? nchunks - 1u - blockIdx.x : blockIdx.x;
+  const uint32_t bid = blockIdx.x;
   const ZnESeg S = zn_efind_chunk(one, segs, nseg, bid);
   const ZnGeom g = S.g;
   const uint8_t* __restrict__ src = ZN_GLOBAL_PTR(const uint8_t, S.src); uint8_t* __restrict__ body = ZN_GLOBAL_PTR(uint8_t, S.body);
@@ -923,16 +901,10 @@ __global__ __launch_bounds__(ZN_E_THREADS) void zn_k_encode_emit(ZnESeg one, con
 #define ZN_LB_VBITS 40u                   // look-back word: generation (22 bits) | state (2 bits: 1 = own size, 2 = inclusive prefix) | value (40 bits)
 #define ZN_LB_VMASK ((1ull << ZN_LB_VBITS) - 1ull)
 
-#ifndef ZN_OP_WGS
 #define ZN_OP_WGS 4                      // one-pass workgroups per CU: the histogram's 32 KiB of LDS allow five (96 registers a wave); the time is the same from two to five
                                          // (profiles/r05_encoder_onepass.txt), and four leave the registers for the emit pass's next tile (ZN_E_PREFETCH_NT)
-#endif
-#ifndef ZN_OP_NT2
 #define ZN_OP_NT2 1                      // the second read non-temporal (0: plain — it then allocates in the caches like the first)
-#endif
-#ifndef ZN_OP_NT1
 #define ZN_OP_NT1 0                      // (developer A/B: 1 = the first read non-temporal as well — nothing is left in the Infinity Cache for the second)
-#endif
 template <int P>
 struct ZnOnePassLds {
   union {
