@@ -280,8 +280,9 @@ __device__ __forceinline__ void zn_pass2(uint32_t* stage, uint32_t wpos, ZnRec& 
     const uint32_t g = ~wm1;                               // low two bits = (-wpos) & 3
     uint32_t* d = (uint32_t*)((uint8_t*)stage + (int32_t)(wm1 & AMASK));
     // (per DWORD: a lane stays out of an atomic whose operand is zero — with wpos == 0 the pair starts one dword BELOW the staging buffer, the neighbouring
-    //  wave's last dword or the LUT's, and only this test keeps that zero-valued atomic from being issued; masks per lane or none at all measured slower /
-    //  are wrong: profiles/r02_decode_experiments.txt)
+    //  wave's last dword or the LUT's, and only this test keeps that zero-valued atomic from being issued.  Measured again in round 6
+    //  (profiles/r06_decode_experiments.txt): every lane, every dword — 12 scalar instructions fewer per record — is 6.7 % SLOWER on bf16 (1.602 vs 1.501 ms), 5 % on fp8:
+    //  the LDS pipe pays for an atomic whether or not it changes anything)
     const uint32_t lo = zn_alignbyte(sv, 0u, g), hi = zn_alignbyte(0u, sv, g);
     if (lo) atomicOr(d, lo);
     if (hi) atomicOr(d + 1, hi);
