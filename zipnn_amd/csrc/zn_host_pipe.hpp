@@ -17,9 +17,6 @@
 #include <time.h>
 #include <string.h>
 #include <sys/mman.h>
-#if defined(__x86_64__) && !defined(ZN_SIMT_EMULATOR)
-#include <immintrin.h>
-#endif
 
 struct ZnHostPipe {
   void* pin[2] = {nullptr, nullptr};
@@ -116,31 +113,8 @@ inline unsigned worker_count(size_t n) {
   return t;
 }
 
-// A worker's copy with non-temporal stores (AVX2, 32 bytes a store): the destination of a staging copy is never read by this core again — the DMA engine reads a
-// bounce buffer from memory, a caller's result buffer is his — so the write-allocate reads of a plain memcpy (a third of its memory traffic) buy nothing.
-// ZN_HOST_NT=0 goes back to memcpy.  (x86-64 hosts; anything else, or no AVX2: memcpy.)
-#if defined(__x86_64__) && !defined(ZN_SIMT_EMULATOR)
-__attribute__((target("avx2"))) inline void stream_copy_avx2(uint8_t* d, const uint8_t* s, size_t n) {
-  const size_t head = (32u - ((uintptr_t)d & 31u)) & 31u;
-  if (head) { const size_t h = head < n ? head : n; memcpy(d, s, h); d += h; s += h; n -= h; }
-  size_t i = 0;
-  for (; i + 128 <= n; i += 128) {
-    const __m256i a = _mm256_loadu_si256((const __m256i*)(s + i)), b = _mm256_loadu_si256((const __m256i*)(s + i + 32));
-    const __m256i c = _mm256_loadu_si256((const __m256i*)(s + i + 64)), e = _mm256_loadu_si256((const __m256i*)(s + i + 96));
-    _mm256_stream_si256((__m256i*)(d + i), a); _mm256_stream_si256((__m256i*)(d + i + 32), b);
-    _mm256_stream_si256((__m256i*)(d + i + 64), c); _mm256_stream_si256((__m256i*)(d + i + 96), e);
-  }
-  _mm_sfence();
-  if (i < n) memcpy(d + i, s + i, n - i);
-}
-inline void worker_copy(uint8_t* d, const uint8_t* s, size_t n) {
-  static const int nt = [] { const char* e = getenv("ZN_HOST_NT"); return ((e && e[0] == '0') || !__builtin_cpu_supports("avx2")) ? 0 : 1; }();
-  if (nt && n >= 4096) stream_copy_avx2(d, s, n); else memcpy(d, s, n);
-}
-#else
-inline void worker_copy(uint8_t* d, const uint8_t* s, size_t n) { memcpy(d, s, n); }
-#endif
-
+// (round 6, measured and not kept: the workers' copies with non-temporal AVX2 stores, 16 / 32 threads, 64 MiB slices — the staged path moves 1 GiB in 33-37 ms each
+//  way in every combination, profiles/r06_host_path.txt: one staged direction already runs at the DMA engine's pace, 18.8 ms per GiB, the one-shot call is their sum)
 // the stripe of [0, len) that worker w of t copies (64-byte aligned cuts)
 inline void stripe(size_t len, unsigned w, unsigned t, size_t* lo, size_t* hi) {
   const size_t per = ((len + t - 1) / t + 63) & ~(size_t)63;
@@ -212,7 +186,7 @@ inline hipError_t zn_host_pipe_copy(ZnHostPipe& p, void* d, void* h, size_t n, b
           go.wait();
           if (stop.load()) return;
           size_t lo, hi; stripe(cur.len, w, nworkers, &lo, &hi);
-          if (hi > lo && !cur.touch) worker_copy(cur.dst + lo, cur.src + lo, hi - lo);
+          if (hi > lo && !cur.touch) memcpy(cur.dst + lo, cur.src + lo, hi - lo);
           else if (hi > lo) { volatile uint8_t* q = cur.dst; for (size_t o = lo; o < hi; o += 4096) q[o] = 0; }      // first touch of a destination piece (it is overwritten by the DMA that follows)
           done.wait();
         }
