@@ -1248,3 +1248,36 @@ def test_decode_status_after_the_workspace_is_released(lib):
     with pytest.raises(ZnError):
         lib.decode_status()                                    # "cannot vouch for it", not a guess
     lib.decode_status()                                        # (asked and answered: the token is spent)
+
+
+@pytest.mark.parametrize("mode", [4, 7, 5, 6, 0])
+def test_host_entry_points_in_every_transfer_mode(lib, mode):
+    """zn_set_host_direct (round 6): the host-buffer entry points — what the INTEGRATION stub binds (reference zipnn/zipnn.py:714-725,
+    1143-1151) — with the staged pipe + huge-page hint (4, the default), with the caller's buffers pinned and moved by DMA (7: direct both ways; 5 / 6: one
+    direction only) and with neither (0): 320 MiB of bf16 (above the 128 MiB / 192 MiB thresholds of the direct path and of the slice pipeline), a ragged tail,
+    fresh AND recycled result buffers, one-shot and pipelined — the same frame as the oracle's every time, the same bytes back."""
+    import ctypes
+    L = lib._L
+    n = 320 * KB * KB + 250_000
+    g = torch.Generator().manual_seed(606)
+    x = (torch.randn(n // 2, generator=g) * 0.02).to(torch.bfloat16).view(torch.uint8).numpy()
+    hdr = np.frombuffer(HDR, dtype=np.uint8)
+    want = O.compress_frame(HDR, x, 2, 1, 10, C, threads=8)
+    cap = L.zn_compress_bound(n, 2, C, 32)
+    sz = ctypes.c_size_t(0)
+    warm_frame, warm_back = np.empty(cap, dtype=np.uint8), np.empty(n, dtype=np.uint8)
+    try:
+        lib.set_host_direct(mode)
+        for slices in (0, 1, 5):
+            lib.set_host_slices(slices)
+            for fresh in (False, True, False):
+                fr = np.empty(cap, dtype=np.uint8) if fresh else warm_frame
+                assert L.zn_compress(hdr.ctypes.data, 32, x.ctypes.data, n, 2, 1, 10, C, ctypes.c_float(0.95), 0, fr.ctypes.data, cap, ctypes.byref(sz)) == 0
+                assert sz.value == len(want) and fr[:sz.value].tobytes() == want, (mode, slices, fresh)
+                bk = np.empty(n, dtype=np.uint8) if fresh else warm_back
+                bk[:64] = 0
+                assert L.zn_decompress(fr.ctypes.data + 32, sz.value - 32, 2, 1, 10, C, n, 0, bk.ctypes.data) == 0
+                assert np.array_equal(bk, x), (mode, slices, fresh)
+    finally:
+        lib.set_host_direct(4); lib.set_host_slices(0)
+    assert torch.cuda.current_device() == 0

@@ -1011,6 +1011,35 @@ def test_decode_status_belongs_to_the_calling_threads_call(simt_lib):
     assert res == [None]
 
 
+@pytest.mark.parametrize("mode", [4, 7])
+def test_host_entry_points_staged_and_direct_bookkeeping(simt_lib, mode):
+    """zn_set_host_direct on the emulated library (hipHostRegister is a no-op there: "device" memory is host memory): the direct path's bookkeeping — piece cuts on
+    2 MiB boundaries, one DMA per registration, the maps of the slice pipeline, the residency rule — against the staged path, 130 MiB of mostly incompressible bytes
+    (cheap for the emulated kernels) with a compressible stretch and a ragged tail; same frame as the oracle, same bytes back, fresh and recycled buffers."""
+    import ctypes
+    L = simt_lib._L
+    n = 130 * 1024 * 1024 + 777
+    rng = np.random.default_rng(9)
+    x = rng.integers(0, 256, n, dtype=np.uint8)
+    x[5 * C: 9 * C] = np.frombuffer(gen_bytes("bf16", 4 * C, 3), dtype=np.uint8)
+    want = O.compress_frame(HDR, x, 2, 1, 10, C, threads=8)
+    hdr = np.frombuffer(HDR, dtype=np.uint8)
+    cap = L.zn_compress_bound(n, 2, C, 32); sz = ctypes.c_size_t(0)
+    warm_frame, warm_back = np.zeros(cap, dtype=np.uint8), np.zeros(n, dtype=np.uint8)
+    try:
+        simt_lib.set_host_direct(mode)
+        for slices, fresh in ((0, False), (3, True), (1, False)):
+            simt_lib.set_host_slices(slices)
+            fr = np.empty(cap, dtype=np.uint8) if fresh else warm_frame
+            assert L.zn_compress(hdr.ctypes.data, 32, x.ctypes.data, n, 2, 1, 10, C, ctypes.c_float(0.95), 0, fr.ctypes.data, cap, ctypes.byref(sz)) == 0
+            assert fr[:sz.value].tobytes() == want
+            bk = np.empty(n, dtype=np.uint8) if fresh else warm_back
+            assert L.zn_decompress(fr.ctypes.data + 32, sz.value - 32, 2, 1, 10, C, n, 0, bk.ctypes.data) == 0
+            assert np.array_equal(bk, x)
+    finally:
+        simt_lib.set_host_direct(4); simt_lib.set_host_slices(0)
+
+
 def test_decode_status_after_the_workspace_is_released(simt_lib):
     """the token of an unverified check = 0 decode outlives zn_release_workspace; the answer is then an error, once, not "ok"."""
     d = gen_bytes("bf16", 2 * C, 4)
