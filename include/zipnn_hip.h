@@ -222,6 +222,15 @@ int zn_set_host_slices(int slices);
  * buffer in get slower in a long-lived process that has pinned user memory).  Also ZIPNN_AMD_HOST_DIRECT=0..7 in the environment.  Returns 0 or ZN_E_ARG. */
 int zn_set_host_direct(int mode);
 
+/* Pinned host memory from the library's arena, for buffers that cross PCIe — above all the RESULT of zn_compress / zn_decompress, which the reference's extension
+ * also allocates itself and returns as a memoryview (csrc/zipnn_core.c:596, 1126).  A transfer between such a block and HBM is one DMA (57 GB/s, no staging copy, no
+ * page faults, and releasing it costs nothing: a pageable 1 GiB result costs its owner 40-130 ms of munmap): with a FRESH block per call — allocate, call, release —
+ * 1 GiB of bf16 takes 28-30 ms to compress and 33-36 ms to decompress, all in, against 59-61 and 75 ms with a fresh pageable result; freed blocks are recycled (up to ZIPNN_AMD_HOST_ARENA_MB = 8192 MiB of them are kept;
+ * zn_release_workspace returns them to the driver).  zn_host_alloc: NULL when the driver has no more pinned memory; zn_host_free: 0, or ZN_E_ARG for a pointer that
+ * is not a live block.  Thread-safe. */
+void* zn_host_alloc(size_t n);
+int zn_host_free(void* p);
+
 /* the one-pass encoder (full chunks histogrammed, coded and placed by one workgroup each, the chunk's second read aimed at the Infinity Cache) —
  * 0 = never (the four-kernel encoder only), 1 (default; ZIPNN_AMD_ONEPASS=0/1/2 in the environment changes the default) = automatic: calls whose
  * bf16-like tensors (two planes, sign rotate) bring at least 6144 full chunks — where it has measured faster —, 2 = every call with full chunks.

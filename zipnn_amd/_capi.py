@@ -10,6 +10,7 @@ The two host-buffer calls mirror the reference's C extension one for one:
 at zipnn/zipnn.py:1143) -> :meth:`ZnLib.decompress`.
 """
 import ctypes
+import weakref
 import os
 
 import numpy as np
@@ -85,6 +86,10 @@ class ZnLib:
         L.zn_set_host_slices.argtypes = [ci]
         L.zn_set_host_direct.restype = ci
         L.zn_set_host_direct.argtypes = [ci]
+        L.zn_host_alloc.restype = vp
+        L.zn_host_alloc.argtypes = [sz]
+        L.zn_host_free.restype = ci
+        L.zn_host_free.argtypes = [vp]
         L.zn_set_decode_group.restype = ci
         L.zn_set_decode_group.argtypes = [ci]
         L.zn_decode_group_for.restype = ci
@@ -149,6 +154,25 @@ class ZnLib:
         return self._L.zn_last_kernels().decode()
 
     # -- host buffers --------------------------------------------------------------------
+    HOST_ARENA_MIN = 8 << 20      # results from this size up come out of the library's pinned arena (zn_host_alloc)
+
+    def host_buffer(self, n):
+        """An uninitialised uint8 numpy array of n bytes for a RESULT that crosses PCIe: from 8 MiB up a block of the library's pinned arena (zn_host_alloc — one
+        DMA instead of a staged copy, no first-touch faults, recycled when the last view of it dies), below that (or when the driver has no pinned memory left, or
+        ZIPNN_AMD_HOST_ARENA_MB=0) plain np.empty.  What the reference's extension does too: its results are memoryviews over memory it allocated (csrc/zipnn_core.c:596, 1126)."""
+        n = max(int(n), 1)
+        if n >= self.HOST_ARENA_MIN and os.environ.get("ZIPNN_AMD_HOST_ARENA_MB") != "0":
+            p = self._L.zn_host_alloc(n)
+            if p:
+                try:
+                    arr = np.ctypeslib.as_array((ctypes.c_uint8 * n).from_address(p)).view(_ArenaArray)
+                    weakref.finalize(arr, self._L.zn_host_free, ctypes.c_void_p(p))     # every view / memoryview of it keeps `arr` alive
+                    return arr
+                except Exception:
+                    self._L.zn_host_free(ctypes.c_void_p(p))
+                    raise
+        return np.empty(n, dtype=np.uint8)
+
     def compress(self, header, data, num_buf, bits_mode, bytes_mode, chunk, threshold, device=0, delta=None):
         """header/data: bytes-like (not modified).  Returns the frame as a writable memoryview over an
         uninitialised numpy buffer (a zero-filled 1 GiB bytearray alone costs 180 ms).  delta: bytes-like of
@@ -157,7 +181,7 @@ class ZnLib:
         dv = memoryview(data).cast("B")
         n = dv.nbytes
         cap = self._L.zn_compress_bound(n, num_buf, chunk, hv.nbytes)
-        out = np.empty(max(cap, 1), dtype=np.uint8)
+        out = self.host_buffer(cap)
         out_len = ctypes.c_size_t(0)
         hb = (ctypes.c_char * max(hv.nbytes, 1)).from_buffer_copy(hv.tobytes() or b"\0")
         src = _as_c_buffer(dv)
@@ -177,7 +201,7 @@ class ZnLib:
         """body: bytes-like after the header.  Returns orig_size bytes as a writable memoryview (numpy-backed).
         delta: bytes-like of orig_size bytes XORed into the output on the device."""
         bv = memoryview(body).cast("B")
-        out = np.empty(max(orig_size, 1), dtype=np.uint8)
+        out = self.host_buffer(orig_size)
         src = _as_c_buffer(bv)
         dl = _as_c_buffer(memoryview(delta).cast("B")) if delta is not None else None
         if dl is not None and memoryview(delta).nbytes != orig_size:
@@ -373,6 +397,10 @@ class ZnLib:
 
     def release_workspace(self):
         self._check(self._L.zn_release_workspace())
+
+
+class _ArenaArray(np.ndarray):
+    """A numpy view of a block of the library's pinned arena (ZnLib.host_buffer): a subclass only so that it can carry a finalizer."""
 
 
 class _CBuf:

@@ -601,7 +601,8 @@ int zn_compress_delta(const void* hdr, size_t hdr_len, const void* src, const vo
   // The DIRECT transfers (the caller's buffers pinned, DMA straight between them and HBM: zn_host_pipe.hpp) are for calls whose RESULT buffer is already
   // backed by pages — a recycled buffer, or one its owner has written before.  A call that has to fault its result in goes the staged way of rounds 1-5 in
   // BOTH directions: page faults in a process with pinned user memory were measured slow and disruptive to every DMA in flight (profiles/r06_host_path.txt).
-  const bool direct = zn_host_pipe_detail::direct_enabled() && zn_host_resident(dst, hdr_len + 9u * (size_t)num_buf * zn_num_chunks(n, chunk) + n / 2);
+  // (a result buffer from zn_host_alloc needs none of this: its downloads are plain DMAs whichever way the call is cut — zn_host_pipe_copy sees to that)
+  const bool direct = zn_host_pipe_detail::direct_enabled() && !zn_arena().covers(dst, dst_cap) && zn_host_resident(dst, hdr_len + 9u * (size_t)num_buf * zn_num_chunks(n, chunk) + n / 2);
   if (!delta && (num_buf == 1 || num_buf == 2 || num_buf == 4) && chunk) {
     const int S = zn_host_slices(n, chunk, false, direct);
     if (S >= 2) {
@@ -659,7 +660,9 @@ int zn_decompress_delta(const void* body, size_t body_len, const void* delta, in
   ZN_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) return ZN_E_ARG;
   zn_host_thp_hint(dst, orig_size);
-  const bool direct = zn_host_pipe_detail::direct_enabled() && zn_host_resident(dst, orig_size);      // (see zn_compress_delta)
+  // (an arena result stays one shot like a pageable one: measured, the slice pipeline with a STAGED upload beside the arena's download DMAs is slower than their sum —
+  //  36-38 ms against 33 for 1 GiB; the copy threads and the two DMA directions meet in the host's memory: profiles/r06_host_path.txt)
+  const bool direct = zn_host_pipe_detail::direct_enabled() && !zn_arena().covers(dst, orig_size) && zn_host_resident(dst, orig_size);      // (see zn_compress_delta)
   if (!delta && (num_buf == 1 || num_buf == 2 || num_buf == 4) && chunk) {
     const int S = zn_host_slices(orig_size, chunk, true, direct);
     if (S >= 2) {
@@ -982,6 +985,8 @@ static int zn_host_slices(size_t n, size_t chunk, bool decompress, bool direct) 
   if (S > K) S = K;
   return S >= 2 ? (int)S : 0;
 }
+void* zn_host_alloc(size_t n) { try { return zn_arena().alloc(n); } catch (...) { return nullptr; } }
+int zn_host_free(void* p) { if (!p) return ZN_OK; try { return zn_arena().release(p) ? ZN_OK : ZN_E_ARG; } catch (...) { return ZN_E_ALLOC; } }
 int zn_set_host_direct(int mode) {
   if (mode < 0 || mode > 7) return ZN_E_ARG;
   zn_host_pipe_detail::direct_mode_ref().store(mode, std::memory_order_relaxed);
@@ -1017,8 +1022,10 @@ static int zn_decompress_host_pipelined(const void* body, size_t body_len, int n
   // the caller's two buffers made DMA-able ahead of the transfers (zn_host_pipe.hpp: ZnHostMap): the payload for reading, the result — hinted to
   // huge pages, touched, pinned, piece by piece on helper threads — for writing.  Declared ahead of the workers: unpinned after they are joined.
   ZnHostMap src_map, dst_map;
-  if (direct) { src_map.start(const_cast<uint8_t*>(v.pay), v.pay_len, false, ~(size_t)0, dev); dst_map.start(dst, orig_size, true, ~(size_t)0, dev); }
-  else { src_map.gave_up = true; dst_map.gave_up = true; }
+  // (user memory is only pinned when the caller asked for it — zn_set_host_direct — and never a block of the library's own arena: that is pinned already)
+  const bool pin_user = direct;
+  if (pin_user && !zn_arena().covers(v.pay, v.pay_len)) src_map.start(const_cast<uint8_t*>(v.pay), v.pay_len, false, ~(size_t)0, dev); else src_map.gave_up = true;
+  if (pin_user && !zn_arena().covers(dst, orig_size)) dst_map.start(dst, orig_size, true, ~(size_t)0, dev); else dst_map.gave_up = true;
   try {
     ZnWorkers wk;
     ZnGateGuard guard(&up, &dec);
@@ -1107,8 +1114,9 @@ static int zn_compress_host_pipelined(const void* hdr, size_t hdr_len, const voi
   int rc_up = ZN_OK, rc_down = ZN_OK, rc_enc = ZN_OK;
   std::vector<std::vector<uint8_t>> metas((size_t)S);
   ZnHostMap src_map, dst_map;                       // (as in the decompress pipeline; the result is prepared as far as a weights-like tensor will need it, further on demand)
-  if (direct) { src_map.start(const_cast<void*>(src), n, false, ~(size_t)0, dev); dst_map.start(dst, dst_cap, true, hdr_len + 9 * P * K + n / 2 + n / 4, dev); }
-  else { src_map.gave_up = true; dst_map.gave_up = true; }
+  const bool pin_user = direct;
+  if (pin_user && !zn_arena().covers(src, n)) src_map.start(const_cast<void*>(src), n, false, ~(size_t)0, dev); else src_map.gave_up = true;
+  if (pin_user && !zn_arena().covers(dst, dst_cap)) dst_map.start(dst, dst_cap, true, hdr_len + 9 * P * K + n / 2 + n / 4, dev); else dst_map.gave_up = true;
   try {
     ZnWorkers wk;
     ZnGateGuard guard(&up, &queued);
@@ -1408,6 +1416,7 @@ int zn_debug_hold_device_lock(int dev, int ms) {
 #endif
 
 int zn_release_workspace(void) {
+  zn_arena().trim();
   { std::lock_guard<std::mutex> mk(g_multi_mu); for (int i = 0; i < 64; i++) { free(g_multi_stage[i].p); g_multi_stage[i].p = nullptr; g_multi_stage[i].cap = 0; } }
   int prev = -1;
   if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; }

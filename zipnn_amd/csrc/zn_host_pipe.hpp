@@ -151,6 +151,66 @@ inline hipError_t zn_host_pipe_init(ZnHostPipe& p) {
 }
 
 // to_device: host `h` -> device `d`; else device `d` -> host `h`.  Returns when the transfer is complete.
+// ---- the library's own pinned host memory (round 6): zn_host_alloc / zn_host_free ---------------------------------------------------
+// Result buffers that the LIBRARY hands out — what the reference's extension does as well: its two functions return memoryviews over memory it
+// malloc'ed itself (csrc/zipnn_core.c:596, 1126) — come from an arena of hipHostMalloc'ed blocks that are recycled: no first-touch faults, no 50-130 ms
+// munmap per GiB on release, and a transfer between such a block and HBM is ONE asynchronous DMA (57 GB/s; with the upload of the call running beside it
+// the copy engines reach their full duplex).  Driver-allocated pinned memory has none of the side effects measured for hipHostRegister'ed user memory
+// (profiles/r06_host_path.txt): the library has staged through two such blocks since round 1.
+// Blocks are kept when freed, up to ZIPNN_AMD_HOST_ARENA_MB (default 8192) MiB of free blocks; a request takes the smallest free block that fits and is
+// not more than twice too big, else a new one (rounded up to 2 MiB).
+struct ZnArena {
+  struct Block { uint8_t* p; size_t cap; bool used; };
+  std::mutex m;
+  std::vector<Block> blocks;
+  size_t free_bytes = 0;
+  static size_t limit() {
+    static const size_t v = [] { const char* e = getenv("ZIPNN_AMD_HOST_ARENA_MB"); const long long mb = e ? atoll(e) : 8192; return (size_t)(mb < 0 ? 0 : mb) << 20; }();
+    return v;
+  }
+  void* alloc(size_t n) {
+    if (n == 0) n = 1;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      int best = -1;
+      for (size_t i = 0; i < blocks.size(); i++)
+        if (!blocks[i].used && blocks[i].cap >= n && blocks[i].cap / 2 <= n && (best < 0 || blocks[i].cap < blocks[(size_t)best].cap)) best = (int)i;
+      if (best >= 0) { blocks[(size_t)best].used = true; free_bytes -= blocks[(size_t)best].cap; return blocks[(size_t)best].p; }
+    }
+    const size_t cap = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    try { std::lock_guard<std::mutex> lk(m); blocks.push_back(Block{(uint8_t*)p, cap, true}); }
+    catch (...) { (void)hipHostFree(p); return nullptr; }
+    return p;
+  }
+  bool release(void* p) {                         // false: not a block of this arena
+    void* drop = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(m);
+      size_t i = 0;
+      for (; i < blocks.size(); i++) if (blocks[i].p == (uint8_t*)p && blocks[i].used) break;
+      if (i == blocks.size()) return false;
+      if (free_bytes + blocks[i].cap > limit()) { drop = blocks[i].p; blocks.erase(blocks.begin() + (long)i); }
+      else { blocks[i].used = false; free_bytes += blocks[i].cap; }
+    }
+    if (drop) (void)hipHostFree(drop);
+    return true;
+  }
+  // is [h, h + n) inside one (in-use) block?
+  bool covers(const void* h, size_t n) {
+    std::lock_guard<std::mutex> lk(m);
+    for (const Block& b : blocks) if (b.used && (const uint8_t*)h >= b.p && (const uint8_t*)h + n <= b.p + b.cap) return true;
+    return false;
+  }
+  void trim() {                                   // every free block back to the driver (zn_release_workspace)
+    std::vector<void*> drop;
+    { std::lock_guard<std::mutex> lk(m); for (size_t i = blocks.size(); i-- > 0;) if (!blocks[i].used) { drop.push_back(blocks[i].p); blocks.erase(blocks.begin() + (long)i); } free_bytes = 0; }
+    for (void* q : drop) (void)hipHostFree(q);
+  }
+};
+inline ZnArena& zn_arena() { static ZnArena a; return a; }
+
 // keep (optional): pieces of the caller's buffer that the direct path pinned are left pinned and listed there — the caller unregisters them
 // (zn_host_unpin) once every stream that may touch them is idle.
 struct ZnPinList { std::mutex m; std::vector<void*> v; };
@@ -167,6 +227,11 @@ inline hipError_t zn_host_pipe_copy(ZnHostPipe& p, void* d, void* h, size_t n, b
   }
   if (e != hipSuccess)                          // no pinned memory to be had: the plain, slower way
     return to_device ? hipMemcpy(d, h, n, hipMemcpyHostToDevice) : hipMemcpy(h, d, n, hipMemcpyDeviceToHost);
+  if (zn_arena().covers(h, n)) {                // the library's own pinned memory (zn_host_alloc): one DMA, nothing to stage (cut into 4-64 MiB pieces: no difference, measured)
+    e = to_device ? hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, p.stream) : hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, p.stream);
+    const hipError_t e2 = hipStreamSynchronize(p.stream);
+    return e != hipSuccess ? e : e2;
+  }
   const size_t S = p.slice;
   const unsigned T = worker_count(n);
   Barrier go(T + 1), done(T + 1);
@@ -343,6 +408,7 @@ struct ZnHostMap {
 // one transfer of the pipelined paths: through the map when the range is pinned (one asynchronous DMA on the pipe's stream, waited for), the staged copy otherwise
 inline hipError_t zn_host_copy_mapped(ZnHostMap& map, ZnHostPipe& p, void* d, void* h, size_t len, bool to_device) {
   if (len == 0) return hipSuccess;
+  if (len >= ((size_t)1 << 20) && zn_arena().covers(h, len)) return zn_host_pipe_copy(p, d, h, len, to_device, nullptr, true);      // (its arena branch: one DMA)
   const size_t off = (size_t)((uint8_t*)h - map.h);
   if (len >= ((size_t)1 << 20) && (uint8_t*)h >= map.h && off + len <= map.n && map.wait(off, len)) {
     hipError_t e = zn_host_pipe_init(p);
