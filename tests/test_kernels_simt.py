@@ -1040,6 +1040,39 @@ def test_host_entry_points_staged_and_direct_bookkeeping(simt_lib, mode):
         simt_lib.set_host_direct(4); simt_lib.set_host_slices(0)
 
 
+def test_results_come_out_of_the_pinned_arena_and_go_back(simt_lib):
+    """zn_host_alloc / zn_host_free (round 6) and what stands on them: ZnLib.compress / decompress hand out results of 8 MiB and more as views of a block of the
+    library's pinned arena (the reference's extension also returns memoryviews over memory it allocated: csrc/zipnn_core.c:596, 1126); the block goes back when the
+    LAST view of it dies and is the block the next request of that size gets."""
+    import ctypes
+    import gc
+    L = simt_lib._L
+    p1 = L.zn_host_alloc(10 << 20); assert p1
+    assert L.zn_host_free(ctypes.c_void_p(p1)) == 0
+    assert L.zn_host_free(ctypes.c_void_p(p1)) == -1                   # not a live block any more
+    assert L.zn_host_free(ctypes.c_void_p(0)) == 0
+    p2 = L.zn_host_alloc(9 << 20); assert p2 == p1                       # recycled (within a factor of two of its size)
+    p3 = L.zn_host_alloc(1 << 20); assert p3 and p3 != p2                # … but not for a request a tenth of it
+    assert L.zn_host_free(ctypes.c_void_p(p2)) == 0 and L.zn_host_free(ctypes.c_void_p(p3)) == 0
+    n = 9 * 1024 * 1024 + 5
+    d = np.random.default_rng(3).integers(0, 256, n, dtype=np.uint8).tobytes()
+    want = O.compress_frame(HDR, d, 2, 1, 10, C, threads=8)
+    fr = simt_lib.compress(HDR, d, 2, 1, 10, C, 0.95)
+    assert bytes(fr) == want
+    base = fr.obj
+    assert type(base).__name__ == "_ArenaArray"
+    addr = base.ctypes.data
+    back = simt_lib.decompress(fr[32:], 2, 1, 10, C, n)
+    assert bytes(back) == d and type(back.obj).__name__ == "_ArenaArray"
+    tail = fr[100:200]                                                   # a view of a view keeps the block alive
+    del fr, base; gc.collect()
+    assert bytes(tail) == want[100:200]
+    assert L.zn_host_alloc.restype is not None and addr                 # (the block is still out: `tail` holds it)
+    del tail, back; gc.collect()
+    small = simt_lib.compress(HDR, d[:C], 2, 1, 10, C, 0.95)             # below 8 MiB: ordinary memory
+    assert type(small.obj).__name__ != "_ArenaArray"
+
+
 def test_decode_status_after_the_workspace_is_released(simt_lib):
     """the token of an unverified check = 0 decode outlives zn_release_workspace; the answer is then an error, once, not "ok"."""
     d = gen_bytes("bf16", 2 * C, 4)
