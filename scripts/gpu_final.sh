@@ -21,6 +21,6 @@ echo "== bench under torch.distributed.run, one rank (the RCCL path) =="
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-dtypes --no-plugin 2>/dev/null | grep "^{" > "$OUT/bench_rccl_1rank.json"; python -c "
 import json,sys; j=json.load(open('$OUT/bench_rccl_1rank.json')); print('rccl_ranks', j['rccl_ranks'], 'value', j['value'], 'llama8b', j['llama8b']['value'], j['llama8b']['n_gpus'])"
 echo "== PMC per dtype =="; bash scripts/gpu_pmc_dtypes.sh "${TAG}_pmc" "bf16 fp16 fp32 fp8" > "$OUT/pmc.log" 2>&1; tail -2 "$OUT/pmc.log"
-echo "== host path =="; timeout 300 python scripts/host_path_check.py 2>&1 | grep -v amdgpu | grep -E "one shot|automatic|streaming" | tee "$OUT/host_path.txt"
+echo "== host path =="; timeout 300 python scripts/host_path_check.py 2>&1 | grep -v amdgpu | grep "host-buffer" | tee "$OUT/host_path.txt"
 du -sh "$R/gpurun_out"
 echo "== done =="
