@@ -106,11 +106,15 @@ def compress_device_to_frame(lib, header, flat, num_buf, bits_mode, bytes_mode, 
     """Device tensor -> host frame bytes (header ‖ body); only compressed bytes cross PCIe."""
     body = compress_device(lib, flat, num_buf, bits_mode, bytes_mode, chunk, threshold)
     hl = len(header)
-    frame = new_bytearray(hl + body.numel())
-    frame[:hl] = header
+    total = hl + body.numel()
+    # (from 8 MiB up a block of the library's pinned arena — ZnLib.host_buffer —: the body then crosses PCIe as one DMA into memory that needs no page faults and
+    #  goes back to the arena, not to munmap, when the caller drops the frame; the caller sees a memoryview either way, as from the reference's extension)
+    frame = lib.host_buffer(total) if hasattr(lib, "host_buffer") and total >= getattr(lib, "HOST_ARENA_MIN", 1 << 62) else new_bytearray(total)
+    fv = memoryview(frame).cast("B")
+    fv[:hl] = bytes(header)
     if hl >= 32:
-        frame[24:32] = len(frame).to_bytes(8, "little")   # what the reference core writes at zipnn_core.c:121
-    to_host(lib, body, memoryview(frame)[hl:])
+        fv[24:32] = total.to_bytes(8, "little")           # what the reference core writes at zipnn_core.c:121
+    to_host(lib, body, fv[hl:])
     return frame
 
 

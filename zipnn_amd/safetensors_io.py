@@ -126,15 +126,17 @@ def _compress_file_on_device(filename, out_path, dev, method):
         arena, offs, lens = codec.compress_device_batch(lib, [(blob[lo:hi], P, bits, byts, chunk, th) for (_, lo, hi, _, _, P, bits, byts, chunk, th) in batch],
                                                        gap=GAP, return_arena=True)
         end = max(o + n for o, n in zip(offs, lens))
-        host = codec.to_host(lib, arena[:end])                                     # one transfer: every body (and the unused tail of every slot in between)
+        # one transfer: every body (and the unused tail of every slot in between), into a block of the library's pinned arena (one DMA, no page faults, nothing to munmap)
+        host = codec.to_host(lib, arena[:end], out=lib.host_buffer(end))
+        hv = memoryview(host).cast("B")
         for (name, lo, hi, like, hdr, *_), o, n in zip(batch, offs, lens):
             total = len(hdr) + n
             if total >= hi - lo:                                                   # did not shrink: stored as it was
                 tensors[name] = blob[lo:hi].cpu().view(like.dtype).reshape(like.shape)
                 continue
             s0 = o - len(hdr)
-            host[s0:o] = hdr
-            host[s0 + 24: s0 + 32] = total.to_bytes(8, "little")                   # what the core writes at zipnn_core.c:121
+            hv[s0:o] = bytes(hdr)
+            hv[s0 + 24: s0 + 32] = total.to_bytes(8, "little")                     # what the core writes at zipnn_core.c:121
             tensors[name] = torch.frombuffer(host, dtype=COMPRESSED_DTYPE, offset=s0, count=total)
             infos[name] = build_compressed_tensor_info(like)
     if not metadata:
