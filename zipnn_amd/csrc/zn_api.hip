@@ -458,7 +458,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
   if ((rc = ws_reserve(w, WS_ENC, all_pk))) return rc;                       // … and the same per (plane, chunk)
   const uint64_t all_tail = tail_of[0] + tail_of[1] + tail_of[2];
   if ((rc = ws_reserve(w, WS_PLANES, all_tail * ZN_TAIL_SLOT))) return rc;   // decoded Huffman planes of partial last chunks
-  const size_t sync_off = (all_tail + 15u) & ~(size_t)15u;                   // … and whether the tail kernel produced them; behind that two flag words per tensor with a partial chunk
+  const size_t sync_off = (4u * all_tail + 15u) & ~(size_t)15u;              // … and whether the tail workgroups produced them (four flag bytes per plane: one per huff0 stream); behind that two flag words per tensor with a partial chunk
   if ((rc = ws_reserve(w, WS_META_A, sync_off + 2u * sizeof(uint32_t) * all_tail))) return rc;
   if ((rc = ws_reserve(w, WS_WORDS, ZN_WORDS_BYTES))) return rc;
   if ((rc = ws_host_words(w))) return rc;
@@ -521,7 +521,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     uint8_t* d_done = (uint8_t*)w.buf[WS_META_B] + k_base;
     ZnPlaneDesc* d_descs = (ZnPlaneDesc*)w.buf[WS_META_C] + pk_base;
     uint8_t* d_tails = (uint8_t*)w.buf[WS_PLANES] + tail_base * ZN_TAIL_SLOT;
-    uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + tail_base;
+    uint8_t* d_tail_done = (uint8_t*)w.buf[WS_META_A] + 4u * tail_base;
     uint8_t* d_pdone = (uint8_t*)w.buf[WS_ENC] + pk_base;
     // (behind the wide kernel, in launches without partial chunks, the fused kernel's rest instance also does the generic kernels' job)
     // (round 5, three boxes, interleaved: at 4 GiB the plain instance + the two generic launches behind it decode 1.0-1.4 % FASTER than the rest instance alone —
@@ -1379,11 +1379,11 @@ long long zn_last_tail_planes(void) {
     std::lock_guard<std::mutex> lk(g_dev_mu[dev]);
     Workspace& w = g_ws[dev];
     if (!w.last_tails || !w.buf[WS_META_A]) return 0;
-    std::string flags(w.last_tails, '\0');
+    std::string flags(4u * w.last_tails, '\0');     // (four flag bytes per plane: one per huff0 stream)
     ZN_HIP(hipDeviceSynchronize());
-    ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_A], w.last_tails, hipMemcpyDeviceToHost));
+    ZN_HIP(hipMemcpy(&flags[0], w.buf[WS_META_A], 4u * w.last_tails, hipMemcpyDeviceToHost));
     long long n = 0;
-    for (char f : flags) n += (f != 0);
+    for (size_t i = 0; i < w.last_tails; i++) n += (flags[4 * i] && flags[4 * i + 1] && flags[4 * i + 2] && flags[4 * i + 3]);
     return n;
   } catch (...) { return ZN_E_ALLOC; }
 }

@@ -671,11 +671,23 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   return ok && carry == b0 && J == seg && JF >= seg;
 }
 
-// (b = index of the tail workgroup inside the launch; runs as the FIRST workgroups of zn_k_decode_fused, so that
-// the one-workgroup job overlaps the decode of the full chunks instead of following it)
-__device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t b,
+// The Huffman-coded planes of a PARTIAL last chunk.  Round 6: FOUR workgroups per plane, one per huff0 stream (bt = 4 · plane + stream; the first
+// workgroups of zn_k_decode_fused, so that the job overlaps the decode of the full chunks instead of following it).  Each parses the tree description and fills the
+// look-up table for itself (13 + 5 µs, side by side on four CUs); then its four waves SHARE the stream the way the small-input kernel's do (zn_wide_chunk, one-stream form:
+// in round r wave q takes tile 4 r + q, the tiles' tops guess their start like every sub-block does) — a stream's five or six tiles take two rounds instead of six
+// tile times on one wave, which is what a ragged tensor of a few hundred chunks waited for (100 MiB + 250 KB: 108 µs against 77 without the tail).  A stream whose code
+// is not of that form's density (dense codes, very short codes) is decoded by wave 0 alone with zn_fused_wave, as all four were until round 5.  Into a padded scratch
+// slot: stream w's symbols start at slot + w * ZN_TAIL_SEGPAD, the last, incomplete row of a stream is stored whole; tail_done[4 plane + stream] = 1 where it worked —
+// the merge workgroups / the generic merge kernel take a plane whose four flags are set from the scratch, anything else (raw / RLE / tiny planes, tableLog 12,
+// malformed blocks) is left to the serial generic code.
+__device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t bt,
+                                  uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status, uint32_t* tail0_out);
+#include "zn_decode_wide.hpp"
+
+__device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t bt,
                                   uint8_t* __restrict__ scratch, uint8_t* __restrict__ tail_done, uint32_t* __restrict__ status, uint32_t* tail0_out) {
   ZnFusedLds& L = *ZN_LDS_PTR(ZnFusedLds, &L_);     // (this is a real call: keep the LDS accesses DS operations)
+  const uint32_t b = bt >> 2, sq = zn_uniform(bt & 3u);     // tail plane of the launch / huff0 stream of its block
   const ZnSeg S = zn_find_seg<3>(one, segs, nseg, b);
   *tail0_out = S.tail0;
   const ZnGeom g = S.g;
@@ -698,34 +710,56 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg*
   const int hs = st.hs; const uint32_t TL = st.tl;
   if (hs < 0 || TL > ZN_F_TLMAX || (uint32_t)hs >= m.csize || m.csize - (uint32_t)hs < 10u) return;
   __syncthreads();                             // (ring[0] held the parser's scratch)
-  zn_fused_fill_luts(L, tid, TL, 0);
+  zn_fused_fill_luts(L, tid, TL, 0, zn_uniform(st.lmin));
   const uint8_t* js = src + hs; const uint32_t rem = m.csize - (uint32_t)hs;
-  const uint32_t l1 = zn_ld16(js), l2 = zn_ld16(js + 2), l3 = zn_ld16(js + 4);
+  const uint32_t l1 = zn_uniform(zn_ld16(js)), l2 = zn_uniform(zn_ld16(js + 2)), l3 = zn_uniform(zn_ld16(js + 4));
   if (l1 + l2 + l3 + 6u > rem) return;
   const uint32_t l4 = rem - 6u - l1 - l2 - l3;
   if (l1 == 0 || l2 == 0 || l3 == 0 || l4 == 0) return;
   const uint32_t seg3 = (m.plen + 3u) / 4u;
   if (3u * seg3 >= m.plen) return;
-  const uint32_t segw = (wave < 3u) ? seg3 : m.plen - 3u * seg3;
-  const uint32_t so = 6u + (wave > 0 ? l1 : 0u) + (wave > 1 ? l2 : 0u) + (wave > 2 ? l3 : 0u);
-  const uint8_t* stream = js + so; const uint32_t slen = (wave == 0) ? l1 : (wave == 1) ? l2 : (wave == 2) ? l3 : l4;
+  const uint32_t segw = (sq < 3u) ? seg3 : m.plen - 3u * seg3;        // this workgroup's stream: its symbols …
+  const uint32_t so = 6u + (sq > 0 ? l1 : 0u) + (sq > 1 ? l2 : 0u) + (sq > 2 ? l3 : 0u);
+  const uint8_t* stream = js + so; const uint32_t slen = (sq == 0) ? l1 : (sq == 1) ? l2 : (sq == 2) ? l3 : l4;      // … and its bytes
   __syncthreads();                             // lut16 (aliasing ring[0]) is dead from here on
 
   constexpr uint32_t UNIT1 = 64u * 16u;        // row of the single-plane instance
   ZnFusedPlane pl[1]; pl[0].off = m.off; pl[0].kind = ZN_KIND_HUF; pl[0].csize = m.csize;
-  const uint8_t* rawq[1] = {nullptr};
-  uint8_t* outq = scratch + (uint64_t)b * ZN_TAIL_SLOT + (uint64_t)wave * ZN_TAIL_SEGPAD;
+  uint8_t* outq = scratch + (uint64_t)b * ZN_TAIL_SLOT + (uint64_t)sq * ZN_TAIL_SEGPAD;
   uint32_t Du = ((ZN_F_RING_BYTES - UNIT1 - 128u) * slen) / (256u * segw);
   Du = Du > ZN_F_DMAX ? ZN_F_DMAX : (Du < 1u ? 1u : Du);
+  // the shared form takes the density the small-input kernel takes (the fused kernel's 4-dword sub-blocks, not its dense-code instance; same rule as zn_k_decode_wide)
+  // (… measured the way that kernel measures it — against the row of a TWO-plane tensor: its rule is about the code's bits per symbol, ≥ 2.4, and the tile slots of
+  //  4-dword sub-blocks; this function's own one-plane rows would make a bf16 exponent stream "3 dwords" — which is also why, until round 5, every bf16 / fp32 tail
+  //  ran the looping form: Du == 3 has no compile-time instance)
+  const uint32_t Dw = ((ZN_F_RING_BYTES - 512u - 128u) * slen) / (256u * segw);
+  const bool dense = Dw > 4u && zn_uniform(st.lmin) >= ZN_F_DENSE_LMIN;
+  const bool shared_form = Dw >= 4u && !dense && (Dw == 4u || zn_uniform(st.dom) < ZN_F_DOM_MAX);
   if (ZN_F_DCAP && Du > ZN_F_DCAP && st.dom < ZN_F_DOM_MAX) Du = ZN_F_DCAP;
   Du = (uint32_t)__builtin_amdgcn_readfirstlane((int)Du);
-  const bool ok = (Du == ZN_F_DCONST)
-    ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
-    : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[wave], L.in[wave], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
-  if (lane == 0) L.what[wave] = ok ? 1u : 0u;
-  __syncthreads();
+  bool ok = false;
+  if (shared_form) {
+    ok = zn_wide_chunk<1, 0, 4, ZnTailWideLds, true>(*reinterpret_cast<ZnTailWideLds*>(&L), g, body, body_end, outq, pl, segw, TL, js, l1, l2, l3, l4, sq);
+#if defined(ZN_SIMT_EMULATOR)
+    if (tid == 0) zn_dbg_tiles[ok ? 7 : 5]++;            // (emulated build: tail streams decoded by the shared form / attempts that gave up)
+#endif
+  }
+  if (!ok) {
+    // (one wave, the stream's tiles one after the other: the form of rounds 1-5 — also behind a shared-form attempt that gave up: it has written nothing that this does not overwrite)
+    __syncthreads();
+    const uint8_t* rawq[1] = {nullptr};
+    bool ok1 = true;
+    if (wave == 0) {
+      ok1 = (Du == ZN_F_DCONST)
+        ? zn_fused_wave<1, 0, ZN_F_DCONST>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[0], L.in[0], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS)
+        : zn_fused_wave<1, 0, 0>(g, body, body_end, outq, nullptr, pl, rawq, L.lut, L.ring[0], L.in[0], lane, segw, TL, Du, stream, slen, true ZN_PT_PASS);
+      if (lane == 0) L.what[0] = ok1 ? 1u : 0u;
+    }
+    __syncthreads();
+    ok = L.what[0] != 0u;
+  }
   if (tid == 0) {
-    if (L.what[0] & L.what[1] & L.what[2] & L.what[3]) tail_done[b] = 1;
+    if (ok) tail_done[bt] = 1;
     else atomicOr(status, ZN_DEV_CORRUPT);
   }
   ZN_PT_FLUSH();
@@ -821,7 +855,7 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint64_t c = S.g.K - 1u;
     __shared__ uint32_t ok_s, serial_s;
-    if (tid == 0) { ok_s = zn_flag_wait(tailsync + 2u * tt, (uint32_t)P) ? 1u : 0u; serial_s = 0; ZN_FLAG_ACQUIRE(); }      // (one lane's acquire drops this CU's L1 lines: the tail workgroups' bytes come from L2)
+    if (tid == 0) { ok_s = zn_flag_wait(tailsync + 2u * tt, 4u * (uint32_t)P) ? 1u : 0u; serial_s = 0; ZN_FLAG_ACQUIRE(); }      // (one lane's acquire drops this CU's L1 lines: the tail workgroups' bytes come from L2)
     __syncthreads();
     if (!ok_s) { if (tid == 0) atomicOr(status, ZN_DEV_SYNC_TIMEOUT); return; }     // (a slow or preempted device is not a corrupt frame: ZN_E_TIMEOUT)
     static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS");
@@ -1016,12 +1050,6 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   ZN_PT_FLUSH();
 }
 
-#include "zn_decode_wide.hpp"
-
-// The Huffman-coded planes of a PARTIAL last chunk: one workgroup per plane, wave w = stream w, with the same
-// parallel stream decoder (its single-plane instance), into a padded scratch slot: stream w's symbols start at
-// slot + w * ZN_TAIL_SEGPAD.  The generic merge kernel interleaves from there.  Anything unusual (raw / RLE /
-// tiny planes, tableLog 12, malformed blocks) is left to the serial generic kernel: tail_done stays 0.
 #ifdef ZN_PHASE_TIMERS
 extern "C" int zn_debug_phase_read(unsigned long long* out, int reset) {
   if (hipDeviceSynchronize() != hipSuccess) return -2;
@@ -1093,7 +1121,8 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   // launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9); partial last chunks (ntail > 0) are finished by merge workgroups at the
   // end of the same launch (d_tailsync: two zeroed words per tensor with a partial chunk) — except behind the wide kernel, which keeps the generic launches
   if (delta || (ntail != 0 && (wide || !d_tailsync))) d_descs_rest = nullptr;
-  const uint32_t ntt = ntail / (uint32_t)P;      // tensors with a partial last chunk
+  const uint32_t ntt = ntail / (uint32_t)P;      // tensors with a partial last chunk (ntail: their Huffman-plane slots, P per tensor)
+  uint32_t ntail_wg = 4u * ntail;                // … decoded by four workgroups per plane, one per huff0 stream (zn_decode_tail_wg)
   uint32_t merge_per = 0;
   if (d_descs_rest && ntail) { merge_per = 32u; while (merge_per > 1u && (uint64_t)merge_per * ntt > 4096u) merge_per >>= 1; }
   else d_tailsync = nullptr;
@@ -1103,16 +1132,16 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   if (wide) {
     // small inputs: one 16-wave workgroup per chunk first; the fused kernel behind it takes what that one left pending (and the tails)
     const uint32_t zs = (!status_zeroed && ntail == 0) ? 1u : 0u;
-#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail, d_tail_scratch, d_tail_done)
+#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail_wg), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail_wg, d_tail_scratch, d_tail_done)
     if (wide == 4) { if (P == 1) ZN_GOW(1, 4); else if (P == 2) ZN_GOW(2, 4); else ZN_GOW(4, 4); }
     else { if (P == 1) ZN_GOW(1, 2); else if (P == 2) ZN_GOW(2, 2); else ZN_GOW(4, 2); }
 #undef ZN_GOW
     zn_note_kernel(wide == 4 ? (ntail ? "zn_k_decode_wide+tail" : "zn_k_decode_wide") : (ntail ? "zn_k_decode_wide^2+tail" : "zn_k_decode_wide^2"));
-    ntail = 0;                                   // (done: the launch below has none)
+    ntail = 0; ntail_wg = 0;                     // (done: the launch below has none)
   }
-  total_wg += ntail;                             // the tail workgroups come first
+  total_wg += ntail_wg;                          // the tail workgroups come first
   total_wg += merge_per * ntt;                   // … and the merge workgroups of the partial chunks last
-#define ZN_GO(P_, X_, R_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_, R_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail, d_tail_scratch, d_tail_done, only_pending, d_descs_rest, nchunk_wg, merge_per, d_tailsync)
+#define ZN_GO(P_, X_, R_) hipLaunchKernelGGL((zn_k_decode_fused<P_, X_, R_>), dim3(total_wg), dim3(ZN_F_THREADS), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, ntail_wg, d_tail_scratch, d_tail_done, only_pending, d_descs_rest, nchunk_wg, merge_per, d_tailsync)
   if (d_descs_rest) { if (P == 1) ZN_GO(1, false, true); else if (P == 2) ZN_GO(2, false, true); else ZN_GO(4, false, true); }
   else if (!delta) { if (P == 1) ZN_GO(1, false, false); else if (P == 2) ZN_GO(2, false, false); else ZN_GO(4, false, false); }
   else { if (P == 1) ZN_GO(1, true, false); else if (P == 2) ZN_GO(2, true, false); else ZN_GO(4, true, false); }

@@ -83,7 +83,9 @@ __device__ inline void zn_decode_plane_item(ZnPlanesLds& L, const ZnSeg& one, co
     else { d.kind = ZN_KIND_HUF; d.off = 0; }
   }
   if (bad) { d.kind = ZN_KIND_RLE; d.off = 0; }   // keep the merge kernel in bounds; output is discarded by the caller
-  if (!bad && d.kind == ZN_KIND_HUF && S.has_tail && c == g.K - 1u && tail_done && tail_done[S.tail0 + p]) {
+  // (four tail workgroups per plane, one per huff0 stream, each with a flag byte of its own: the plane is in the scratch when all four are set)
+  if (!bad && d.kind == ZN_KIND_HUF && S.has_tail && c == g.K - 1u && tail_done &&
+      (tail_done[4u * (S.tail0 + p)] & tail_done[4u * (S.tail0 + p) + 1u] & tail_done[4u * (S.tail0 + p) + 2u] & tail_done[4u * (S.tail0 + p) + 3u]) != 0) {
     d.kind = ZN_KIND_HUFS; d.off = (uint64_t)(S.tail0 + p) * ZN_TAIL_SLOT;       // already decoded by the tail workgroups of zn_k_decode_fused
   }
 

@@ -46,28 +46,46 @@ struct __attribute__((aligned(16))) ZnWideLds {
   uint32_t again[ZN_W_MAXFIX + 2];       // [i]: some wave decoded again in fix-up iteration i
   uint32_t rounds, fail;
 };
+// ONE stream by four waves (round 6): the layout of a TAIL workgroup — a partial last chunk's Huffman plane gets four of them, one per huff0 stream, at the front of
+// the fused launch —, laid over the fused kernel's own LDS allocation (its look-up table sits at the same offset; what follows it is dead once that table is filled)
+struct __attribute__((aligned(16))) ZnTailWideLds {
+  static constexpr uint32_t RING = 16384u;           // the stream's circular staging buffer: a round's four tiles (≤ ~3.5 KB each at this density) + the carried remainder
+  static constexpr uint32_t THREADS = 256u;
+  uint2 lut[1u << ZN_F_TLMAX];
+  uint32_t ring[1][RING / 4 + 4];
+  uint32_t in[4][ZN_W_IN_DW];
+  int32_t x_start[4], x_exit[4];
+  uint32_t x_n[4], x_flag[4];
+  uint32_t again[ZN_W_MAXFIX + 2];
+  uint32_t rounds, fail;
+};
+static_assert(sizeof(ZnTailWideLds) <= sizeof(ZnFusedLds), "the one-stream wide form lives in the fused kernel's LDS allocation");
 static_assert(sizeof(ZnWideLds<4>) <= 160u * 1024u, "ZnWideLds<4>: one workgroup per CU");
 static_assert(sizeof(ZnWideLds<2>) <= 80u * 1024u, "ZnWideLds<2>: two workgroups per CU");
 
 // One chunk, all 16 waves.  Returns (workgroup-uniform) whether the chunk was decoded; false = nothing usable was produced.
-template <int P, int H, int WPS>
-__device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
+// ONE (LDS = ZnTailWideLds, four waves): the workgroup decodes huff0 stream `s_one` alone — `seg` symbols, to outc (a padded scratch: the stream's last,
+// incomplete row is stored whole) — instead of the chunk's four streams side by side; one plane, no raw planes.
+template <int P, int H, int WPS, typename LDS = ZnWideLds<WPS>, bool ONE = false>
+__device__ __forceinline__ bool zn_wide_chunk(LDS& L, const ZnGeom& g, const uint8_t* __restrict__ body, const uint8_t* body_end,
                                               uint8_t* outc, const ZnFusedPlane (&pl)[P], uint32_t seg, uint32_t TL,
-                                              const uint8_t* js, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4) {
+                                              const uint8_t* js, uint32_t l1, uint32_t l2, uint32_t l3, uint32_t l4, uint32_t s_one = 0) {
+  static_assert(!ONE || (P == 1 && H == 0 && WPS == 4), "the one-stream form: a single Huffman plane by four waves");
   constexpr int EPL = (P == 1) ? 16 : 8, EW = EPL / 4;
   constexpr uint32_t UNIT = 64u * EPL;
   constexpr bool SPLIT = (P == 4) && (ZN_F_SPLIT4 != 0);      // four planes: a lane owns two runs of 4 symbols of a row (whole-sector stores; see zn_fused_wave)
   constexpr int RB = (P == 2) ? 8 : 4;      // rows of one flush batch: a wave's share of a round (the staging buffer holds ≤ 31 rows of 512 symbols, ≤ 15 of 1024) in one batch (two for 4 planes)
   constexpr int TF = ZN_F_TF(ZN_W_D), TB = 3, UF = (32 * ZN_W_D - 31) / 11;
   constexpr int32_t TD = ZN_W_TD;
-  constexpr uint32_t ZN_W_RING = ZnWideLds<WPS>::RING, ZN_W_THREADS = ZnWideLds<WPS>::THREADS;
-  const uint32_t tid = threadIdx.x, wave = zn_uniform(tid >> 6), s_id = wave / (uint32_t)WPS, q = wave % (uint32_t)WPS;
+  constexpr uint32_t ZN_W_RING = LDS::RING, ZN_W_THREADS = LDS::THREADS;
+  const uint32_t tid = threadIdx.x, wave = zn_uniform(tid >> 6), s_id = wave / (uint32_t)WPS, q = wave % (uint32_t)WPS;      // (ONE: four waves, s_id = 0: LDS indices only)
+  const uint32_t ss = ONE ? zn_uniform(s_one) : s_id;                  // which huff0 stream of the block
   uint32_t lane = zn_lane_id();
   uint32_t lane_v = lane; ZN_OPAQUE32(lane_v);
-  const uint32_t so = 6u + (s_id > 0 ? l1 : 0u) + (s_id > 1 ? l2 : 0u) + (s_id > 2 ? l3 : 0u);
+  const uint32_t so = 6u + (ss > 0 ? l1 : 0u) + (ss > 1 ? l2 : 0u) + (ss > 2 ? l3 : 0u);
   const uint8_t* const stream = zn_uniform_ptr(js + so);
-  const uint32_t slen = (s_id == 0) ? l1 : (s_id == 1) ? l2 : (s_id == 2) ? l3 : l4;
-  uint8_t* const outq = zn_uniform_ptr(outc + (uint64_t)s_id * (g.chunk / 4u));
+  const uint32_t slen = (ss == 0) ? l1 : (ss == 1) ? l2 : (ss == 2) ? l3 : l4;
+  uint8_t* const outq = zn_uniform_ptr(ONE ? outc : outc + (uint64_t)s_id * (g.chunk / 4u));
   const uint8_t* rawq[P];
   for (int p = 0; p < P; p++) rawq[p] = zn_uniform_ptr(body + pl[p].off + (uint64_t)s_id * seg);
   uint32_t* const ring = L.ring[s_id]; uint32_t* const in = L.in[wave];
@@ -296,6 +314,22 @@ __device__ __forceinline__ bool zn_wide_chunk(ZnWideLds<WPS>& L, const ZnGeom& g
       if (m0 + (uint32_t)WPS * RB >= rows_total) break;
     }
     if (sok) { J += Nr; JF += rows_total * UNIT; carry = expect; }
+  }
+  if constexpr (ONE) {
+    // the stream's last row is incomplete (a partial chunk's streams are not whole rows): stored whole by wave 0 — the destination is padded, the ring beyond the last
+    // symbol holds zeros
+    if (sok && carry == b0 && J == seg && JF < seg && J - JF < UNIT) {
+      if (q == 0) {
+        const uint32_t ra = JF & (ZN_W_RING - 1u);
+        const uint32_t ix = (ra + (uint32_t)EPL * lane) >> 2;
+        uint32_t t[EW];
+        for (int k = 0; k < EW; k++) t[k] = ring[ix + k];
+        if (ra == 0u && lane == 0) t[0] |= ring[ZN_W_RING / 4u];
+        uint8_t* o = (outq + (uint64_t)JF * P) + (uint32_t)EPL * (uint32_t)P * lane_v;
+        ZN_ST128(o, t[0], t[1 % EW], t[2 % EW], t[3 % EW]);
+      }
+      JF = seg;
+    }
   }
   if (!(sok && carry == b0 && J == seg && JF == seg)) { if (lane == 0) L.fail = 1u; }
   __syncthreads();
