@@ -274,7 +274,8 @@ inline int& zn_simt_current_device() { static thread_local int d = 0; return d; 
 static inline hipError_t hipGetDeviceCount(int* n) { *n = 2; return hipSuccess; }
 static inline hipError_t hipGetDevice(int* d) { *d = zn_simt_current_device(); return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 };
-static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 1; return hipSuccess; }
+// (the emulated device has ONE compute unit; a test that needs the host logic of a bigger one says ZN_SIMT_CUS=<n> in the environment)
+static inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { const char* e = getenv("ZN_SIMT_CUS"); const int n = e ? atoi(e) : 1; *v = n > 0 ? n : 1; return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= 2) return hipErrorInvalidValue; zn_simt_current_device() = d; return hipSuccess; }
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "zn_simt"; }

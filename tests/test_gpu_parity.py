@@ -173,12 +173,12 @@ def test_fused_decode_chunk_groups(lib, group, decode_group, request):
 @pytest.mark.parametrize("kind,P,rot,bm", [("bf16", 2, 1, 10), ("fp32", 4, 1, 220), ("fp16", 2, 0, 10), ("fp8", 1, 0, 10), ("slowsync", 2, 0, 10), ("mixed", 2, 0, 10)])
 def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, request):
     """zn_k_decode_wide (16 waves per chunk, four per huff0 stream, tile tops guessed and checked across waves): every mode of
-    zn_set_decode_wide gives the input back — 1, 7 + tail, 200 and 257 chunks, repeated (the waves of a workgroup race differently
+    zn_set_decode_wide gives the input back — 1, 7 + tail, 20 + a 1 KB tail, 200 and 257 chunks, repeated (the waves of a workgroup race differently
     every time), with the frame equal to the oracle's.  Automatic mode uses it up to one chunk per CU."""
     from test_kernels_simt import _gen2, _slow_sync_bf16
     request.addfinalizer(lambda: lib.set_decode_wide(1))
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    for nb in (C, 7 * C + C // 2 + 10, 200 * C, (cus + 1) * C, (2 * cus + 1) * C):
+    for nb in (C, 7 * C + C // 2 + 10, 20 * C + 1000, 200 * C, (cus + 1) * C, (2 * cus + 1) * C):
         if kind == "slowsync":
             d = _slow_sync_bf16(nb, 3)
         elif kind == "mixed":          # chunk by chunk: weights-like, incompressible, constant, two Huffman planes, dense
@@ -195,7 +195,8 @@ def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, reques
             used = lib.last_kernels().split(";")[0]
             full = nb // C
             want = {0: "zn_k_decode_fused", 2: "zn_k_decode_wide", 3: "zn_k_decode_wide^2",
-                    1: "zn_k_decode_fused" if rot != 1 or nb % C or full > 2 * cus else "zn_k_decode_wide" if full <= cus else "zn_k_decode_wide^2"}[mode]     # (automatic: sign-rotated layouts, whole chunks)
+                    1: "zn_k_decode_fused" if rot != 1 or full > 2 * cus or (nb % C and (full + 4 * P > cus or (nb % C) // P < 4096)) else "zn_k_decode_wide" if full <= cus else "zn_k_decode_wide^2"}[mode]
+            # (automatic: sign-rotated layouts; whole chunks — or, round 6, a partial last chunk long enough for the tail workgroups in a call whose chunks and tail workgroups get a CU each)
             assert used.split("+")[0].replace("^rest", "") == want, (used, mode, K)       # (a call of whole chunks: the fused kernel's rest instance, no generic launches)
             assert lib.last_fused_chunks() >= (nb // C if kind in ("bf16", "fp32", "fp16", "fp8", "slowsync") else 0)
 

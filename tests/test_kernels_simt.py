@@ -276,7 +276,7 @@ TAILS = [("bf16", C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 1
 
 
 @pytest.mark.parametrize("case", TAILS, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
-def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
+def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case, request, monkeypatch):
     """A big partial last chunk: its Huffman planes are decoded by the tail workgroups of zn_k_decode_fused (4 ragged streams into padded
     scratch), merge workgroups at the end of the SAME launch classify the chunk's planes and interleave them (round 5: the two generic launches
     behind every ragged tensor are gone); tiny / raw tails are decoded serially by those workgroups.  Output == input."""
@@ -285,11 +285,23 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case):
     frame = O.compress_frame(HDR, d, P, rot, bm, chunk)
     body = torch.frombuffer(bytearray(frame[32:]), dtype=torch.uint8)
     out = torch.empty(nb, dtype=torch.uint8)
+    request.addfinalizer(lambda: simt_lib.set_decode_wide(1))
+    simt_lib.set_decode_wide(0)                  # (the emulated device has one CU: automatic mode gives a call this small to the 16-wave form — below)
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
     assert out.numpy().tobytes() == d
     # one launch: tail workgroups at its front, the chunk's merge workgroups at its end, no generic kernels behind it
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
     assert simt_lib.last_tail_planes() == want_tail_planes
+    # automatic: a sign-rotated tensor whose full chunks AND tail workgroups find a CU each (an emulated device of 32 here), with a tail the tail workgroups take, rides
+    # the small-input kernel — tail workgroups at the front of ITS launch, the merge workgroups in the launch behind it (round 6)
+    simt_lib.set_decode_wide(1)
+    monkeypatch.setenv("ZN_SIMT_CUS", "32")
+    out.zero_()
+    simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
+    assert out.numpy().tobytes() == d
+    assert simt_lib.last_tail_planes() == want_tail_planes
+    small_call = rot == 1 and P > 1 and 1 <= nb // chunk and nb // chunk + 4 * P <= 32 and (nb % chunk) // P >= 4096
+    assert simt_lib.last_kernels() == ("zn_k_decode_wide+tail;zn_k_decode_fused^rest+merge" if small_call else "zn_k_decode_fused^rest+tail+merge")
 
 
 def test_corrupted_bodies_never_crash(simt_lib):
@@ -851,10 +863,10 @@ def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt
     assert cnt[4] == wide_chunks and cnt[5] == pending
     ks = simt_lib.last_kernels().split(";")
     name = "zn_k_decode_wide" if mode == 2 else "zn_k_decode_wide^2"
-    # without a partial chunk the fused kernel's `rest` instance is the only other launch (it decodes what neither takes with the generic path's own code);
-    # with one, the tail workgroups ride in the wide launch and the two generic kernels follow
+    # the fused kernel's `rest` instance is the only other launch (it decodes what neither takes with the generic path's own code); with a partial chunk
+    # the tail workgroups ride in the wide launch and the merge workgroups in the one behind it (round 6: it was two generic kernels more)
     if nb % C:
-        assert ks == [name + "+tail", "zn_k_decode_fused^pending", "zn_k_decode_planes", "zn_k_merge_planes"]
+        assert ks == [name + "+tail", "zn_k_decode_fused^rest+merge"]
     else:
         assert ks == [name, "zn_k_decode_fused^rest"]
     if kind == "slowsync":
@@ -866,7 +878,7 @@ def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt
     assert simt_lib.last_kernels().split(";")[0].startswith("zn_k_decode_fused") and "wide" not in simt_lib.last_kernels()
 
 
-def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(simt_lib, wide_mode):
+def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(simt_lib, wide_mode, monkeypatch):
     """Mode 1 (the default): sign-rotated layouts without a delta base, at most one full chunk per CU of the device (the emulated device has one CU)
     in the 16-wave form, at most two in the 8-wave form."""
     d1 = _gen2("bf16", C, 5); d2 = _gen2("bf16", 2 * C, 7); d3 = _gen2("bf16", 3 * C, 6)
@@ -878,10 +890,22 @@ def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(s
     assert simt_lib.last_kernels().startswith("zn_k_decode_wide^2")                 # two: the 8-wave form
     assert bytes(simt_lib.decompress(f3[32:], 2, 1, 10, C, len(d3))) == d3
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest"                      # three: the fused kernel (its rest instance: no generic launches behind a call of whole chunks)
-    dt = d1 + d1[:1000]                                                             # a partial last chunk: its tail workgroup + merge set the pace either way
+    dt = d1 + d1[:1000]                                                             # a partial last chunk too short for the tail workgroups (a serial decode): beside the bulk, in the fused launch
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"            # (… inside ONE launch since round 5)
+    dt = d1 + d1[:40000]                                                            # … one they take: its eight tail workgroups want CUs of their own beside the full chunks'
+    ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
+    assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
+    assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
+    monkeypatch.setenv("ZN_SIMT_CUS", "9")                                          # … on a device of nine CUs: the 16-wave form, tail workgroups in its launch, merge workgroups in the one behind (round 6)
+    assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
+    assert simt_lib.last_kernels() == "zn_k_decode_wide+tail;zn_k_decode_fused^rest+merge"
+    dt = d2 + d1[:40000]                                                            # … but never the 8-wave form (the launch behind it cannot start before it ends: measured slower than the fused launch)
+    ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
+    assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
+    assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
+    monkeypatch.delenv("ZN_SIMT_CUS")
     f16 = O.compress_frame(HDR, d1, 2, 0, 10, C)                                    # no sign rotate (an fp16 layout): not in automatic mode
     assert bytes(simt_lib.decompress(f16[32:], 2, 0, 10, C, len(d1))) == d1
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest"

@@ -698,7 +698,7 @@ __device__ void zn_decode_tail_wg(ZnFusedLds& L_, const ZnSeg& one, const ZnSeg*
   const uint64_t c = g.K - 1u;
   ZN_PT_DECL;
   const ZnPcMeta m = zn_pc_meta(g, body, body_len, p, c);
-  if (!(m.ok && m.type == 1u && m.csize > 1u && m.csize < m.plen && m.plen >= 4096u && m.plen <= 4u * ZN_TAIL_SEGPAD)) return;
+  if (!(m.ok && m.type == 1u && m.csize > 1u && m.csize < m.plen && m.plen >= ZN_TAIL_WG_MIN_PLANE && m.plen <= 4u * ZN_TAIL_SEGPAD)) return;
   const uint8_t* src = body + m.off;
   if (wave == 0) {
     uint8_t* tmp = (uint8_t*)&L.ring[0][0];
@@ -1091,7 +1091,7 @@ uint32_t zn_decode_fused_group(uint64_t K) {
 // is an exponent byte; measured: fp16 / fp8 calls only pay the extra parse, 2-12 us); up to two chunks per CU its 8-wave form, two workgroups per CU.
 // Returns the waves per stream (4 / 2) or 0.  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 / 3 = always the 16- / 8-wave form.
 static std::atomic<int> g_zn_decode_wide{1};
-int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like) {     // weights_like: sign-rotated layouts, no partial last chunk
+int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like, uint64_t tail_wgs) {     // weights_like: sign-rotated layouts, no partial chunk too short for the tail workgroups; tail_wgs: the tail workgroups of the call's partial last chunks
   const int mode = g_zn_decode_wide.load(std::memory_order_relaxed);
   if (mode == 0 || delta || K == 0) return 0;
   if (mode == 2) return 4;
@@ -1100,7 +1100,7 @@ int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like) {     // weigh
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return 0; }
-  return K <= (uint64_t)cus ? 4 : K <= 2ull * (uint64_t)cus ? 2 : 0;
+  return K + tail_wgs <= (uint64_t)cus ? 4 : (K <= 2ull * (uint64_t)cus && tail_wgs == 0) ? 2 : 0;
 }
 extern "C" int zn_set_decode_wide(int mode) {
   if (mode < 0 || mode > 3) return -1;     // ZN_E_ARG
@@ -1119,8 +1119,8 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
                             uint8_t* d_tail_done, bool delta, int wide, bool status_zeroed, ZnPlaneDesc* d_descs_rest, uint32_t* d_tailsync, hipStream_t stream) {
   // the rest instance: every launch without delta bases (its tile loops run as fast as the plain instance's — measured, 160 MiB .. 4 GiB — and the two generic
   // launches behind it are saved: 256 MiB 128.4 -> 125.9 us, 4 GiB 1514.9 -> 1512.9); partial last chunks (ntail > 0) are finished by merge workgroups at the
-  // end of the same launch (d_tailsync: two zeroed words per tensor with a partial chunk) — except behind the wide kernel, which keeps the generic launches
-  if (delta || (ntail != 0 && (wide || !d_tailsync))) d_descs_rest = nullptr;
+  // end of the same launch (d_tailsync: two zeroed words per tensor with a partial chunk); behind the wide kernel, whose launch has the tail workgroups, the merge workgroups of this one find their reports in
+  if (delta || (ntail != 0 && !d_tailsync)) d_descs_rest = nullptr;
   const uint32_t ntt = ntail / (uint32_t)P;      // tensors with a partial last chunk (ntail: their Huffman-plane slots, P per tensor)
   uint32_t ntail_wg = 4u * ntail;                // … decoded by four workgroups per plane, one per huff0 stream (zn_decode_tail_wg)
   uint32_t merge_per = 0;
@@ -1132,12 +1132,12 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   if (wide) {
     // small inputs: one 16-wave workgroup per chunk first; the fused kernel behind it takes what that one left pending (and the tails)
     const uint32_t zs = (!status_zeroed && ntail == 0) ? 1u : 0u;
-#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail_wg), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail_wg, d_tail_scratch, d_tail_done)
+#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail_wg), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail_wg, d_tail_scratch, d_tail_done, d_tailsync)
     if (wide == 4) { if (P == 1) ZN_GOW(1, 4); else if (P == 2) ZN_GOW(2, 4); else ZN_GOW(4, 4); }
     else { if (P == 1) ZN_GOW(1, 2); else if (P == 2) ZN_GOW(2, 2); else ZN_GOW(4, 2); }
 #undef ZN_GOW
     zn_note_kernel(wide == 4 ? (ntail ? "zn_k_decode_wide+tail" : "zn_k_decode_wide") : (ntail ? "zn_k_decode_wide^2+tail" : "zn_k_decode_wide^2"));
-    ntail = 0; ntail_wg = 0;                     // (done: the launch below has none)
+    ntail_wg = 0;                                // (done: the launch below has none — its merge workgroups, if any, find the reports of the wide launch's)
   }
   total_wg += ntail_wg;                          // the tail workgroups come first
   total_wg += merge_per * ntt;                   // … and the merge workgroups of the partial chunks last
@@ -1146,6 +1146,6 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   else if (!delta) { if (P == 1) ZN_GO(1, false, false); else if (P == 2) ZN_GO(2, false, false); else ZN_GO(4, false, false); }
   else { if (P == 1) ZN_GO(1, true, false); else if (P == 2) ZN_GO(2, true, false); else ZN_GO(4, true, false); }
 #undef ZN_GO
-  zn_note_kernel(d_descs_rest ? (ntail ? "zn_k_decode_fused^rest+tail+merge" : "zn_k_decode_fused^rest") : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
+  zn_note_kernel(d_descs_rest ? (ntail ? (wide ? "zn_k_decode_fused^rest+merge" : "zn_k_decode_fused^rest+tail+merge") : "zn_k_decode_fused^rest") : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
   return d_descs_rest != nullptr;
 }

@@ -343,7 +343,8 @@ template <int P, int WPS>
 __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, const ZnSeg* __restrict__ segs, uint32_t nseg,
                                                                     uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                     uint32_t* __restrict__ status, uint32_t zero_status, uint32_t ntail,
-                                                                    uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done) {
+                                                                    uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done,
+                                                                    uint32_t* __restrict__ tailsync) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnWideLds<WPS> L;
@@ -354,8 +355,12 @@ __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, cons
   if (blockIdx.x < ntail) {
     if (threadIdx.x >= ZN_F_THREADS) return;
     const ZnSeg one_c = one;                       // (a copy on this path only: see zn_k_decode_fused)
-    uint32_t tail0_unused = 0;
-    zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status, &tail0_unused);
+    uint32_t tail0 = 0;
+    zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status, &tail0);
+    if (tailsync) {                              // (the merge workgroups of the launch BEHIND this one count the reports, as they do inside a fused launch)
+      __syncthreads();
+      if (threadIdx.x == 0) { ZN_FLAG_RELEASE(); ZN_FLAG_ADD32(tailsync + 2u * (tail0 / (uint32_t)P), 1u); }
+    }
     return;
   }
   const uint32_t wg = blockIdx.x - ntail;

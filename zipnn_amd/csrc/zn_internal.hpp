@@ -50,7 +50,7 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
 // !status_zeroed: … and zeroes the status words (the call's first launch: the caller then leaves out its memset);
 // d_descs_rest (used when the launch has no tail workgroups and no delta base): the fused kernel's `rest` instance decodes what it does not take with the generic
 // path's own code (zn_decode_rest.hpp) — returns true then, and the caller leaves out zn_launch_decode_generic
-int zn_decode_use_wide(uint64_t total_full_chunks, bool delta, bool weights_like);     // weights_like: every tensor of the call is split with the sign rotate (bf16 / fp32)
+int zn_decode_use_wide(uint64_t total_full_chunks, bool delta, bool weights_like, uint64_t tail_wgs);     // weights_like: every tensor of the call is split with the sign rotate (bf16 / fp32)
 
 // ---- encode ----
 struct ZnEncDesc {           // per (plane, chunk): what the emit kernel needs for a plane kept as huff0 / RLE
