@@ -3,7 +3,7 @@ import sys, time, torch
 sys.path.insert(0, ".")
 from zipnn_amd import _capi, codec
 lib = _capi.lib(); dev = torch.device("cuda:0")
-for n in ((64 << 20) + 250000, (60 << 20) + 250000, (100 << 20) + 250 * 1024 + 2, (8 << 20) + 3000, (8 << 20) + 100000, (16 << 20) + 200000, (32 << 20) + 70000):
+for n in ((64 << 20) + 250000, (60 << 20) + 250000, (126 << 20) + 250000, (128 << 20) + 250000, (100 << 20) + 250 * 1024 + 2, (8 << 20) + 3000, (8 << 20) + 100000, (16 << 20) + 200000, (32 << 20) + 70000):
     g = torch.Generator(device=dev); g.manual_seed(1)
     x = (torch.randn(n // 2, generator=g, device=dev) * 0.02).to(torch.bfloat16)
     flat = codec.flat_bytes(x)

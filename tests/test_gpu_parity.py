@@ -194,9 +194,10 @@ def test_wide_decoder_for_small_inputs_on_hardware(lib, kind, P, rot, bm, reques
                 assert bytes(lib.decompress(frame[32:], P, rot, bm, C, nb)) == d, (kind, nb, mode)
             used = lib.last_kernels().split(";")[0]
             full = nb // C
+            slots = full + (4 * P if nb % C else 0)
             want = {0: "zn_k_decode_fused", 2: "zn_k_decode_wide", 3: "zn_k_decode_wide^2",
-                    1: "zn_k_decode_fused" if rot != 1 or full > 2 * cus or (nb % C and (full + 4 * P > cus or (nb % C) // P < 4096)) else "zn_k_decode_wide" if full <= cus else "zn_k_decode_wide^2"}[mode]
-            # (automatic: sign-rotated layouts; whole chunks — or, round 6, a partial last chunk long enough for the tail workgroups in a call whose chunks and tail workgroups get a CU each)
+                    1: "zn_k_decode_fused" if rot != 1 or slots > 2 * cus else "zn_k_decode_wide" if slots <= cus else "zn_k_decode_wide^2"}[mode]
+            # (automatic: sign-rotated layouts whose full chunks and — round 6 — tail workgroups find a workgroup slot each: one per CU in the 16-wave form, two in the 8-wave form)
             assert used.split("+")[0].replace("^rest", "") == want, (used, mode, K)       # (a call of whole chunks: the fused kernel's rest instance, no generic launches)
             assert lib.last_fused_chunks() >= (nb // C if kind in ("bf16", "fp32", "fp16", "fp8", "slowsync") else 0)
 

@@ -292,16 +292,17 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case, req
     # one launch: tail workgroups at its front, the chunk's merge workgroups at its end, no generic kernels behind it
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
     assert simt_lib.last_tail_planes() == want_tail_planes
-    # automatic: a sign-rotated tensor whose full chunks AND tail workgroups find a CU each (an emulated device of 32 here), with a tail the tail workgroups take, rides
-    # the small-input kernel — tail workgroups at the front of ITS launch, the merge workgroups in the launch behind it (round 6)
+    # automatic: a sign-rotated tensor whose full chunks AND tail workgroups find a slot each (an emulated device of 32 CUs here) rides the small-input kernel —
+    # tail workgroups at the front of ITS launch, the merge workgroups at its end (round 6)
     simt_lib.set_decode_wide(1)
     monkeypatch.setenv("ZN_SIMT_CUS", "32")
     out.zero_()
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
     assert out.numpy().tobytes() == d
     assert simt_lib.last_tail_planes() == want_tail_planes
-    small_call = rot == 1 and P > 1 and 1 <= nb // chunk and nb // chunk + 4 * P <= 32 and (nb % chunk) // P >= 4096
-    assert simt_lib.last_kernels() == ("zn_k_decode_wide+tail;zn_k_decode_fused^rest+merge" if small_call else "zn_k_decode_fused^rest+tail+merge")
+    slots = nb // chunk + 4 * P                  # full chunks + tail workgroups
+    form = None if not (rot == 1 and P > 1 and nb // chunk >= 1 and slots <= 64) else "zn_k_decode_wide" if slots <= 32 else "zn_k_decode_wide^2"
+    assert simt_lib.last_kernels() == (form + "+tail+merge;zn_k_decode_fused^rest" if form else "zn_k_decode_fused^rest+tail+merge")
 
 
 def test_corrupted_bodies_never_crash(simt_lib):
@@ -846,14 +847,14 @@ def _slow_sync_bf16(nbytes, seed):
 
 
 @pytest.mark.parametrize("kind,nb,P,rot,bm,wide_chunks,pending", [
-    ("bf16", 3 * C, 2, 1, 10, 3, 0), ("fp32", 2 * C, 4, 1, 220, 2, 0), ("bf16", 2 * C + C // 2 + 10, 2, 1, 10, 2, 1), ("fp32", C + C // 4 + 4, 4, 1, 220, 1, 1),
+    ("bf16", 3 * C, 2, 1, 10, 3, 0), ("fp32", 2 * C, 4, 1, 220, 2, 0), ("bf16", 2 * C + C // 2 + 10, 2, 1, 10, 2, 0), ("fp32", C + C // 4 + 4, 4, 1, 220, 1, 0),
     ("fp8", 2 * C, 1, 0, 10, 0, 2), ("fp16", 2 * C, 2, 0, 10, 0, 2), ("rand", 2 * C, 2, 1, 10, 0, 2), ("const", 2 * C, 2, 1, 10, 0, 2), ("slowsync", 3 * C, 2, 0, 10, 3, 0)],
     ids=["bf16", "fp32", "bf16-tail", "fp32-tail", "fp8-dense-code", "fp16-dense-code", "raw-planes", "rle-planes", "slow-sync"])
 @pytest.mark.parametrize("mode", [2, 3], ids=["16-waves", "8-waves"])
 def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt_lib, wide_mode, mode, kind, nb, P, rot, bm, wide_chunks, pending):
     """Forced on (mode 2): the full chunks of weights-like tensors are decoded by zn_k_decode_wide (counter 4 of the emulated build); dense codes,
-    chunks without exactly one Huffman plane and partial last chunks are left pending (counter 5) and taken by the fused kernel behind it — same
-    bytes in every case.  The slow-sync tensor makes some tile tops guess wrong: those tiles are decoded again (counter 6)."""
+    chunks without exactly one Huffman plane are left pending (counter 5) and taken by the fused kernel behind it; a partial last chunk is finished
+    by the tail and merge workgroups of the wide launch itself (round 6) — same bytes in every case.  The slow-sync tensor makes some tile tops guess wrong: those tiles are decoded again (counter 6)."""
     d = _slow_sync_bf16(nb, 4) if kind == "slowsync" else _gen2(kind, nb, 23)
     frame = O.compress_frame(HDR, d, P, rot, bm, C)
     wide_mode(mode)                        # 2: four waves per stream (16-wave workgroups), 3: two (8-wave workgroups, two per CU)
@@ -864,9 +865,9 @@ def test_wide_decoder_takes_weights_like_chunks_and_leaves_the_rest_pending(simt
     ks = simt_lib.last_kernels().split(";")
     name = "zn_k_decode_wide" if mode == 2 else "zn_k_decode_wide^2"
     # the fused kernel's `rest` instance is the only other launch (it decodes what neither takes with the generic path's own code); with a partial chunk
-    # the tail workgroups ride in the wide launch and the merge workgroups in the one behind it (round 6: it was two generic kernels more)
+    # the tail workgroups ride at the front of the wide launch and the merge workgroups at its end (round 6: it was the pending pass + two generic kernels)
     if nb % C:
-        assert ks == [name + "+tail", "zn_k_decode_fused^rest+merge"]
+        assert ks == [name + "+tail+merge", "zn_k_decode_fused^rest"]
     else:
         assert ks == [name, "zn_k_decode_fused^rest"]
     if kind == "slowsync":
@@ -890,21 +891,21 @@ def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(s
     assert simt_lib.last_kernels().startswith("zn_k_decode_wide^2")                 # two: the 8-wave form
     assert bytes(simt_lib.decompress(f3[32:], 2, 1, 10, C, len(d3))) == d3
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest"                      # three: the fused kernel (its rest instance: no generic launches behind a call of whole chunks)
-    dt = d1 + d1[:1000]                                                             # a partial last chunk too short for the tail workgroups (a serial decode): beside the bulk, in the fused launch
+    dt = d1 + d1[:1000]                                                             # a partial last chunk: its eight tail workgroups want slots beside the full chunks' — one CU has two
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"            # (… inside ONE launch since round 5)
-    dt = d1 + d1[:40000]                                                            # … one they take: its eight tail workgroups want CUs of their own beside the full chunks'
+    dt = d1 + d1[:40000]                                                            # … whatever its length
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
     monkeypatch.setenv("ZN_SIMT_CUS", "9")                                          # … on a device of nine CUs: the 16-wave form, tail workgroups in its launch, merge workgroups in the one behind (round 6)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
-    assert simt_lib.last_kernels() == "zn_k_decode_wide+tail;zn_k_decode_fused^rest+merge"
-    dt = d2 + d1[:40000]                                                            # … but never the 8-wave form (the launch behind it cannot start before it ends: measured slower than the fused launch)
+    assert simt_lib.last_kernels() == "zn_k_decode_wide+tail+merge;zn_k_decode_fused^rest"
+    dt = d2 + d1[:1000]                                                             # … ten workgroups on nine CUs: the 8-wave form (two per CU), whatever the length of the tail
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
-    assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
+    assert simt_lib.last_kernels() == "zn_k_decode_wide^2+tail+merge;zn_k_decode_fused^rest"
     monkeypatch.delenv("ZN_SIMT_CUS")
     f16 = O.compress_frame(HDR, d1, 2, 0, 10, C)                                    # no sign rotate (an fp16 layout): not in automatic mode
     assert bytes(simt_lib.decompress(f16[32:], 2, 0, 10, C, len(d1))) == d1

@@ -411,13 +411,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (items[i].chunk) full_chunks += items[i].orig_size / items[i].chunk;
     // (tensors without the sign rotate — fp16, fp8, integers: their Huffman planes are dense codes, which the wide kernel parses and declines)
     if (!(items[i].bits_mode == 1 && items[i].num_buf > 1)) all_rotated = false;
-    // (… a partial last chunk: its tail workgroups ride at the front of the wide launch, its merge workgroups in the launch behind it — which cannot start before
-    //  the wide one is through, where the fused launch merges beside its bulk: the 16-wave form still wins (32 MiB + 70 KB: 66 µs against 86), the 8-wave form does
-    //  not (100 MiB + 250 KB: 98 against 92), and a tail too short for the tail workgroups is one serial decode behind everything (8 MiB + 3 KB: 120 against 84))
-    if (items[i].chunk && items[i].orig_size % items[i].chunk) {
-      tail_wgs += 4u * (uint64_t)(items[i].num_buf > 0 ? items[i].num_buf : 1);      // (they take workgroup slots of the same launch: 64 MiB + 250 KB = 256 chunks + 8 took two rounds on 256 CUs, 113 µs)
-      if ((items[i].orig_size % items[i].chunk) / (size_t)(items[i].num_buf > 0 ? items[i].num_buf : 1) < ZN_TAIL_WG_MIN_PLANE) all_rotated = false;
-    }
+    // (… a partial last chunk: its tail workgroups ride at the front of the wide launch and its merge workgroups at the end of it, as in a fused launch; the tail
+    //  workgroups take workgroup slots of their own — 64 MiB + 250 KB = 256 chunks + 8 took two rounds of the 16-wave form on 256 CUs, 113 µs against the 8-wave form's 73)
+    if (items[i].chunk && items[i].orig_size % items[i].chunk) tail_wgs += 4u * (uint64_t)(items[i].num_buf > 0 ? items[i].num_buf : 1);
   }
   const int wide = zn_decode_use_wide(full_chunks, any_delta, all_rotated, tail_wgs);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
   uint32_t ncg_of[3];

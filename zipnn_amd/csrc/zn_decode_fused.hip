@@ -671,6 +671,38 @@ __device__ __forceinline__ bool zn_fused_wave(const ZnGeom& g, const uint8_t* __
   return ok && carry == b0 && J == seg && JF >= seg;
 }
 
+// A MERGE workgroup of a tensor's partial last chunk (four waves; index m among the launch's merge workgroups, `merge_per` per tensor): waits until the tensor's
+// tail workgroups — lower block indices of the same launch — have all reported (tailsync[2 t]), classifies the chunk's planes (the generic path's own item function,
+// every merge workgroup for itself) and merges its share of the chunk's words into the output.  Shared by zn_k_decode_fused (REST) and zn_k_decode_wide.
+template <int P>
+__device__ __forceinline__ void zn_tail_merge_wg(ZnFusedLds& L, const ZnSeg& one_c, const ZnSeg* __restrict__ segs, uint32_t nseg, uint32_t m, uint32_t merge_per,
+                                                 uint32_t* __restrict__ tailsync, ZnPlaneDesc* __restrict__ descs_rest, uint32_t* __restrict__ status,
+                                                 uint8_t* __restrict__ tail_done, uint8_t* __restrict__ tail_scratch) {
+  const uint32_t tt = m / merge_per, jm = m % merge_per;
+  const ZnSeg S = zn_find_seg<3>(one_c, segs, nseg, (uint64_t)tt * (uint32_t)P);
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const uint64_t c = S.g.K - 1u;
+  __shared__ uint32_t ok_s, serial_s;
+  if (tid == 0) { ok_s = zn_flag_wait(tailsync + 2u * tt, 4u * (uint32_t)P) ? 1u : 0u; serial_s = 0; ZN_FLAG_ACQUIRE(); }      // (one lane's acquire drops this CU's L1 lines: the tail workgroups' bytes come from L2)
+  __syncthreads();
+  if (!ok_s) { if (tid == 0) atomicOr(status, ZN_DEV_SYNC_TIMEOUT); return; }     // (a slow or preempted device is not a corrupt frame: ZN_E_TIMEOUT)
+  static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS");
+  // every merge workgroup classifies the chunk's planes for itself (the same descriptors from all of them: raw / RLE / decoded by the tail workgroups) …
+  if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane, true, &serial_s);
+  __syncthreads();
+  if (tid == 0) ZN_FLAG_ACQUIRE();             // (the descriptors were written by other waves of this CU: read them from L2, not from a stale L1 line)
+  __syncthreads();
+  uint32_t sub = jm, nsub = merge_per;           // this workgroup's share of the chunk's words
+  if (serial_s) {
+    // … unless a huff0 plane is left for the serial decoder (a tiny plane, tableLog 12, a block the tail workgroup gave up on): ONE workgroup does the chunk
+    if (jm != 0u) return;
+    if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane);
+    __threadfence(); __syncthreads();
+    sub = 0; nsub = 1;
+  }
+  zn_merge_chunk_item<P>(one_c, segs, nseg, S.chunk0 + c, sub, descs_rest, tail_scratch, nsub);
+}
+
 // The Huffman-coded planes of a PARTIAL last chunk.  Round 6: FOUR workgroups per plane, one per huff0 stream (bt = 4 · plane + stream; the first
 // workgroups of zn_k_decode_fused, so that the job overlaps the decode of the full chunks instead of following it).  Each parses the tree description and fills the
 // look-up table for itself (13 + 5 µs, side by side on four CUs); then its four waves SHARE the stream the way the small-input kernel's do (zn_wide_chunk, one-stream form:
@@ -849,30 +881,8 @@ __global__ __launch_bounds__(ZN_F_THREADS, ZN_F_WAVES_PER_SIMD) void zn_k_decode
   // (the generic merge's item function, its 64 sub-ranges dealt out) — the two generic launches behind every call of a ragged tensor (20-30 us) are gone.
   // The tail workgroups have the lowest block indices and the merge workgroups are few: the wait is for workgroups that run or have run (and it is bounded).
   if (REST && tailsync && blockIdx.x >= ntail + nchunk_wg) {
-    const uint32_t m = blockIdx.x - (ntail + nchunk_wg), tt = m / merge_per, jm = m % merge_per;
     const ZnSeg one_c = one;
-    const ZnSeg S = zn_find_seg<3>(one_c, segs, nseg, (uint64_t)tt * (uint32_t)P);
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    const uint64_t c = S.g.K - 1u;
-    __shared__ uint32_t ok_s, serial_s;
-    if (tid == 0) { ok_s = zn_flag_wait(tailsync + 2u * tt, 4u * (uint32_t)P) ? 1u : 0u; serial_s = 0; ZN_FLAG_ACQUIRE(); }      // (one lane's acquire drops this CU's L1 lines: the tail workgroups' bytes come from L2)
-    __syncthreads();
-    if (!ok_s) { if (tid == 0) atomicOr(status, ZN_DEV_SYNC_TIMEOUT); return; }     // (a slow or preempted device is not a corrupt frame: ZN_E_TIMEOUT)
-    static_assert(4u * sizeof(ZnPlanesLds) <= sizeof(ZnFusedLds), "four generic plane decoders fit over the fused kernel's LDS");
-    // every merge workgroup classifies the chunk's planes for itself (the same descriptors from all of them: raw / RLE / decoded by the tail workgroups) …
-    if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane, true, &serial_s);
-    __syncthreads();
-    if (tid == 0) ZN_FLAG_ACQUIRE();             // (the descriptors were written by other waves of this CU: read them from L2, not from a stale L1 line)
-    __syncthreads();
-    uint32_t sub = jm, nsub = merge_per;           // this workgroup's share of the chunk's words
-    if (serial_s) {
-      // … unless a huff0 plane is left for the serial decoder (a tiny plane, tableLog 12, a block the tail workgroup gave up on): ONE workgroup does the chunk
-      if (jm != 0u) return;
-      if (wave < (uint32_t)P) zn_decode_plane_item(reinterpret_cast<ZnPlanesLds*>(&L)[wave], one_c, segs, nseg, S.desc0 + (uint64_t)wave * S.g.K + c, descs_rest, status, tail_done, lane);
-      __threadfence(); __syncthreads();
-      sub = 0; nsub = 1;
-    }
-    zn_merge_chunk_item<P>(one_c, segs, nseg, S.chunk0 + c, sub, descs_rest, tail_scratch, nsub);
+    zn_tail_merge_wg<P>(L, one_c, segs, nseg, blockIdx.x - (ntail + nchunk_wg), merge_per, tailsync, descs_rest, status, tail_done, tail_scratch);
     return;
   }
 
@@ -1091,7 +1101,7 @@ uint32_t zn_decode_fused_group(uint64_t K) {
 // is an exponent byte; measured: fp16 / fp8 calls only pay the extra parse, 2-12 us); up to two chunks per CU its 8-wave form, two workgroups per CU.
 // Returns the waves per stream (4 / 2) or 0.  zn_set_decode_wide (include/zipnn_hip.h): 0 = never, 1 = automatic, 2 / 3 = always the 16- / 8-wave form.
 static std::atomic<int> g_zn_decode_wide{1};
-int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like, uint64_t tail_wgs) {     // weights_like: sign-rotated layouts, no partial chunk too short for the tail workgroups; tail_wgs: the tail workgroups of the call's partial last chunks
+int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like, uint64_t tail_wgs) {     // weights_like: sign-rotated layouts; tail_wgs: the tail workgroups of the call's partial last chunks (they want slots beside the full chunks')
   const int mode = g_zn_decode_wide.load(std::memory_order_relaxed);
   if (mode == 0 || delta || K == 0) return 0;
   if (mode == 2) return 4;
@@ -1100,7 +1110,7 @@ int zn_decode_use_wide(uint64_t K, bool delta, bool weights_like, uint64_t tail_
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) { (void)hipGetLastError(); return 0; }
-  return K + tail_wgs <= (uint64_t)cus ? 4 : (K <= 2ull * (uint64_t)cus && tail_wgs == 0) ? 2 : 0;
+  return K + tail_wgs <= (uint64_t)cus ? 4 : K + tail_wgs <= 2ull * (uint64_t)cus ? 2 : 0;
 }
 extern "C" int zn_set_decode_wide(int mode) {
   if (mode < 0 || mode > 3) return -1;     // ZN_E_ARG
@@ -1132,12 +1142,12 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   if (wide) {
     // small inputs: one 16-wave workgroup per chunk first; the fused kernel behind it takes what that one left pending (and the tails)
     const uint32_t zs = (!status_zeroed && ntail == 0) ? 1u : 0u;
-#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail_wg), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail_wg, d_tail_scratch, d_tail_done, d_tailsync)
+#define ZN_GOW(P_, W_) hipLaunchKernelGGL((zn_k_decode_wide<P_, W_>), dim3(total_wg + ntail_wg + merge_per * ntt), dim3(256 * W_), 0, stream, one, d_segs, nseg, d_done, d_pdone, d_status, zs, ntail_wg, d_tail_scratch, d_tail_done, d_tailsync, d_descs_rest, nchunk_wg, merge_per)
     if (wide == 4) { if (P == 1) ZN_GOW(1, 4); else if (P == 2) ZN_GOW(2, 4); else ZN_GOW(4, 4); }
     else { if (P == 1) ZN_GOW(1, 2); else if (P == 2) ZN_GOW(2, 2); else ZN_GOW(4, 2); }
 #undef ZN_GOW
-    zn_note_kernel(wide == 4 ? (ntail ? "zn_k_decode_wide+tail" : "zn_k_decode_wide") : (ntail ? "zn_k_decode_wide^2+tail" : "zn_k_decode_wide^2"));
-    ntail_wg = 0;                                // (done: the launch below has none — its merge workgroups, if any, find the reports of the wide launch's)
+    zn_note_kernel(wide == 4 ? (ntail ? (merge_per ? "zn_k_decode_wide+tail+merge" : "zn_k_decode_wide+tail") : "zn_k_decode_wide") : (ntail ? (merge_per ? "zn_k_decode_wide^2+tail+merge" : "zn_k_decode_wide^2+tail") : "zn_k_decode_wide^2"));
+    ntail_wg = 0; merge_per = 0; d_tailsync = nullptr;   // (done, merge workgroups included: the launch below has neither — the partial chunks' done flags say "not pending")
   }
   total_wg += ntail_wg;                          // the tail workgroups come first
   total_wg += merge_per * ntt;                   // … and the merge workgroups of the partial chunks last
@@ -1146,6 +1156,6 @@ bool zn_launch_decode_fused(int P, const ZnSeg& one, const ZnSeg* d_segs, uint32
   else if (!delta) { if (P == 1) ZN_GO(1, false, false); else if (P == 2) ZN_GO(2, false, false); else ZN_GO(4, false, false); }
   else { if (P == 1) ZN_GO(1, true, false); else if (P == 2) ZN_GO(2, true, false); else ZN_GO(4, true, false); }
 #undef ZN_GO
-  zn_note_kernel(d_descs_rest ? (ntail ? (wide ? "zn_k_decode_fused^rest+merge" : "zn_k_decode_fused^rest+tail+merge") : "zn_k_decode_fused^rest") : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
+  zn_note_kernel(d_descs_rest ? (ntail && !wide ? "zn_k_decode_fused^rest+tail+merge" : "zn_k_decode_fused^rest") : wide ? "zn_k_decode_fused^pending" : delta ? (ntail ? "zn_k_decode_fused^delta+tail" : "zn_k_decode_fused^delta") : (ntail ? "zn_k_decode_fused+tail" : "zn_k_decode_fused"));
   return d_descs_rest != nullptr;
 }

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, cons
                                                                     uint8_t* __restrict__ done_all, uint8_t* __restrict__ pdone_all,
                                                                     uint32_t* __restrict__ status, uint32_t zero_status, uint32_t ntail,
                                                                     uint8_t* __restrict__ tail_scratch, uint8_t* __restrict__ tail_done,
-                                                                    uint32_t* __restrict__ tailsync) {
+                                                                    uint32_t* __restrict__ tailsync, ZnPlaneDesc* __restrict__ descs_rest, uint32_t nchunk_wg, uint32_t merge_per) {
   constexpr int EPL = (P == 1) ? 16 : 8;
   constexpr uint32_t UNIT = 64u * EPL;
   __shared__ ZnWideLds<WPS> L;
@@ -357,10 +357,17 @@ __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, cons
     const ZnSeg one_c = one;                       // (a copy on this path only: see zn_k_decode_fused)
     uint32_t tail0 = 0;
     zn_decode_tail_wg(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x, tail_scratch, tail_done, status, &tail0);
-    if (tailsync) {                              // (the merge workgroups of the launch BEHIND this one count the reports, as they do inside a fused launch)
+    if (tailsync) {                              // (the merge workgroups at the end of this grid count the reports, as they do inside a fused launch)
       __syncthreads();
       if (threadIdx.x == 0) { ZN_FLAG_RELEASE(); ZN_FLAG_ADD32(tailsync + 2u * (tail0 / (uint32_t)P), 1u); }
     }
+    return;
+  }
+  // … and their merge workgroups (round 6; the fused kernel's own: zn_tail_merge_wg) at its END: a ragged call is finished inside this launch, beside its
+  // full chunks — in a launch of its own behind this one the merge cost a ragged call of 400 chunks 20 µs
+  if (tailsync && blockIdx.x >= ntail + nchunk_wg) {       // (all of this workgroup's waves: the plane items are per wave, the merge strides by the workgroup's size)
+    const ZnSeg one_c = one;
+    zn_tail_merge_wg<P>(*reinterpret_cast<ZnFusedLds*>(&L), one_c, segs, nseg, blockIdx.x - (ntail + nchunk_wg), merge_per, tailsync, descs_rest, status, tail_done, tail_scratch);
     return;
   }
   const uint32_t wg = blockIdx.x - ntail;
@@ -379,6 +386,10 @@ __global__ __launch_bounds__(256 * WPS, 4) void zn_k_decode_wide(ZnSeg one, cons
   const uint32_t plen = (uint32_t)(g.chunk / P), seg = plen / 4u;
   const uint8_t* body_end = body + body_len;
   if (c >= g.K) return;
+  if (tailsync && zn_uniform(S_.has_tail) && c == g.K - 1u) {          // the partial last chunk: the tail + merge workgroups of this launch ("not by the fused kernels", and not pending)
+    if (tid == 0) done[c] = 0; if (tid < (uint32_t)P) pdone[(uint64_t)tid * g.K + c] = 0;
+    return;
+  }
 
   if (tid < (uint32_t)P) {
     const uint32_t p = tid;
