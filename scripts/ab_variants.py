@@ -30,7 +30,7 @@ VARIANTS = {
     "c1": ("HEAD", []),                             # the last commit
     # the kernels of earlier rounds (their -D switches are gone from the tree: round 6 made the settled ones constants; a variant of an old switch is built from
     # the commit that still had it, e.g. ("741f196", ["-DZN_F_RB2=4"]))
-    "r01": ("fb215d2", []), "r02": ("8959d1d", []), "r03": ("3c0f9d7", []), "r04a": ("5b359c5", []), "r05": ("741f196", []),
+    "r01": ("fb215d2", []), "r02": ("8959d1d", []), "r03": ("3c0f9d7", []), "r04a": ("5b359c5", []), "r05": ("741f196", []), "r06g": ("61a3fa5", []),
     # compiler scheduling options (same sources)
     "ilp": (None, ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
     "iter": (None, ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]),
