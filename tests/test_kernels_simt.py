@@ -272,7 +272,7 @@ def test_batched_decode_matches_per_tensor_decode(simt_lib):
 
 TAILS = [("bf16", C + C // 2 + 10, 2, 1, 10, C, 1), ("bf16", C // 2 + 3, 2, 1, 10, C, 1), ("fp32", 2 * C + C // 2 + 4, 4, 1, 220, C, 1),
          ("fp8", C + 20001, 1, 1, 10, C, 1), ("fp16", 3 * C - 2, 2, 0, 10, C, 1), ("skew", C + 30000, 2, 0, 10, C, 2),
-         ("burst", 40001, 1, 1, 10, C, 1), ("rand", C + 30000, 2, 1, 10, C, 0), ("bf16", C + 4000, 2, 1, 10, C, 0)]
+         ("burst", 40001, 1, 1, 10, C, 1), ("rand", C + 30000, 2, 1, 10, C, 0), ("bf16", C + 4000, 2, 1, 10, C, 1), ("bf16", C + 800, 2, 1, 10, C, 0)]      # (the last one: a plane of 400 bytes, below ZN_TAIL_WG_MIN_PLANE — the merge workgroup decodes it serially)
 
 
 @pytest.mark.parametrize("case", TAILS, ids=lambda c: f"{c[0]}-{c[1]}-P{c[2]}")
@@ -295,13 +295,13 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(simt_lib, case, req
     # automatic: a sign-rotated tensor whose full chunks AND tail workgroups find a slot each (an emulated device of 32 CUs here) rides the small-input kernel —
     # tail workgroups at the front of ITS launch, the merge workgroups at its end (round 6)
     simt_lib.set_decode_wide(1)
-    monkeypatch.setenv("ZN_SIMT_CUS", "32")
+    monkeypatch.setenv("ZN_SIMT_CUS", "48")
     out.zero_()
     simt_lib.decompress_dev(body.data_ptr(), body.numel(), P, rot, bm, chunk, nb, out.data_ptr())
     assert out.numpy().tobytes() == d
     assert simt_lib.last_tail_planes() == want_tail_planes
-    slots = nb // chunk + 4 * P                  # full chunks + tail workgroups
-    form = None if not (rot == 1 and P > 1 and nb // chunk >= 1 and slots <= 64) else "zn_k_decode_wide" if slots <= 32 else "zn_k_decode_wide^2"
+    slots = nb // chunk + 4 * P + 32             # full chunks + tail workgroups + merge workgroups
+    form = None if not (rot == 1 and P > 1 and nb // chunk >= 1 and slots <= 96) else "zn_k_decode_wide" if slots <= 48 else "zn_k_decode_wide^2"
     assert simt_lib.last_kernels() == (form + "+tail+merge;zn_k_decode_fused^rest" if form else "zn_k_decode_fused^rest+tail+merge")
 
 
@@ -899,10 +899,10 @@ def test_wide_decoder_automatic_mode_is_for_calls_of_at_most_two_chunks_per_cu(s
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
     assert simt_lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge"
-    monkeypatch.setenv("ZN_SIMT_CUS", "9")                                          # … on a device of nine CUs: the 16-wave form, tail workgroups in its launch, merge workgroups in the one behind (round 6)
+    monkeypatch.setenv("ZN_SIMT_CUS", "41")                                         # … on a device of 41 CUs (1 chunk + 8 tail + 32 merge workgroups): the 16-wave form, tail workgroups in its launch, merge workgroups in the one behind (round 6)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
     assert simt_lib.last_kernels() == "zn_k_decode_wide+tail+merge;zn_k_decode_fused^rest"
-    dt = d2 + d1[:1000]                                                             # … ten workgroups on nine CUs: the 8-wave form (two per CU), whatever the length of the tail
+    dt = d2 + d1[:1000]                                                             # … 42 workgroups on 41 CUs: the 8-wave form (two per CU), whatever the length of the tail
     ft = O.compress_frame(HDR, dt, 2, 1, 10, C)
     assert bytes(simt_lib.decompress(ft[32:], 2, 1, 10, C, len(dt))) == dt
     assert simt_lib.last_kernels() == "zn_k_decode_wide^2+tail+merge;zn_k_decode_fused^rest"

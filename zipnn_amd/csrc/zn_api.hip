@@ -413,7 +413,7 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     if (!(items[i].bits_mode == 1 && items[i].num_buf > 1)) all_rotated = false;
     // (… a partial last chunk: its tail workgroups ride at the front of the wide launch and its merge workgroups at the end of it, as in a fused launch; the tail
     //  workgroups take workgroup slots of their own — 64 MiB + 250 KB = 256 chunks + 8 took two rounds of the 16-wave form on 256 CUs, 113 µs against the 8-wave form's 73)
-    if (items[i].chunk && items[i].orig_size % items[i].chunk) tail_wgs += 4u * (uint64_t)(items[i].num_buf > 0 ? items[i].num_buf : 1);
+    if (items[i].chunk && items[i].orig_size % items[i].chunk) tail_wgs += 4u * (uint64_t)(items[i].num_buf > 0 ? items[i].num_buf : 1) + 32u;      // (… + the tensor's merge workgroups at the end of the grid)
   }
   const int wide = zn_decode_use_wide(full_chunks, any_delta, all_rotated, tail_wgs);       // small calls: a 16-wave workgroup per full chunk (zn_decode_wide.hpp)
   uint32_t ncg_of[3];

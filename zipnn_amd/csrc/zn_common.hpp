@@ -32,7 +32,7 @@
 #define ZN_KIND_HUFS 3u  // huff0 block of a partial last chunk, already decoded into the tail scratch (4 padded streams)
 #define ZN_TAIL_SEGPAD 32768u            // stride of a stream inside a tail-scratch slot (a huff0 block is ≤ 128 KiB)
 #define ZN_TAIL_SLOT (4u * ZN_TAIL_SEGPAD)
-#define ZN_TAIL_WG_MIN_PLANE 4096u       // a partial chunk's plane shorter than this is not worth four workgroups: the merge workgroup decodes it serially
+#define ZN_TAIL_WG_MIN_PLANE 512u        // a partial chunk's plane shorter than this is not worth four workgroups: the merge workgroup decodes it serially
 
 __device__ __forceinline__ uint32_t zn_hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 
