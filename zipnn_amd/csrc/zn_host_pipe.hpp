@@ -179,7 +179,11 @@ struct ZnArena {
     }
     const size_t cap = (n + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
     void* p = nullptr;
-    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      trim();                                      // (free blocks of other sizes may be what is in the way: hand them back and ask once more)
+      if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
     try { std::lock_guard<std::mutex> lk(m); blocks.push_back(Block{(uint8_t*)p, cap, true}); }
     catch (...) { (void)hipHostFree(p); return nullptr; }
     return p;
