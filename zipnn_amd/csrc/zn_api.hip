@@ -527,7 +527,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     // (round 5, three boxes, interleaved: at 4 GiB the plain instance + the two generic launches behind it decode 1.0-1.4 % FASTER than the rest instance alone —
     //  1.445 / 1.445 / 1.500 against 1.460 / 1.466 / 1.516 ms, profiles/r05_rest_instance_ab.txt —: the generic path's code in its cold paths costs the rest instance
     //  twelve spilled registers.  What it saves is two launches, ≈ 4-8 us: it is the instance of calls of up to ZN_REST_MAX_CHUNKS chunks.)
-    if (total_chunks > ZN_REST_MAX_CHUNKS) rest_ok[q] = false;
+    // (… unless the launch has partial chunks: their merge workgroups ride in the rest instance — 1.0-1.4 % of a large call — where the plain instance needs the two
+    //  generic launches behind it, and the generic merge of ONE partial chunk takes 33 µs: 1 GiB + 200 KB 451 µs that way)
+    if (total_chunks > ZN_REST_MAX_CHUNKS && tail_of[q] == 0) rest_ok[q] = false;
     const bool rest = zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
                                              d_tail_done, delta_of[q], wide, status_zeroed, rest_ok[q] ? d_descs : nullptr,
                                              tail_of[q] ? (uint32_t*)((uint8_t*)w.buf[WS_META_A] + sync_off) + 2u * tail_base : nullptr, stream);
