@@ -385,6 +385,7 @@ int zn_compress_batch_dev(zn_cbatch_item* items, size_t count, void* stream_) {
 // Decode `count` tensors in one set of launches per plane count.  A single tensor travels to the kernels as an
 // argument; a batch as a segment table in device memory.
 #define ZN_REST_MAX_CHUNKS 2048u          // (512 MiB of 256 KiB chunks)
+#define ZN_REST_TAIL_MAX_CHUNKS 24576u    // (6 GiB: a launch WITH partial chunks stays with the rest instance up to here)
 // A batch that mixes one-plane tensors (fp8: dense codes, the decode is LDS-bound at a fifth of the HBM roofline) with two- / four-plane ones (memory-bound) decodes
 // the two kinds CONCURRENTLY: the one-plane launches go to a second stream, forked from and joined to the caller's with events, so that the dispatcher fills a CU with
 // workgroups of both kernels — one kind waits on LDS look-ups while the other waits on HBM.  ZIPNN_AMD_DECODE_OVERLAP=0 keeps everything on the caller's stream.
@@ -528,8 +529,9 @@ static int decompress_items(const zn_batch_item* items, size_t count, hipStream_
     //  1.445 / 1.445 / 1.500 against 1.460 / 1.466 / 1.516 ms, profiles/r05_rest_instance_ab.txt —: the generic path's code in its cold paths costs the rest instance
     //  twelve spilled registers.  What it saves is two launches, ≈ 4-8 us: it is the instance of calls of up to ZN_REST_MAX_CHUNKS chunks.)
     // (… unless the launch has partial chunks: their merge workgroups ride in the rest instance — 1.0-1.4 % of a large call — where the plain instance needs the two
-    //  generic launches behind it, and the generic merge of ONE partial chunk takes 33 µs: 1 GiB + 200 KB 451 µs that way)
-    if (total_chunks > ZN_REST_MAX_CHUNKS && tail_of[q] == 0) rest_ok[q] = false;
+    //  generic launches behind it, and the generic merge of ONE partial chunk takes 33 µs: 1 GiB + 200 KB 445 µs that way, 417 this way; 4 GiB + 200 KB 1 573 / 1 555.
+    //  From about 6 GiB on the percent outweighs the 33 µs: the Llama-3-8B batch — 16 GB of bf16, its 8 KB norm vectors the partial chunks — 12.12 ms against 11.94)
+    if (total_chunks > ZN_REST_MAX_CHUNKS && (tail_of[q] == 0 || k_of[q] > ZN_REST_TAIL_MAX_CHUNKS)) rest_ok[q] = false;
     const bool rest = zn_launch_decode_fused(P, segs[q][0], d_segs, nseg, (uint32_t)wg_of[q], d_done, d_pdone, d_status, (uint32_t)tail_of[q], d_tails,
                                              d_tail_done, delta_of[q], wide, status_zeroed, rest_ok[q] ? d_descs : nullptr,
                                              tail_of[q] ? (uint32_t*)((uint8_t*)w.buf[WS_META_A] + sync_off) + 2u * tail_base : nullptr, stream);
