@@ -203,8 +203,9 @@ int zn_set_decode_group(int chunks_per_workgroup);
 int zn_decode_group_for(unsigned long long chunks);
 
 /* the small-input form of the decoder (one workgroup per chunk, four or two waves per huff0 stream) — 0 = never,
- * 1 (default) = automatic: calls whose tensors are all split with the sign rotate (bits_mode 1 with 2 or 4 byte planes: bf16, fp32), are whole
- * multiples of their chunk size, have no delta base and few chunks per compute unit of the device; 2 / 3 = every call without a
+ * 1 (default) = automatic: calls whose tensors are all split with the sign rotate (bits_mode 1 with 2 or 4 byte planes: bf16, fp32), have no
+ * delta base and few workgroups per compute unit of the device — one per full chunk, plus, for a tensor with a partial last chunk (round 6), its tail
+ * and merge workgroups, which ride in the same launch; 2 / 3 = every call without a
  * delta base, 16- / 8-wave form.  The bytes produced are the same in every mode.  Returns 0 or ZN_E_ARG. */
 int zn_set_decode_wide(int mode);
 
