@@ -391,6 +391,32 @@ def test_partial_last_chunk_through_the_parallel_tail_kernel(lib, case):
     assert lib.last_tail_planes() == want_tail_planes
 
 
+def test_large_ragged_tensor_keeps_its_merge_inside_the_launch(lib):
+    """More than ZN_REST_MAX_CHUNKS chunks + a partial one (round 6): the launch takes the rest instance — tail workgroups in front, merge workgroups at its end — instead of
+    the plain instance + the generic merge kernel behind it; exact bytes, and a small tail (a plane of 1 500 bytes: from 512 bytes up the tail workgroups take it).
+    An even tensor of the same size still takes the plain instance and the (idle) generic launches."""
+    from zipnn_amd import codec
+    dev = torch.device("cuda:0")
+    for tail, tail_planes in ((200000, 1), (3000, 1), (600, 0)):
+        n = 2100 * C + tail
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        x = (torch.randn(n // 2, generator=g, device=dev) * 0.02).to(torch.bfloat16)
+        flat = codec.flat_bytes(x)
+        body = codec.compress_device(lib, flat, 2, 1, 10, C, 0.95).clone()
+        out = torch.full((n,), 0x5A, dtype=torch.uint8, device=dev)
+        for _ in range(3):
+            codec.decompress_device(lib, body, 2, 1, 10, C, n, out=out)
+            assert torch.equal(out, flat)
+        assert lib.last_kernels() == "zn_k_decode_fused^rest+tail+merge" and lib.last_tail_planes() == tail_planes
+        del x, flat, body, out
+    n = 2100 * C
+    x = (torch.randn(n // 2, device=dev) * 0.02).to(torch.bfloat16)
+    flat = codec.flat_bytes(x)
+    body = codec.compress_device(lib, flat, 2, 1, 10, C, 0.95).clone()
+    assert torch.equal(codec.decompress_device(lib, body, 2, 1, 10, C, n), flat)
+    assert lib.last_kernels() == "zn_k_decode_fused;zn_k_decode_planes;zn_k_merge_planes"
+
+
 def test_streaming_blob_decodes_in_one_batched_launch(lib):
     """is_streaming BYTE frames (1 MiB each): the decompress side parses every header on the host and decodes all
     frames with one batched launch; bytes equal the input, and a delta (XOR) second buffer composes."""
