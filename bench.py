@@ -274,6 +274,25 @@ def multi_dev_inprocess(lib, codec, n_bytes=1 << 30):
         return {"devices": nd, "error": repr(e)[:300]}
 
 
+def multi_dev_isolated(timeout_s=240):
+    """multi_dev_inprocess in a CHILD process with a time limit.  The fan-out over several devices in one process has never run on more than one real GPU (the builder
+    box has one): on the first box that has several, whatever it does — an exception, a crash, a hang — must not take the bench line with it."""
+    import subprocess
+    nd = torch.cuda.device_count()
+    if nd < 2:
+        return None
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--multi-dev-leg"], capture_output=True, text=True, timeout=timeout_s)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{") or ln == "null":
+                return json.loads(ln)
+        return {"devices": nd, "error": f"child rc={r.returncode}: " + (r.stderr or "")[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"devices": nd, "error": f"child process timed out after {timeout_s} s and was killed (the rest of this line was measured before it)"}
+    except Exception as e:       # noqa: BLE001
+        return {"devices": nd, "error": repr(e)[:300]}
+
+
 def host_info():
     """What BASELINE.md §3 wants next to every CPU number."""
     info = {"nproc": os.cpu_count() or 1, "cpu_model": None, "numa_nodes": None,
@@ -758,8 +777,13 @@ def main():
     ap.add_argument("--no-other-dtypes", action="store_true")
     ap.add_argument("--no-plugin", action="store_true", help="skip plugin_gpt2 (BASELINE.json configs[3])")
     ap.add_argument("--no-llama8b", action="store_true", help="skip the llama8b sub-run on the default line (BASELINE.json configs[4])")
+    ap.add_argument("--multi-dev-leg", action="store_true", help="(internal) run only the in-process multi-device leg and print its JSON: the child of multi_dev_isolated()")
     ap.add_argument("--cpu-sample-mib", type=int, default=4096, help="bytes of the tensor the CPU reference is timed on and the GPU frame is compared on")
     args = ap.parse_args()
+    if args.multi_dev_leg:                       # the child of multi_dev_isolated(): its own process, its own contexts on every device, one JSON value on stdout
+        from zipnn_amd import _capi, codec
+        print(json.dumps(multi_dev_inprocess(_capi.lib(), codec)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -917,8 +941,6 @@ def main():
             line["plugin_gpt2"] = plugin_gpt2(lib, device)
         if world == 1 and not args.no_plugin:
             line["host_path"] = host_path(lib, device)
-        if world == 1:
-            line["multi_dev_inprocess"] = multi_dev_inprocess(lib, codec)
         if world == 1 and not args.no_cpu_baseline:
             sample = min(args.cpu_sample_mib << 20, n_bytes) // CHUNK * CHUNK
             if sample:
@@ -926,6 +948,11 @@ def main():
                 fs = codec.flat_bytes(xs)
                 sbody = body if sample == n_bytes else codec.compress_device(lib, fs, P, ROT, BMODE, CHUNK, THR)
                 line["cpu_baseline"] = cpu_baseline(fs.cpu().numpy(), sbody.cpu().numpy())
+                del xs, fs, sbody
+        if world == 1:                           # (last, and in a child process with a time limit: first contact with several devices in one process)
+            del body
+            torch.cuda.empty_cache()
+            line["multi_dev_inprocess"] = multi_dev_isolated()
         print(json.dumps(line), flush=True)
     if dist:
         td.barrier()

@@ -93,3 +93,18 @@ def test_design_quotes_the_binary_s_register_and_spill_counts(hip_lib):
     assert stated is not None, "DESIGN.md lost its codeobj block"
     assert stated == m.table().strip(), "DESIGN.md's register/spill table differs from the built code objects: python scripts/codeobj_stats.py --write"
     assert "(not in this build)" not in stated
+
+
+def test_bench_runs_its_multi_device_leg_in_a_child_process_with_a_time_limit(monkeypatch):
+    """bench.py's in-process fan-out over several devices has never met more than one real GPU: it runs in a child process, last, with a time limit, so that an
+    exception, a crash or a hang there cannot take the bench line down.  Here (no GPU): the child finds fewer than two devices and says `null`; a child that
+    does not finish in time is killed and the leg reports it."""
+    import sys
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.multi_dev_isolated() is None                      # fewer than two devices: nothing is started
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 2)
+    assert bench.multi_dev_isolated(timeout_s=600) is None         # the child (a real second process: it sees this machine's devices) prints null
+    r = bench.multi_dev_isolated(timeout_s=0.05)
+    assert r["devices"] == 2 and "timed out" in r["error"]
